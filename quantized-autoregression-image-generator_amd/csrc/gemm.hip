@@ -1,0 +1,199 @@
+// fp32 MFMA GEMM with fused epilogues: the contraction behind every Linear layer
+// of the Transformer (reference models/layers.py:234-254 LinearLayer, :258-304
+// ResidualLinearLayer, :308-366 FeedforwardBlock, :389-418 q/k/v blocks) and its
+// backward (dX = dY W, dW = dY^T X).
+//
+//   C[M,N] = epilogue( sum_k A(m,k) * B(n,k) )
+//
+// A and B may each be stored reduction-contiguous ([X][K], "kc") or
+// tile-contiguous ([K][X], "xc"); that covers forward (kc,kc), backward-data
+// (kc,xc) and backward-weight (xc,xc) without materialising a transpose.
+#include "qarig_common.h"
+
+namespace qarig {
+
+struct GemmEpilogue {
+    float* C; int64_t ldc;
+    const float* bias;                    // [N], per column, or null
+    const float* residual; int64_t ldr;   // [M][N] added before the activation, or null
+    float* preact; int64_t ldp;           // receives acc+bias+residual, or null
+    int act;                              // activation applied to what goes to C
+    const float* gradz; int64_t ldz;      // C *= act'(gradz[m][n]) (backward fusion), or null
+    int gact;
+};
+
+template <class SA, class SB>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpilogue ep, int M,
+                                                           int N, int K, int tiles_n, int splitk,
+                                                           float* slabs) {
+    __shared__ __attribute__((aligned(16))) float lds[GEMM_LDS_FLOATS];
+    const int nwg = gridDim.x;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    int k_begin = 0, k_end = K;
+    if (splitk > 1) {
+        const int per = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
+        k_begin = blockIdx.z * per;
+        k_end = min(K, k_begin + per);
+    }
+
+    Acc acc;
+    acc_zero(acc);
+    contract(acc, sa, sb, m0, n0, k_begin, k_end, lds);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cl = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + cl;
+            if (col >= N) continue;
+            const float b = (ep.bias && splitk == 1) ? ep.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if (row >= M) continue;
+                float t = acc.t[i][j][r];
+                if (splitk > 1) {
+                    slabs[((int64_t)blockIdx.z * M + row) * N + col] = t;
+                    continue;
+                }
+                t += b;
+                if (ep.residual) t += ep.residual[(int64_t)row * ep.ldr + col];
+                if (ep.preact) ep.preact[(int64_t)row * ep.ldp + col] = t;
+                float y = act_fwd(t, ep.act);
+                if (ep.gradz) y *= act_grad(ep.gradz[(int64_t)row * ep.ldz + col], ep.gact);
+                ep.C[(int64_t)row * ep.ldc + col] = y;
+            }
+        }
+    }
+}
+
+// out[i] (+ld handling) = sum_z slabs[z][i], z ascending: deterministic.
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                   int64_t ldc, int M, int N, int nslab) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int z = 0; z < nslab; ++z) s += slabs[(int64_t)z * total + i];
+        const int64_t row = i / N, col = i - row * N;
+        out[row * ldc + col] = s;
+    }
+}
+
+// Column sums of X[M][N] (bias gradients; LayerNorm gamma/beta gradients).
+// Stage 1: one block per (64 columns x COLSUM_ROWS rows), fixed order inside.
+constexpr int COLSUM_ROWS = 512;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X,
+                                                             int64_t ldx, int M, int N,
+                                                             float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    const int r0 = blockIdx.y * COLSUM_ROWS;
+    const int r1 = min(M, r0 + COLSUM_ROWS);
+    float s = 0.0f;
+    if (col < N)
+        for (int r = r0 + ry; r < r1; r += 4) s += X[(int64_t)r * ldx + col];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < N)
+        part[(int64_t)blockIdx.y * N + col] = ((red[0][cx] + red[1][cx]) + red[2][cx]) + red[3][cx];
+}
+
+}  // namespace qarig
+
+using namespace qarig;
+
+extern "C" size_t qarig_gemm_workspace_bytes(int M, int N, int splitk) {
+    return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0;
+}
+
+extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const float* B,
+                              int64_t ldb, int b_kcontig, float* C, int64_t ldc, int M, int N,
+                              int K, const float* bias, const float* residual, int64_t ldr,
+                              float* preact, int64_t ldp, int act, const float* gradz,
+                              int64_t ldz, int gact, int splitk, void* workspace,
+                              size_t ws_bytes, void* stream) {
+    QARIG_CHECK_ARG(A && B && C, "gemm: null operand");
+    QARIG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad extents M=%d N=%d K=%d", M, N, K);
+    QARIG_CHECK_ARG(act >= 0 && act <= 3 && gact >= 0 && gact <= 3, "gemm: bad activation id");
+    if (splitk < 1) splitk = 1;
+    if (splitk > 1) {
+        QARIG_CHECK_ARG(!bias && !residual && !preact && !gradz && act == ACT_NONE,
+                        "gemm: split-K supports the plain epilogue only");
+        if (ws_bytes < qarig_gemm_workspace_bytes(M, N, splitk) || !workspace) {
+            qarig_set_error("gemm: workspace too small (%zu < %zu)", ws_bytes,
+                            qarig_gemm_workspace_bytes(M, N, splitk));
+            return QARIG_ERR_WORKSPACE;
+        }
+    }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    dim3 grid(tiles_m * tiles_n, 1, splitk), block(NTHREADS);
+    GemmEpilogue ep{C, ldc, bias, residual, ldr, preact, ldp, act, gradz, ldz, gact};
+    hipStream_t st = (hipStream_t)stream;
+    float* slabs = (float*)workspace;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (a_kcontig && b_kcontig) {
+        SrcKContig sa{A, lda, M, K, 1.0f, al16(A) && lda % 4 == 0};
+        SrcKContig sb{B, ldb, N, K, 1.0f, al16(B) && ldb % 4 == 0};
+        hipLaunchKernelGGL((gemm_kernel<SrcKContig, SrcKContig>), grid, block, 0, st, sa, sb, ep, M,
+                           N, K, tiles_n, splitk, slabs);
+    } else if (a_kcontig && !b_kcontig) {
+        SrcKContig sa{A, lda, M, K, 1.0f, al16(A) && lda % 4 == 0};
+        SrcXContig sb{B, ldb, N, K, 1.0f, al16(B) && ldb % 4 == 0};
+        hipLaunchKernelGGL((gemm_kernel<SrcKContig, SrcXContig>), grid, block, 0, st, sa, sb, ep, M,
+                           N, K, tiles_n, splitk, slabs);
+    } else if (!a_kcontig && !b_kcontig) {
+        SrcXContig sa{A, lda, M, K, 1.0f, al16(A) && lda % 4 == 0};
+        SrcXContig sb{B, ldb, N, K, 1.0f, al16(B) && ldb % 4 == 0};
+        hipLaunchKernelGGL((gemm_kernel<SrcXContig, SrcXContig>), grid, block, 0, st, sa, sb, ep, M,
+                           N, K, tiles_n, splitk, slabs);
+    } else {
+        SrcXContig sa{A, lda, M, K, 1.0f, al16(A) && lda % 4 == 0};
+        SrcKContig sb{B, ldb, N, K, 1.0f, al16(B) && ldb % 4 == 0};
+        hipLaunchKernelGGL((gemm_kernel<SrcXContig, SrcKContig>), grid, block, 0, st, sa, sb, ep, M,
+                           N, K, tiles_n, splitk, slabs);
+    }
+    QARIG_CHECK_LAUNCH("gemm");
+    if (splitk > 1) {
+        const int64_t total = (int64_t)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, C, ldc, M, N,
+                           splitk);
+        QARIG_CHECK_LAUNCH("gemm slab reduce");
+    }
+    return QARIG_OK;
+}
+
+extern "C" size_t qarig_colsum_workspace_bytes(int M, int N) {
+    const int chunks = (M + COLSUM_ROWS - 1) / COLSUM_ROWS;
+    return (size_t)chunks * N * sizeof(float);
+}
+
+// out[N] = sum over rows of X[M][N]; fixed summation order (bit-reproducible).
+extern "C" int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out,
+                                void* workspace, size_t ws_bytes, void* stream) {
+    QARIG_CHECK_ARG(X && out && M > 0 && N > 0, "colsum: bad arguments");
+    if (!workspace || ws_bytes < qarig_colsum_workspace_bytes(M, N)) {
+        qarig_set_error("colsum: workspace too small");
+        return QARIG_ERR_WORKSPACE;
+    }
+    const int chunks = (M + COLSUM_ROWS - 1) / COLSUM_ROWS;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, X, ldx,
+                       M, N, part);
+    QARIG_CHECK_LAUNCH("colsum partial");
+    int blocks = (N + 255) / 256;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, out, (int64_t)N, 1,
+                       N, chunks);
+    QARIG_CHECK_LAUNCH("colsum reduce");
+    return QARIG_OK;
+}

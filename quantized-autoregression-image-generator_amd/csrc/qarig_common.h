@@ -1,0 +1,264 @@
+// Shared device/host helpers for the qarig HIP library (gfx950 / CDNA4 only).
+//
+// The contraction core in here is the one every matmul-shaped kernel of the hot
+// path is built on (Linear fwd/bwd, BMU distance, SOM neighbourhood, conv as
+// implicit GEMM): a 128x128x16 block tile, 4 waves in a 2x2 arrangement, each wave
+// owning a 64x64 sub-tile as 2x2 v_mfma_f32_32x32x2_f32 accumulators.  fp32 in,
+// fp32 accumulate: the MFMA is bit-for-bit a k-ordered fmaf chain, which is what
+// the parity contract (<=1e-5 on pixels, bit-exact BMU indices) needs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define QARIG_OK 0
+#define QARIG_ERR_ARG -1
+#define QARIG_ERR_LAUNCH -2
+#define QARIG_ERR_WORKSPACE -3
+
+extern "C" void qarig_set_error(const char* fmt, ...);
+
+#define QARIG_CHECK_ARG(cond, ...)                 \
+    do {                                           \
+        if (!(cond)) {                             \
+            qarig_set_error(__VA_ARGS__);          \
+            return QARIG_ERR_ARG;                  \
+        }                                          \
+    } while (0)
+
+#define QARIG_CHECK_LAUNCH(name)                                              \
+    do {                                                                      \
+        hipError_t e__ = hipGetLastError();                                   \
+        if (e__ != hipSuccess) {                                              \
+            qarig_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return QARIG_ERR_LAUNCH;                                          \
+        }                                                                     \
+    } while (0)
+
+namespace qarig {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Activation ids shared with the host side (models/layers.py get_activation:
+// reference layers.py:74-80).
+enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_TANH = 2, ACT_SIGMOID = 3 };
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    switch (act) {
+        case ACT_SILU: return x * sigmoid_f(x);
+        case ACT_TANH: return tanhf(x);
+        case ACT_SIGMOID: return sigmoid_f(x);
+        default: return x;
+    }
+}
+
+// d act(x) / dx, from the pre-activation x.
+__device__ __forceinline__ float act_grad(float x, int act) {
+    switch (act) {
+        case ACT_SILU: {
+            float s = sigmoid_f(x);
+            return s * (1.0f + x * (1.0f - s));
+        }
+        case ACT_TANH: {
+            float t = tanhf(x);
+            return 1.0f - t * t;
+        }
+        case ACT_SIGMOID: {
+            float s = sigmoid_f(x);
+            return s * (1.0f - s);
+        }
+        default: return 1.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Block-tile geometry of the contraction core.
+// ---------------------------------------------------------------------------
+constexpr int BM = 128;       // rows of the block tile  (A side)
+constexpr int BN = 128;       // cols of the block tile  (B side)
+constexpr int BK = 16;        // reduction depth per staged tile
+constexpr int LDT = BM + 4;   // LDS row stride in floats (16-B aligned rows; the +4
+                              // makes the transposing ds_write_b32 at most 2-way,
+                              // which costs nothing on gfx950)
+constexpr int NTHREADS = 256; // 4 waves
+constexpr int STAGE = 8;      // floats each thread stages per operand per tile
+constexpr int TILE_FLOATS = BK * LDT;
+constexpr int GEMM_LDS_FLOATS = 4 * TILE_FLOATS;  // A,B double-buffered
+
+struct Acc {
+    f32x16 t[2][2];  // [m-subtile][n-subtile] of the wave's 64x64
+};
+
+__device__ __forceinline__ void acc_zero(Acc& a) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a.t[i][j][r] = 0.0f;
+}
+
+// Row (A-side index) inside a 32x32 accumulator tile held by this lane in
+// register r; the column is lane & 31.  (C/D map of v_mfma_f32_32x32x2_f32.)
+__device__ __forceinline__ int acc_row(int r, int lane) {
+    return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// --- operand tile loaders ---------------------------------------------------
+// A staged tile is BK x 128 in LDS, reduction-major ("k-major"): T[k][x], so that
+// the MFMA fragment read (lane -> x = lane&31, k = 2*s + lane>>5) is a
+// conflict-free ds_read_b32.  Three kinds of global source feed it.
+
+// Source stored [X][K] (reduction index contiguous): Linear weights (N,K),
+// activations (M,K).  Thread -> (x = tid>>1, 8 consecutive k).
+struct SrcKContig {
+    const float* p;
+    int64_t ld;    // elements between consecutive x
+    int X, K;      // extents (for guards)
+    float scale;   // multiplied in while staging (exact for powers of two)
+    bool vec4;     // rows 16-B aligned and ld % 4 == 0
+
+    __device__ __forceinline__ void load(float (&r)[STAGE], int x0, int k0, int tid) const {
+        const int x = x0 + (tid >> 1);
+        const int k = k0 + (tid & 1) * 8;
+        if (x < X && vec4 && k + 8 <= K) {
+            const float4* q = reinterpret_cast<const float4*>(p + (int64_t)x * ld + k);
+            float4 a = q[0], b = q[1];
+            r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+            r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                r[j] = (x < X && k + j < K) ? p[(int64_t)x * ld + k + j] : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void store(const float (&r)[STAGE], float* T, int tid) const {
+        const int x = tid >> 1;
+        const int k = (tid & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) T[(k + j) * LDT + x] = r[j] * scale;
+    }
+};
+
+// Source stored [K][X] (tile index contiguous): the transposed operands of the
+// backward contractions.  Thread -> (k = tid>>5 (+8), 4 consecutive x).
+struct SrcXContig {
+    const float* p;
+    int64_t ld;    // elements between consecutive k
+    int X, K;
+    float scale;
+    bool vec4;
+
+    __device__ __forceinline__ void load(float (&r)[STAGE], int x0, int k0, int tid) const {
+        const int x = x0 + (tid & 31) * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + (tid >> 5) + 8 * h;
+            if (k < K && vec4 && x + 4 <= X) {
+                float4 a = *reinterpret_cast<const float4*>(p + (int64_t)k * ld + x);
+                r[4 * h + 0] = a.x; r[4 * h + 1] = a.y; r[4 * h + 2] = a.z; r[4 * h + 3] = a.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    r[4 * h + j] = (k < K && x + j < X) ? p[(int64_t)k * ld + x + j] : 0.0f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(const float (&r)[STAGE], float* T, int tid) const {
+        const int x = (tid & 31) * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = (tid >> 5) + 8 * h;
+            float4 v = make_float4(r[4 * h] * scale, r[4 * h + 1] * scale, r[4 * h + 2] * scale,
+                                   r[4 * h + 3] * scale);
+            *reinterpret_cast<float4*>(T + k * LDT + x) = v;
+        }
+    }
+};
+
+// One BK-deep slab of MFMAs from staged tiles TA/TB for this wave.
+// ksteps = number of 2-deep MFMA steps that carry data (<= BK/2).
+__device__ __forceinline__ void mma_tile(Acc& acc, const float* TA, const float* TB, int wm,
+                                         int wn, int lane, int ksteps) {
+    const int x = lane & 31;
+    const int h = lane >> 5;
+    const float* pa = TA + h * LDT + wm * 64 + x;
+    const float* pb = TB + h * LDT + wn * 64 + x;
+#pragma unroll 4
+    for (int s = 0; s < ksteps; ++s) {
+        const float a0 = pa[(2 * s) * LDT];
+        const float a1 = pa[(2 * s) * LDT + 32];
+        const float b0 = pb[(2 * s) * LDT];
+        const float b1 = pb[(2 * s) * LDT + 32];
+        acc.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc.t[0][0], 0, 0, 0);
+        acc.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc.t[0][1], 0, 0, 0);
+        acc.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc.t[1][0], 0, 0, 0);
+        acc.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc.t[1][1], 0, 0, 0);
+    }
+}
+
+// acc += A[m0:m0+128, k_begin:k_end] * B[n0:n0+128, k_begin:k_end]^T through
+// double-buffered LDS tiles.  `lds` holds GEMM_LDS_FLOATS floats.  All threads of
+// the block must call it; it ends with the tiles no longer in use (a barrier has
+// been passed), so the caller may reuse `lds`.
+template <class SA, class SB>
+__device__ __forceinline__ void contract(Acc& acc, const SA& sa, const SB& sb, int m0, int n0,
+                                         int k_begin, int k_end, float* lds) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    float* TA[2] = {lds, lds + TILE_FLOATS};
+    float* TB[2] = {lds + 2 * TILE_FLOATS, lds + 3 * TILE_FLOATS};
+
+    float ra[STAGE], rb[STAGE];
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+    if (nk <= 0) return;
+    sa.load(ra, m0, k_begin, tid);
+    sb.load(rb, n0, k_begin, tid);
+    sa.store(ra, TA[0], tid);
+    sb.store(rb, TB[0], tid);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const int kb = k_begin + kt * BK;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            sa.load(ra, m0, kb + BK, tid);
+            sb.load(rb, n0, kb + BK, tid);
+        }
+        int rem = k_end - kb;
+        if (rem > BK) rem = BK;
+        mma_tile(acc, TA[cur], TB[cur], wm, wn, lane, (rem + 1) >> 1);
+        if (more) {
+            sa.store(ra, TA[cur ^ 1], tid);
+            sb.store(rb, TB[cur ^ 1], tid);
+        }
+        __syncthreads();
+    }
+}
+
+// XCD-aware remap of a linear block id (T1 of the CDNA4 guide, bijective form):
+// blocks b and b+8 share an XCD, so give each XCD a contiguous chunk of the tile
+// order and neighbouring tiles (which share operand panels) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace qarig

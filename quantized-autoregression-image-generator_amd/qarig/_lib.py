@@ -1,0 +1,105 @@
+"""ctypes binding of libqarig_hip.so (C ABI declared in include/qarig.h).
+
+There is no CPU fallback: if the library is missing, or a CPU tensor reaches an op,
+the call raises.  torch is used only to own device memory and streams.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_int64, c_size_t, c_void_p, c_float, c_char_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libqarig_hip.so")
+
+P = c_void_p
+I = c_int
+L = c_int64
+Z = c_size_t
+F = c_float
+
+# name -> (restype, argtypes); must list every symbol include/qarig.h declares
+# (tests/test_abi.py cross-checks the two).
+SIGNATURES = {
+    "qarig_version": (I, []),
+    "qarig_target_arch": (c_char_p, []),
+    "qarig_last_error": (I, [c_char_p, Z]),
+    "qarig_bmu_workspace_bytes": (Z, [L, I]),
+    "qarig_bmu_fwd": (I, [P, I, I, I, I, I, I, P, I, I, P, P, Z, P]),
+    "qarig_gemm_workspace_bytes": (Z, [I, I, I]),
+    "qarig_gemm_f32": (I, [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, P, Z, P]),
+    "qarig_colsum_workspace_bytes": (Z, [I, I]),
+    "qarig_colsum_f32": (I, [P, L, I, I, P, P, Z, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with "
+            "`python quantized-autoregression-image-generator_amd/build.py` "
+            "(there is no CPU fallback for the qarig ops)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    load().qarig_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what} failed ({status}): {last_error()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "qarig ops run on MI355X only: got a CPU tensor "
+                "(the CPU restatement lives in oracle/ and is test infrastructure)")
+
+
+def f32c(t):
+    """fp32 + contiguous view/copy of t (no-op when already so)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only per-device scratch buffer (uint8).  Kernels that use it run on the
+    current stream in issue order, so one buffer per tag can be shared."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
