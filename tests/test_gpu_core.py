@@ -1,0 +1,140 @@
+"""GPU parity of the contraction core (GEMM) and the BMU search against the oracle.
+Everything goes through the C ABI (qarig.ops -> ctypes -> libqarig_hip.so)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+GEMM_TOL = 2e-6  # |err| / max|ref| ; fp32 fma chain vs fp64 reference
+
+
+def _ref_gemm(A, B, ak, bk):
+    Ad = A.double().cpu() if ak else A.double().cpu().t()
+    Bd = B.double().cpu() if bk else B.double().cpu().t()
+    return Ad @ Bd.t()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (257, 130, 70), (64, 513, 512), (1000, 96, 33),
+                                   (2048, 512, 2048)])
+@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, False), (False, True)])
+def test_gemm_layouts(M, N, K, ak, bk):
+    from qarig import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((M, K) if ak else (K, M), generator=g).cuda()
+    B = torch.randn((N, K) if bk else (K, N), generator=g).cuda()
+    C = ops.gemm(A, B, ak, bk)
+    ref = _ref_gemm(A, B, ak, bk)
+    assert rel_err(C, ref) < GEMM_TOL * max(1, K / 512) ** 0.5
+
+
+def test_gemm_epilogues():
+    from qarig import ops
+    from oracle import ref_models as rm
+    g = torch.Generator().manual_seed(0)
+    M, N, K = 300, 200, 96
+    A = torch.randn((M, K), generator=g)
+    W = torch.randn((N, K), generator=g) * 0.2
+    b = torch.randn((N,), generator=g)
+    R = torch.randn((M, N), generator=g)
+    Z = torch.randn((M, N), generator=g)
+    for act_name, act in (("silu", 1), ("tanh", 2), ("sigmoid", 3), (None, 0)):
+        C, pre = ops.gemm(A.cuda(), W.cuda(), bias=b.cuda(), residual=R.cuda(), want_preact=True,
+                          act=act)
+        t = A.double() @ W.double().t() + b.double() + R.double()
+        assert rel_err(pre, t) < GEMM_TOL
+        assert rel_err(C, rm.activation(t, act_name)) < 5e-6
+        # backward fusion: C = acc * act'(Z)
+        Zd = Z.double().requires_grad_(True)
+        rm.activation(Zd, act_name).sum().backward()
+        G = ops.gemm(A.cuda(), W.cuda(), gradz=Z.cuda(), gact=act)
+        assert rel_err(G, (A.double() @ W.double().t()) * Zd.grad) < 5e-6
+
+
+def test_gemm_splitk_and_colsum():
+    from qarig import ops
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 200, 96, 5000
+    A = torch.randn((K, M), generator=g).cuda()
+    B = torch.randn((K, N), generator=g).cuda()
+    ref = _ref_gemm(A, B, False, False)
+    for s in (1, 3, 8):
+        C = ops.gemm(A, B, False, False, splitk=s)
+        assert rel_err(C, ref) < 1e-5
+    C2 = ops.gemm(A, B, False, False, splitk=8)
+    assert torch.equal(C, C2)  # deterministic slab order
+    X = torch.randn((3001, 130), generator=g).cuda()
+    assert rel_err(ops.colsum(X), X.double().sum(0)) < 2e-6
+
+
+def test_gemm_strided_views():
+    from qarig import ops
+    g = torch.Generator().manual_seed(2)
+    big = torch.randn((300, 513), generator=g).cuda()
+    A = big[:, 1:101]           # ld 513, not 16-B aligned -> scalar path
+    W = torch.randn((64, 100), generator=g).cuda()
+    C = ops.gemm(A, W)
+    assert rel_err(C, A.double().cpu() @ W.double().cpu().t()) < GEMM_TOL
+
+
+BMU_CASES = ["trained_p1", "trained_p2", "trained_p4", "trained_p8", "trained_full", "ragged",
+             "fresh_p4", "ties", "direct"]
+
+
+@pytest.mark.parametrize("case", BMU_CASES)
+def test_bmu_vs_oracle_and_golden(case):
+    """HIP BMU == C oracle bit-for-bit on every case (same fp32 fma order), and ==
+    the reference's golden indices wherever the oracle is."""
+    from qarig import ops
+    from oracle import bmu as obmu
+    g = load_golden("bmu")[case]
+    p = int(g["p"])
+    got = ops.bmu(g["x"].cuda(), g["w"].cuda(), (p, p)).cpu().numpy()
+    want = obmu.bmu(g["x"].numpy(), g["w"].numpy(), (p, p))
+    assert got.dtype == np.int64
+    assert np.array_equal(got, want)
+    if case != "fresh_p4":
+        assert np.array_equal(got, g["idx"].numpy().reshape(-1))
+
+
+@pytest.mark.parametrize("N,C,H,W,p,K", [(64, 4, 32, 32, 4, 512), (64, 4, 32, 32, 32, 512),
+                                         (16, 4, 64, 64, 1, 8192), (64, 4, 32, 32, 2, 512),
+                                         (5, 3, 18, 30, 3, 100)])
+def test_bmu_seeded_vs_oracle(N, C, H, W, p, K):
+    from qarig import ops
+    from oracle import bmu as obmu
+    g = torch.Generator().manual_seed(N + p + K)
+    x = torch.tanh(torch.randn((N, C, H, W), generator=g))
+    w = torch.tanh(torch.randn((K, C * p * p), generator=g))
+    got = ops.bmu(x.cuda(), w.cuda(), (p, p)).cpu().numpy()
+    want = obmu.bmu(x.numpy(), w.numpy(), (p, p))
+    assert np.array_equal(got, want)
+    ref = torch.argmin(torch.cdist(torch.from_numpy(obmu.patchify(x.numpy(), (p, p))), w), -1)
+    assert (ref.numpy() != got).mean() <= 1e-4  # torch's own sgemm order: noise rows only
+
+
+def test_bmu_full_size_properties():
+    """BASELINE-size run (65,536 rows x K=512): properties that need no oracle pass --
+    the chosen unit's exact distance is within fp32 noise of the exact minimum, and
+    quantising codebook rows themselves returns their own index."""
+    from qarig import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.tanh(torch.randn((64, 4, 64, 64), generator=g)).cuda()
+    w = torch.tanh(torch.randn((512, 16), generator=g)).cuda()
+    idx = ops.bmu(x, w, (2, 2))
+    from oracle import ref_models as rm
+    xp = rm.patchify(x, (2, 2)).reshape(-1, 16).double()
+    d = torch.cdist(xp, w.double())
+    chosen = d.gather(1, idx[:, None]).squeeze(1)
+    assert float((chosen - d.min(1).values).max()) < 1e-5
+    # identity property: patches that ARE codebook rows map to themselves
+    img = rm.unpatchify(w[:256].reshape(1, 256, 16), (32, 32), (2, 2))
+    assert torch.equal(ops.bmu(img, w, (2, 2)).cpu(), torch.arange(256))
+
+
+def test_cpu_tensor_is_refused():
+    from qarig import ops
+    with pytest.raises(RuntimeError):
+        ops.bmu(torch.zeros(1, 4, 4, 4), torch.zeros(8, 16), (2, 2))
