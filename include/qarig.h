@@ -73,6 +73,82 @@ size_t qarig_colsum_workspace_bytes(int M, int N);
 int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, void* workspace,
                      size_t ws_bytes, void* stream);
 
+/* ---- Codebook (continued) ------------------------------------------------------ */
+
+/* patchify / unpatchify -- models/layers.py:8-34 / :37-71.  image (N,C,H,W) <->
+ * patches (N*Seq, C*pH*pW).  H,W must be multiples of the patch here. */
+int qarig_patchify_fwd(const float* image, int N, int C, int H, int W, int pH, int pW,
+                       float* patches, void* stream);
+int qarig_unpatchify_fwd(const float* patches, int N, int C, int H, int W, int pH, int pW,
+                         float* image, void* stream);
+
+/* Codebook.get_quantized_image -- models/Codebook.py:138-154: image = unpatchify(
+ * codebook[ids]).  ids int64 (N*Seq); *bad_flag (device int, caller-zeroed) is set on
+ * an id outside [0,K). */
+int qarig_codebook_gather_image(const int64_t* ids, int N, int C, int H, int W, int pH, int pW,
+                                const float* codebook, int K, float* image, int* bad_flag,
+                                void* stream);
+
+/* nn.Embedding row gather out[r] = table[ids[r]] -- models/Codebook.py:132,144. */
+int qarig_gather_rows(const int64_t* ids, int64_t R, int D, int K, const float* table, float* out,
+                      int* bad_flag, void* stream);
+
+/* Gaussian index-neighbourhood weights g[r][j] = exp(-(j-bmu[r])^2 / two_var) --
+ * models/Codebook.py:112-126 (the (R,K)@(K,D) product then goes through qarig_gemm_f32). */
+int qarig_som_weights_fwd(const int64_t* bmu, int64_t R, int K, float two_var, float* g,
+                          void* stream);
+
+/* ---- Transformer pieces ------------------------------------------------------- */
+
+/* get_positional_embeddings -- models/layers.py:83-96.  pos fp32 (R,), freq (D/2,)
+ * (host-computed exactly as the reference does), out (R,D) = [sin | cos]. */
+int qarig_posemb_fwd(const float* pos, int R, int D, const float* freq, float* out, void* stream);
+
+/* nn.Embedding + additive position table -- models/Transformer.py:127-139,154-167.
+ * ids int64 (M = N*S); pe (S,D) or NULL; out (M,D). */
+int qarig_embedding_fwd(const int64_t* ids, int M, int S, int D, int V, const float* table,
+                        const float* pe, float* out, int* bad_flag, void* stream);
+/* dtable[v] = sum_{m: ids[m]==v} dy[m], m ascending (autograd of nn.Embedding). */
+int qarig_embedding_bwd(const int64_t* ids, int M, int D, int V, const float* dy, float* dtable,
+                        void* stream);
+
+/* nn.LayerNorm(D) (gamma,beta) / AdaLNZero modulation (scale,shift per token) --
+ * models/layers.py:130-153,327,499,559.  Exactly one of the pairs, or neither. */
+int qarig_layernorm_fwd(const float* x, int M, int D, float eps, const float* gamma,
+                        const float* beta, const float* scale, const float* shift, float* y,
+                        float* mean, float* rstd, void* stream);
+int qarig_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                        const float* gamma, const float* scale, int M, int D, float* dx,
+                        float* dy_xhat, void* stream);
+
+/* AttentionLayer core -- models/layers.py:433-474.  q (N,Sq,H*d); k,v (N,Sk,H*d);
+ * o (N,Sq,H*d); lse (N,H,Sq); sqrt_d = float(d ** 0.5). */
+int qarig_attention_fwd(const float* q, const float* k, const float* v, int N, int Sq, int Sk,
+                        int H, int d, int causal, float sqrt_d, float* o, float* lse,
+                        void* stream);
+int qarig_attention_bwd(const float* q, const float* k, const float* v, const float* o,
+                        const float* dO, const float* lse, int N, int Sq, int Sk, int H, int d,
+                        int causal, float sqrt_d, float* dq, float* dk, float* dv, float* delta,
+                        void* stream);
+
+/* nn.CrossEntropyLoss() mean over rows + d/dlogits --
+ * train_quantized_transformer.py:337,496-502.  row_ws: M floats. */
+int qarig_cross_entropy_fwd(const float* logits, const int64_t* target, int M, int C, float* loss,
+                            float* dlogits, float* row_ws, int* bad_flag, void* stream);
+
+/* torch.optim.Adam step on a flat buffer -- train_quantized_transformer.py:317-320. */
+int qarig_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
+                    float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale,
+                    void* stream);
+
+/* elementwise helpers (ResidualLinearLayer gate, models/layers.py:293-295) */
+int qarig_mul_fwd(const float* a, const float* b, float* y, int64_t n, void* stream);
+int qarig_mul_bwd(const float* dy, const float* a, const float* b, float* da, float* db, int64_t n,
+                  void* stream);
+int qarig_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);
+int qarig_act_bwd(const float* dy, const float* z, float* dz, int64_t n, int act, void* stream);
+int qarig_scale_by(const float* x, const float* s, float* y, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,100 @@
+// Token embedding + sinusoidal positions (reference models/Transformer.py:127-167,
+// models/layers.py:83-96) and the embedding-weight gradient.
+#include "qarig_common.h"
+
+namespace qarig {
+
+// out[r][c] = c < half ? sin(pos[r]*freq[c]) : cos(pos[r]*freq[c-half]).
+// freq (half floats) is computed by the host exactly as the reference does
+// (torch.exp(arange(half) * -ln(1e4)/(half-1)) in fp32) so that the angle is
+// bit-identical; sinf/cosf are the full-range ocml versions.
+__global__ void posemb_kernel(const float* __restrict__ pos, int R, int D,
+                              const float* __restrict__ freq, float* __restrict__ out) {
+    const int half = D >> 1;
+    const int64_t total = (int64_t)R * D;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / D), c = (int)(idx - (int64_t)r * D);
+        const float p = pos[r];
+        out[idx] = c < half ? sinf(p * freq[c]) : cosf(p * freq[c - half]);
+    }
+}
+
+// out[m][:] = table[ids[m]][:] + pe[m % S][:]   (pe may be null)
+__global__ void embedding_fwd_kernel(const int64_t* __restrict__ ids, int M, int S, int D, int V,
+                                     const float* __restrict__ table,
+                                     const float* __restrict__ pe, float* __restrict__ out,
+                                     int* __restrict__ bad) {
+    const int64_t total = (int64_t)M * D;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / D), c = (int)(idx - (int64_t)m * D);
+        const int64_t id = ids[m];
+        if (id < 0 || id >= V) {
+            if (c == 0) atomicExch(bad, 1);
+            out[idx] = 0.0f;
+            continue;
+        }
+        float t = table[id * D + c];
+        if (pe) t += pe[(int64_t)(m % S) * D + c];
+        out[idx] = t;
+    }
+}
+
+// dtable[v][:] = sum over m with ids[m]==v of dy[m][:], m ascending (deterministic).
+// One block per vocabulary row; the id stream is wave-uniform (scalar loads).
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ ids, int M,
+                                                            int D, const float* __restrict__ dy,
+                                                            float* __restrict__ dtable) {
+    const int v = blockIdx.x;
+    for (int c0 = 0; c0 < D; c0 += 256) {
+        const int c = c0 + threadIdx.x;
+        float acc = 0.0f;
+        for (int m = 0; m < M; ++m) {
+            if (ids[m] == v && c < D) acc += dy[(int64_t)m * D + c];
+        }
+        if (c < D) dtable[(int64_t)v * D + c] = acc;
+    }
+}
+
+}  // namespace qarig
+
+using namespace qarig;
+
+static int ew_blocks(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+// get_positional_embeddings, models/layers.py:83-96.  pos: fp32 (R,), freq: (D/2,).
+extern "C" int qarig_posemb_fwd(const float* pos, int R, int D, const float* freq, float* out,
+                                void* stream) {
+    QARIG_CHECK_ARG(pos && freq && out && R > 0 && D > 0 && (D % 2) == 0, "posemb: bad arguments");
+    hipLaunchKernelGGL(posemb_kernel, dim3(ew_blocks((int64_t)R * D)), dim3(256), 0,
+                       (hipStream_t)stream, pos, R, D, freq, out);
+    QARIG_CHECK_LAUNCH("posemb");
+    return QARIG_OK;
+}
+
+// nn.Embedding lookup fused with the additive position table (Transformer.py:127-139,
+// 154-167).  ids: int64 (M,), M = N*S; pe: (S,D) or NULL.  *bad_flag (device int,
+// caller-zeroed) is set to 1 if an id is out of range (the host raises IndexError).
+extern "C" int qarig_embedding_fwd(const int64_t* ids, int M, int S, int D, int V,
+                                   const float* table, const float* pe, float* out, int* bad_flag,
+                                   void* stream) {
+    QARIG_CHECK_ARG(ids && table && out && bad_flag && M > 0 && S > 0 && D > 0 && V > 0,
+                    "embedding_fwd: bad arguments");
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(ew_blocks((int64_t)M * D)), dim3(256), 0,
+                       (hipStream_t)stream, ids, M, S, D, V, table, pe, out, bad_flag);
+    QARIG_CHECK_LAUNCH("embedding_fwd");
+    return QARIG_OK;
+}
+
+extern "C" int qarig_embedding_bwd(const int64_t* ids, int M, int D, int V, const float* dy,
+                                   float* dtable, void* stream) {
+    QARIG_CHECK_ARG(ids && dy && dtable && M > 0 && D > 0 && V > 0, "embedding_bwd: bad arguments");
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, M, D,
+                       dy, dtable);
+    QARIG_CHECK_LAUNCH("embedding_bwd");
+    return QARIG_OK;
+}

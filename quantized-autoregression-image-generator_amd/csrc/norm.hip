@@ -1,0 +1,104 @@
+// LayerNorm over the last dimension, one wave per row, with the two affine forms the
+// Transformer uses fused in:
+//   - nn.LayerNorm(D) with gamma/beta          (encoder blocks, layers.py:327,499,559)
+//   - AdaLNZero: scale(cond)*LN(x)+shift(cond) (decoder blocks, layers.py:130-153),
+//     scale/shift being per-token (M,D) tensors produced by the cond GEMMs.
+// eps = 1e-5, biased variance, fp32 throughout (torch.nn.LayerNorm semantics).
+#include "qarig_common.h"
+
+namespace qarig {
+
+constexpr int LN_WAVES = 4;
+
+__global__ __launch_bounds__(LN_WAVES * 64) void layernorm_fwd_kernel(
+    const float* __restrict__ x, int M, int D, float eps, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ y, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (int64_t)row * D;
+    float s = 0.0f;
+    for (int c = lane; c < D; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)D;
+    float v = 0.0f;
+    for (int c = lane; c < D; c += 64) {
+        const float t = xr[c] - mean;
+        v = fmaf(t, t, v);
+    }
+    const float var = wave_sum(v) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (lane == 0) {
+        mean_out[row] = mean;
+        rstd_out[row] = rstd;
+    }
+    float* yr = y + (int64_t)row * D;
+    for (int c = lane; c < D; c += 64) {
+        float h = (xr[c] - mean) * rstd;
+        if (gamma) h = h * gamma[c] + beta[c];
+        else if (scale) h = scale[(int64_t)row * D + c] * h + shift[(int64_t)row * D + c];
+        yr[c] = h;
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * (gamma | scale | 1)
+// dy_xhat (optional) = dy * xhat: AdaLN's d(scale), or the column-summed d(gamma).
+__global__ __launch_bounds__(LN_WAVES * 64) void layernorm_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_in,
+    const float* __restrict__ rstd_in, const float* __restrict__ gamma,
+    const float* __restrict__ scale, int M, int D, float* __restrict__ dx,
+    float* __restrict__ dy_xhat) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int64_t off = (int64_t)row * D;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int c = lane; c < D; c += 64) {
+        const float h = (x[off + c] - mean) * rstd;
+        const float d = dy[off + c];
+        const float g = gamma ? d * gamma[c] : (scale ? d * scale[off + c] : d);
+        s1 += g;
+        s2 = fmaf(g, h, s2);
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    for (int c = lane; c < D; c += 64) {
+        const float h = (x[off + c] - mean) * rstd;
+        const float d = dy[off + c];
+        const float g = gamma ? d * gamma[c] : (scale ? d * scale[off + c] : d);
+        dx[off + c] = rstd * ((g - s1) - h * s2);
+        if (dy_xhat) dy_xhat[off + c] = d * h;
+    }
+}
+
+}  // namespace qarig
+
+using namespace qarig;
+
+extern "C" int qarig_layernorm_fwd(const float* x, int M, int D, float eps, const float* gamma,
+                                   const float* beta, const float* scale, const float* shift,
+                                   float* y, float* mean, float* rstd, void* stream) {
+    QARIG_CHECK_ARG(x && y && mean && rstd && M > 0 && D > 0, "layernorm_fwd: bad arguments");
+    QARIG_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "layernorm_fwd: gamma/beta pair");
+    QARIG_CHECK_ARG((scale == nullptr) == (shift == nullptr), "layernorm_fwd: scale/shift pair");
+    QARIG_CHECK_ARG(!(gamma && scale), "layernorm_fwd: affine and AdaLN forms are exclusive");
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((M + LN_WAVES - 1) / LN_WAVES),
+                       dim3(LN_WAVES * 64), 0, (hipStream_t)stream, x, M, D, eps, gamma, beta, scale,
+                       shift, y, mean, rstd);
+    QARIG_CHECK_LAUNCH("layernorm_fwd");
+    return QARIG_OK;
+}
+
+extern "C" int qarig_layernorm_bwd(const float* dy, const float* x, const float* mean,
+                                   const float* rstd, const float* gamma, const float* scale,
+                                   int M, int D, float* dx, float* dy_xhat, void* stream) {
+    QARIG_CHECK_ARG(dy && x && mean && rstd && dx && M > 0 && D > 0, "layernorm_bwd: bad arguments");
+    QARIG_CHECK_ARG(!(gamma && scale), "layernorm_bwd: affine and AdaLN forms are exclusive");
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + LN_WAVES - 1) / LN_WAVES),
+                       dim3(LN_WAVES * 64), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, scale,
+                       M, D, dx, dy_xhat);
+    QARIG_CHECK_LAUNCH("layernorm_bwd");
+    return QARIG_OK;
+}

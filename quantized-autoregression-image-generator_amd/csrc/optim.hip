@@ -1,0 +1,47 @@
+// Adam step over one flat fp32 buffer (all parameters of a model live in one
+// allocation; so do their gradients and moments): one launch per step, and the same
+// flat gradient buffer is what the DP all-reduce moves.  Semantics of
+// torch.optim.Adam(lr, betas) without weight decay / amsgrad
+// (train_quantized_transformer.py:317-320; train_autoencoder.py:133-136).
+#include "qarig_common.h"
+
+namespace qarig {
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, int64_t n, float beta1,
+                            float beta2, float eps, float step_size, float bc2_sqrt,
+                            float grad_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * grad_scale;
+        // exp_avg.lerp_(grad, 1 - beta1), torch's two-branch lerp
+        const float w = 1.0f - beta1;
+        const float mi = m[i];
+        const float mn = w < 0.5f ? mi + w * (gi - mi) : gi - (gi - mi) * (1.0f - w);
+        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        const float vn = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+        const float denom = sqrtf(vn) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mn / denom);
+        m[i] = mn;
+        v[i] = vn;
+    }
+}
+
+}  // namespace qarig
+
+using namespace qarig;
+
+// step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t), both computed by the
+// host in double as torch does.  grad_scale multiplies g first (1/world after a sum
+// all-reduce; 1 otherwise).
+extern "C" int qarig_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
+                               float beta2, float eps, float step_size, float bc2_sqrt,
+                               float grad_scale, void* stream) {
+    QARIG_CHECK_ARG(p && g && m && v && n > 0, "adam: bad arguments");
+    int64_t b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
+    QARIG_CHECK_LAUNCH("adam");
+    return QARIG_OK;
+}

@@ -1,0 +1,106 @@
+"""Drop-in `models.Transformer.Transformer` (reference models/Transformer.py:16-202):
+optional encoder stack + DiT-style decoder stack + position-conditioning MLP +
+classifier, same constructor, state-dict keys and forward signature; compute on HIP."""
+import torch
+import torch.nn as nn
+from torch.utils import checkpoint
+
+from qarig import functional as QF
+from qarig import ops
+
+from ._loading import load_matching
+from .layers import LinearLayer, TransformerBlock, _mlp2_forward
+
+
+class Transformer(nn.Module):
+    def __init__(self, use_encoder=True, use_pos_cond=True, num_enc_layers=5, num_dec_layers=10,
+                 num_enc_embedding=512, num_dec_embedding=512, self_attn_heads=8,
+                 cross_attn_heads=8, transformer_in_dim=512, transformer_out_dim=512,
+                 transformer_hidden_dim=4096, hidden_activation="silu",
+                 use_activation_checkpoint=False):
+        super().__init__()
+        self.use_encoder = use_encoder
+        self.use_pos_cond = use_pos_cond
+        self.use_activation_checkpoint = use_activation_checkpoint
+
+        if self.use_encoder:
+            self.enc_embedding = nn.Embedding(num_embeddings=num_enc_embedding,
+                                              embedding_dim=transformer_in_dim)
+            self.encoder_layers = nn.ModuleList(
+                TransformerBlock(in_dim=transformer_in_dim, hidden_dim=transformer_hidden_dim,
+                                 self_attn_heads=self_attn_heads, use_cross_attn=False,
+                                 use_masked_attn=False, use_adaln0=False, use_scale_layer=False,
+                                 activation_type=hidden_activation)
+                for _ in range(num_enc_layers))
+
+        self.dec_embedding = nn.Embedding(num_embeddings=num_dec_embedding,
+                                          embedding_dim=transformer_in_dim)
+        self.decoder_layers = nn.ModuleList(
+            TransformerBlock(in_dim=transformer_in_dim, cond_dim=transformer_in_dim,
+                             cross_cond_dim=transformer_in_dim, hidden_dim=transformer_hidden_dim,
+                             self_attn_heads=self_attn_heads, cross_attn_heads=cross_attn_heads,
+                             use_cross_attn=self.use_encoder, use_masked_attn=True,
+                             use_adaln0=self.use_pos_cond, use_scale_layer=self.use_pos_cond,
+                             activation_type=hidden_activation)
+            for _ in range(num_dec_layers))
+
+        if self.use_pos_cond:
+            self.pos_cond_layer = nn.Sequential(
+                LinearLayer(in_dim=transformer_in_dim, out_dim=transformer_hidden_dim,
+                            use_activation=True, activation_type=hidden_activation),
+                LinearLayer(in_dim=transformer_hidden_dim, out_dim=transformer_in_dim,
+                            use_activation=False))
+
+        self.classifier = nn.Sequential(
+            LinearLayer(in_dim=transformer_in_dim, out_dim=transformer_hidden_dim,
+                        use_activation=True),
+            LinearLayer(in_dim=transformer_hidden_dim, out_dim=transformer_out_dim,
+                        use_activation=False))
+        self._pe_cache = {}
+
+    def custom_load_state_dict(self, state_dict):
+        load_matching(self, state_dict)
+
+    def _sequence_pe(self, seq, dim, device):
+        """sinusoid of positions 1..seq (reference Transformer.py:130-139,159-167);
+        constant per (seq, dim), so built once and kept on the device."""
+        key = (seq, dim, str(device))
+        pe = self._pe_cache.get(key)
+        if pe is None:
+            pe = ops.posemb(torch.arange(1, seq + 1, device=device), dim)
+            self._pe_cache[key] = pe
+        return pe
+
+    def encode(self, x_enc):
+        """Encoder half alone (constant across the decode steps of one stage, so
+        generation can call it once)."""
+        table = self.enc_embedding.weight
+        enc = QF.embedding_pos(x_enc, table, self._sequence_pe(x_enc.shape[1], table.shape[1],
+                                                               table.device))
+        for layer in self.encoder_layers:
+            if self.use_activation_checkpoint and torch.is_grad_enabled():
+                enc = checkpoint.checkpoint(layer, enc, use_reentrant=False)
+            else:
+                enc = layer(enc)
+        return enc
+
+    def decode(self, x_dec, enc=None, pos_cond=None):
+        table = self.dec_embedding.weight
+        N, S = x_dec.shape
+        D = table.shape[1]
+        x = QF.embedding_pos(x_dec, table, self._sequence_pe(S, D, table.device))
+        cond = None
+        if self.use_pos_cond:
+            cond = ops.posemb(pos_cond.flatten(), D).reshape(N, S, D)
+            cond = _mlp2_forward(self.pos_cond_layer, cond)
+        for layer in self.decoder_layers:
+            if self.use_activation_checkpoint and torch.is_grad_enabled():
+                x = checkpoint.checkpoint(layer, x, cross_cond=enc, pos_cond=cond,
+                                          use_reentrant=False)
+            else:
+                x = layer(x=x, cross_cond=enc, pos_cond=cond)
+        return _mlp2_forward(self.classifier, x)
+
+    def forward(self, x_dec, x_enc=None, pos_cond=None):
+        enc = self.encode(x_enc) if self.use_encoder else None
+        return self.decode(x_dec, enc, pos_cond)

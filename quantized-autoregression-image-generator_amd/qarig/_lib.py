@@ -30,6 +30,25 @@ SIGNATURES = {
     "qarig_gemm_f32": (I, [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, P, Z, P]),
     "qarig_colsum_workspace_bytes": (Z, [I, I]),
     "qarig_colsum_f32": (I, [P, L, I, I, P, P, Z, P]),
+    "qarig_patchify_fwd": (I, [P, I, I, I, I, I, I, P, P]),
+    "qarig_unpatchify_fwd": (I, [P, I, I, I, I, I, I, P, P]),
+    "qarig_codebook_gather_image": (I, [P, I, I, I, I, I, I, P, I, P, P, P]),
+    "qarig_gather_rows": (I, [P, L, I, I, P, P, P, P]),
+    "qarig_som_weights_fwd": (I, [P, L, I, F, P, P]),
+    "qarig_posemb_fwd": (I, [P, I, I, P, P, P]),
+    "qarig_embedding_fwd": (I, [P, I, I, I, I, P, P, P, P, P]),
+    "qarig_embedding_bwd": (I, [P, I, I, I, P, P, P]),
+    "qarig_layernorm_fwd": (I, [P, I, I, F, P, P, P, P, P, P, P, P]),
+    "qarig_layernorm_bwd": (I, [P, P, P, P, P, P, I, I, P, P, P]),
+    "qarig_attention_fwd": (I, [P, P, P, I, I, I, I, I, I, F, P, P, P]),
+    "qarig_attention_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P, P, P, P, P]),
+    "qarig_cross_entropy_fwd": (I, [P, P, I, I, P, P, P, P, P]),
+    "qarig_adam_step": (I, [P, P, P, P, L, F, F, F, F, F, F, P]),
+    "qarig_mul_fwd": (I, [P, P, P, L, P]),
+    "qarig_mul_bwd": (I, [P, P, P, P, P, L, P]),
+    "qarig_act_fwd": (I, [P, P, L, I, P]),
+    "qarig_act_bwd": (I, [P, P, P, L, I, P]),
+    "qarig_scale_by": (I, [P, P, P, L, P]),
 }
 
 _lib = None

@@ -1,0 +1,265 @@
+"""Differentiable building blocks: torch.autograd.Function shells whose forward and
+backward are the HIP kernels behind the C ABI (qarig.ops).  torch owns the tensors and
+the graph; every FLOP and every byte moved is ours.
+
+Saved-tensor policy: HBM is 288 GB per GPU, so every pre-activation that a backward
+needs is kept (no recompute); compatible with torch.utils.checkpoint(use_reentrant=
+False) for the reference's --use-activation-checkpoint flag.
+"""
+import torch
+
+from . import ops
+from ._lib import f32c, require_cuda
+
+
+def _2d(t):
+    return t.reshape(-1, t.shape[-1])
+
+
+def _wgrad(dT, X):
+    """dW[N,K] = dT^T X over the row dimension, split-K through fp32 slabs."""
+    M, N = dT.shape
+    K = X.shape[1]
+    return ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=ops.pick_splitk(N, K, M))
+
+
+class _LinearAct(torch.autograd.Function):
+    """y = act(x W^T + b [+ residual]) -- LinearLayer / ResidualLinearLayer core
+    (reference models/layers.py:234-254, 297-303)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, act):
+        require_cuda(x, weight)
+        shp = x.shape
+        x2 = _2d(f32c(x))
+        r2 = _2d(f32c(residual)) if residual is not None else None
+        if act:
+            y, t = ops.gemm(x2, weight, bias=bias, residual=r2, want_preact=True, act=act)
+        else:
+            y, t = ops.gemm(x2, weight, bias=bias, residual=r2), None
+        ctx.save_for_backward(x2, weight, t)
+        ctx.act = act
+        ctx.has_res = residual is not None
+        ctx.has_bias = bias is not None
+        return y.reshape(*shp[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, t = ctx.saved_tensors
+        dy2 = _2d(f32c(dy))
+        dT = ops.act_bwd(dy2, t, ctx.act) if ctx.act else dy2
+        dx = dw = db = dr = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dT, weight, a_kcontig=True, b_kcontig=False).reshape(
+                *dy.shape[:-1], weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(dT, x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dT)
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dr = dT.reshape(dy.shape)
+        return dx, dw, db, dr, None
+
+
+def linear_act(x, weight, bias=None, residual=None, act=0):
+    return _LinearAct.apply(x, weight, bias, residual, act)
+
+
+class _MLP2(torch.autograd.Function):
+    """y = act2(act1(x W1^T + b1) W2^T + b2): the two-layer MLPs that make up q/k/v
+    blocks, the FFN, the pos-cond MLP and the classifier (reference
+    models/layers.py:330-340, 389-418; models/Transformer.py:82-102).  Backward fuses
+    act1' into the epilogue of the dH GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act1, act2):
+        require_cuda(x, w1, w2)
+        shp = x.shape
+        x2 = _2d(f32c(x))
+        h, t1 = ops.gemm(x2, w1, bias=b1, want_preact=True, act=act1)
+        if act2:
+            y, t2 = ops.gemm(h, w2, bias=b2, want_preact=True, act=act2)
+        else:
+            y, t2 = ops.gemm(h, w2, bias=b2), None
+        ctx.save_for_backward(x2, w1, w2, t1, h, t2)
+        ctx.act1, ctx.act2 = act1, act2
+        return y.reshape(*shp[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, t1, h, t2 = ctx.saved_tensors
+        dy2 = _2d(f32c(dy))
+        dT2 = ops.act_bwd(dy2, t2, ctx.act2) if ctx.act2 else dy2
+        dT1 = ops.gemm(dT2, w2, a_kcontig=True, b_kcontig=False, gradz=t1, gact=ctx.act1)
+        dx = dw1 = db1 = dw2 = db2 = None
+        if ctx.needs_input_grad[3]:
+            dw2 = _wgrad(dT2, h)
+        if ctx.needs_input_grad[4]:
+            db2 = ops.colsum(dT2)
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dT1, w1, a_kcontig=True, b_kcontig=False).reshape(
+                *dy.shape[:-1], w1.shape[1])
+        if ctx.needs_input_grad[1]:
+            dw1 = _wgrad(dT1, x2)
+        if ctx.needs_input_grad[2]:
+            db1 = ops.colsum(dT1)
+        return dx, dw1, db1, dw2, db2, None, None
+
+
+def mlp2(x, w1, b1, w2, b2, act1, act2=0):
+    return _MLP2.apply(x, w1, b1, w2, b2, act1, act2)
+
+
+class _Mul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        require_cuda(a, b)
+        a, b = f32c(a), f32c(b)
+        ctx.save_for_backward(a, b)
+        return ops.mul_fwd(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        da, db = ops.mul_bwd(f32c(dy), a, b)
+        return da, db
+
+
+def mul(a, b):
+    return _Mul.apply(a, b)
+
+
+class _LayerNormAffine(torch.autograd.Function):
+    """nn.LayerNorm(D) with gamma/beta (encoder blocks)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        require_cuda(x, gamma, beta)
+        x2 = _2d(f32c(x))
+        y, mean, rstd = ops.layernorm_fwd(x2, gamma=gamma, beta=beta, eps=eps)
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        dy2 = _2d(f32c(dy))
+        dx, dyx = ops.layernorm_bwd(dy2, x2, mean, rstd, gamma=gamma, want_dy_xhat=True)
+        return dx.reshape(dy.shape), ops.colsum(dyx), ops.colsum(dy2), None
+
+
+def layernorm_affine(x, gamma, beta, eps=1e-5):
+    return _LayerNormAffine.apply(x, gamma, beta, eps)
+
+
+class _LayerNormMod(torch.autograd.Function):
+    """AdaLNZero: scale * LayerNorm_noaffine(x) + shift, scale/shift per token
+    (reference models/layers.py:146-153)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, eps):
+        require_cuda(x, scale, shift)
+        x2 = _2d(f32c(x))
+        s2 = _2d(f32c(scale))
+        y, mean, rstd = ops.layernorm_fwd(x2, scale=s2, shift=_2d(f32c(shift)), eps=eps)
+        ctx.save_for_backward(x2, s2, mean, rstd)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, s2, mean, rstd = ctx.saved_tensors
+        dy2 = _2d(f32c(dy))
+        dx, dscale = ops.layernorm_bwd(dy2, x2, mean, rstd, scale=s2, want_dy_xhat=True)
+        return dx.reshape(dy.shape), dscale.reshape(dy.shape), dy, None
+
+
+def layernorm_mod(x, scale, shift, eps=1e-5):
+    return _LayerNormMod.apply(x, scale, shift, eps)
+
+
+class _Attention(torch.autograd.Function):
+    """softmax(QK^T/sqrt(d) [causal]) V per head on (N,S,H*d) tensors
+    (reference models/layers.py:433-474)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, causal):
+        require_cuda(q, k, v)
+        q, k, v = f32c(q), f32c(k), f32c(v)
+        o, lse = ops.attention_fwd(q, k, v, heads, causal)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.heads, ctx.causal = heads, causal
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        dq, dk, dv = ops.attention_bwd(q, k, v, o, f32c(do), lse, ctx.heads, ctx.causal)
+        return dq, dk, dv, None, None
+
+
+def attention(q, k, v, heads, causal):
+    return _Attention.apply(q, k, v, heads, causal)
+
+
+class _EmbeddingPos(torch.autograd.Function):
+    """table[ids] + pe[s] (reference models/Transformer.py:127-139, 154-167)."""
+
+    @staticmethod
+    def forward(ctx, ids, table, pe):
+        require_cuda(ids, table)
+        ctx.save_for_backward(ids)
+        ctx.V = table.shape[0]
+        return ops.embedding_fwd(ids, table, pe)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        return None, ops.embedding_bwd(ids, dy, ctx.V), None
+
+
+def embedding_pos(ids, table, pe=None):
+    return _EmbeddingPos.apply(ids, table, pe)
+
+
+class _CrossEntropy(torch.autograd.Function):
+    """mean CE over rows; the logits gradient is produced in the forward pass."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        require_cuda(logits, target)
+        l2 = _2d(f32c(logits))
+        t = target.reshape(-1)
+        if t.dtype != torch.int64:
+            t = t.long()
+        loss, dl = ops.cross_entropy_fwd(l2, t.contiguous(), want_grad=True)
+        ctx.save_for_backward(dl)
+        ctx.shape = logits.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dl,) = ctx.saved_tensors
+        return ops.scale_by(dl, f32c(dloss).reshape(1)).reshape(ctx.shape), None
+
+
+def cross_entropy(logits, target):
+    return _CrossEntropy.apply(logits, target)
+
+
+class _Activation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        require_cuda(x)
+        x = f32c(x)
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return ops.act_fwd(x, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.act_bwd(f32c(dy), x, ctx.act), None
+
+
+def activation(x, act):
+    return _Activation.apply(x, act) if act else x

@@ -98,3 +98,251 @@ def pick_splitk(M, N, K):
         return 1
     s = min(max(1, 512 // tiles), K // 512)
     return max(1, min(s, 32))
+
+
+# ------------------------------------------------------------ shared small helpers
+_flag_cache = {}
+
+
+def _bad_flag(device):
+    """Device int the kernels set when they meet an out-of-range index."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    f = _flag_cache.get(key)
+    if f is None:
+        f = torch.zeros(1, dtype=torch.int32, device=device)
+        _flag_cache[key] = f
+    return f
+
+
+def check_index_flag(device, what):
+    """Raises IndexError (what torch's embedding / nll_loss would do) if a kernel
+    flagged an out-of-range index.  Synchronises; callers use it where the reference
+    already synchronises (loss.item()) or in tests/debug mode."""
+    f = _bad_flag(device)
+    if int(f.item()) != 0:
+        f.zero_()
+        raise IndexError(f"{what}: index out of range")
+
+
+def _i64c(t):
+    if t.dtype != torch.int64:
+        t = t.long()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------- codebook
+def patchify(image, patch_dim):
+    """(N,C,H,W) -> (N,Seq,D).  reference models/layers.py:8-34"""
+    require_cuda(image)
+    image = f32c(image)
+    N, C, H, W = image.shape
+    pH, pW = patch_dim
+    if H % pH or W % pW:  # the reference truncates silently (`//`)
+        image = image[:, :, :H // pH * pH, :W // pW * pW].contiguous()
+        N, C, H, W = image.shape
+    out = torch.empty((N, (H // pH) * (W // pW), C * pH * pW), dtype=torch.float32,
+                      device=image.device)
+    check(_lib.load().qarig_patchify_fwd(ptr(image), N, C, H, W, pH, pW, ptr(out), stream()),
+          "qarig_patchify_fwd")
+    return out
+
+
+def unpatchify(patches, image_dim, patch_dim):
+    """(N,Seq,D) -> (N,C,H,W).  reference models/layers.py:37-71"""
+    require_cuda(patches)
+    patches = f32c(patches)
+    H, W = image_dim
+    pH, pW = patch_dim
+    N, Seq, D = patches.shape
+    C = D // (pH * pW)
+    assert Seq == (H // pH) * (W // pW) and H % pH == 0 and W % pW == 0
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=patches.device)
+    check(_lib.load().qarig_unpatchify_fwd(ptr(patches), N, C, H, W, pH, pW, ptr(out), stream()),
+          "qarig_unpatchify_fwd")
+    return out
+
+
+def codebook_gather_image(ids, codebook, image_dim, patch_dim):
+    """unpatchify(codebook[ids]).  reference models/Codebook.py:138-154"""
+    require_cuda(ids, codebook)
+    ids = _i64c(ids)
+    codebook = f32c(codebook)
+    N, Seq = ids.shape
+    H, W = image_dim
+    pH, pW = patch_dim
+    K, D = codebook.shape
+    C = D // (pH * pW)
+    assert Seq == (H // pH) * (W // pW)
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=ids.device)
+    check(_lib.load().qarig_codebook_gather_image(ptr(ids), N, C, H, W, pH, pW, ptr(codebook), K,
+                                                  ptr(out), ptr(_bad_flag(ids.device)), stream()),
+          "qarig_codebook_gather_image")
+    return out
+
+
+def gather_rows(ids, table):
+    require_cuda(ids, table)
+    ids = _i64c(ids).reshape(-1)
+    table = f32c(table)
+    K, D = table.shape
+    out = torch.empty((ids.numel(), D), dtype=torch.float32, device=table.device)
+    check(_lib.load().qarig_gather_rows(ptr(ids), ids.numel(), D, K, ptr(table), ptr(out),
+                                        ptr(_bad_flag(table.device)), stream()), "qarig_gather_rows")
+    return out
+
+
+def som_weights(bmu_idx, K, two_var):
+    require_cuda(bmu_idx)
+    bmu_idx = _i64c(bmu_idx).reshape(-1)
+    g = torch.empty((bmu_idx.numel(), K), dtype=torch.float32, device=bmu_idx.device)
+    check(_lib.load().qarig_som_weights_fwd(ptr(bmu_idx), bmu_idx.numel(), K, float(two_var), ptr(g),
+                                            stream()), "qarig_som_weights_fwd")
+    return g
+
+
+# ------------------------------------------------------------------- transformer
+_freq_cache = {}
+
+
+def pos_frequencies(D, device):
+    """exp(arange(D/2) * -ln(1e4)/(D/2-1)) computed on the host with the same torch
+    ops as the reference (layers.py:84-91), cached per (D, device)."""
+    import math
+    key = (D, str(device))
+    f = _freq_cache.get(key)
+    if f is None:
+        half = D // 2
+        c = math.log(10_000) / (half - 1)
+        f = torch.exp(torch.arange(half, dtype=torch.float32) * -c).to(device)
+        _freq_cache[key] = f
+    return f
+
+
+def posemb(pos, D):
+    """get_positional_embeddings(D, pos) -> (len(pos), D).  pos: int or float tensor."""
+    require_cuda(pos)
+    pos = pos.reshape(-1).to(torch.float32).contiguous()
+    out = torch.empty((pos.numel(), D), dtype=torch.float32, device=pos.device)
+    check(_lib.load().qarig_posemb_fwd(ptr(pos), pos.numel(), D, ptr(pos_frequencies(D, pos.device)),
+                                       ptr(out), stream()), "qarig_posemb_fwd")
+    return out
+
+
+def embedding_fwd(ids, table, pe=None):
+    """table[ids] (+ pe[s]) -> (N,S,D)."""
+    require_cuda(ids, table, pe)
+    ids = _i64c(ids)
+    N, S = ids.shape
+    V, D = table.shape
+    out = torch.empty((N, S, D), dtype=torch.float32, device=table.device)
+    check(_lib.load().qarig_embedding_fwd(ptr(ids), N * S, S, D, V, ptr(table), ptr(pe), ptr(out),
+                                          ptr(_bad_flag(table.device)), stream()),
+          "qarig_embedding_fwd")
+    return out
+
+
+def embedding_bwd(ids, dy, V):
+    ids = _i64c(ids).reshape(-1)
+    dy = f32c(dy).reshape(ids.numel(), -1)
+    D = dy.shape[1]
+    out = torch.empty((V, D), dtype=torch.float32, device=dy.device)
+    check(_lib.load().qarig_embedding_bwd(ptr(ids), ids.numel(), D, V, ptr(dy), ptr(out), stream()),
+          "qarig_embedding_bwd")
+    return out
+
+
+def layernorm_fwd(x2d, gamma=None, beta=None, scale=None, shift=None, eps=1e-5):
+    M, D = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    check(_lib.load().qarig_layernorm_fwd(ptr(x2d), M, D, eps, ptr(gamma), ptr(beta), ptr(scale),
+                                          ptr(shift), ptr(y), ptr(mean), ptr(rstd), stream()),
+          "qarig_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x2d, mean, rstd, gamma=None, scale=None, want_dy_xhat=False):
+    M, D = x2d.shape
+    dx = torch.empty_like(x2d)
+    dyx = torch.empty_like(x2d) if want_dy_xhat else None
+    check(_lib.load().qarig_layernorm_bwd(ptr(dy), ptr(x2d), ptr(mean), ptr(rstd), ptr(gamma),
+                                          ptr(scale), M, D, ptr(dx), ptr(dyx), stream()),
+          "qarig_layernorm_bwd")
+    return dx, dyx
+
+
+def attention_fwd(q, k, v, heads, causal):
+    N, Sq, D = q.shape
+    Sk = k.shape[1]
+    d = D // heads
+    o = torch.empty_like(q)
+    lse = torch.empty((N, heads, Sq), dtype=torch.float32, device=q.device)
+    check(_lib.load().qarig_attention_fwd(ptr(q), ptr(k), ptr(v), N, Sq, Sk, heads, d, int(causal),
+                                          float(d ** 0.5), ptr(o), ptr(lse), stream()),
+          "qarig_attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, dO, lse, heads, causal):
+    N, Sq, D = q.shape
+    Sk = k.shape[1]
+    d = D // heads
+    dq = torch.empty_like(q)
+    dk = torch.empty_like(k)
+    dv = torch.empty_like(v)
+    delta = torch.empty_like(lse)
+    check(_lib.load().qarig_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), N, Sq,
+                                          Sk, heads, d, int(causal), float(d ** 0.5), ptr(dq),
+                                          ptr(dk), ptr(dv), ptr(delta), stream()),
+          "qarig_attention_bwd")
+    return dq, dk, dv
+
+
+def cross_entropy_fwd(logits2d, target, want_grad=True):
+    M, C = logits2d.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits2d.device)
+    dl = torch.empty_like(logits2d) if want_grad else None
+    rows = torch.empty(M, dtype=torch.float32, device=logits2d.device)
+    check(_lib.load().qarig_cross_entropy_fwd(ptr(logits2d), ptr(target), M, C, ptr(loss), ptr(dl),
+                                              ptr(rows), ptr(_bad_flag(logits2d.device)), stream()),
+          "qarig_cross_entropy_fwd")
+    return loss, dl
+
+
+def adam_step(p, g, m, v, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale=1.0):
+    check(_lib.load().qarig_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), beta1, beta2, eps,
+                                      step_size, bc2_sqrt, grad_scale, stream()), "qarig_adam_step")
+
+
+def mul_fwd(a, b):
+    y = torch.empty_like(a)
+    check(_lib.load().qarig_mul_fwd(ptr(a), ptr(b), ptr(y), a.numel(), stream()), "qarig_mul_fwd")
+    return y
+
+
+def mul_bwd(dy, a, b):
+    da = torch.empty_like(a)
+    db = torch.empty_like(a)
+    check(_lib.load().qarig_mul_bwd(ptr(dy), ptr(a), ptr(b), ptr(da), ptr(db), a.numel(), stream()),
+          "qarig_mul_bwd")
+    return da, db
+
+
+def act_fwd(x, act):
+    y = torch.empty_like(x)
+    check(_lib.load().qarig_act_fwd(ptr(x), ptr(y), x.numel(), act, stream()), "qarig_act_fwd")
+    return y
+
+
+def act_bwd(dy, z, act):
+    dz = torch.empty_like(z)
+    check(_lib.load().qarig_act_bwd(ptr(dy), ptr(z), ptr(dz), z.numel(), act, stream()),
+          "qarig_act_bwd")
+    return dz
+
+
+def scale_by(x, s):
+    y = torch.empty_like(x)
+    check(_lib.load().qarig_scale_by(ptr(x), ptr(s), ptr(y), x.numel(), stream()), "qarig_scale_by")
+    return y
