@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline path on MI355X, BASELINE.json config 2:
+BMU codebook quantise + base decoder-only Transformer TRAIN step (fwd + CE + bwd +
+Adam), 128x128 images == 32x32x4 latents, batch 64 per GPU, fp32.
+
+One "step" = one pass of the hot loop of train_quantized_transformer.py (reference
+:404-514) over one batch of synthetic latents already resident in HBM:
+  BMU(LR codebook, patch 32) + BMU(HR codebook, patch 2) -> 257-token sequences ->
+  random 256-token window -> 7-layer DiT-style decoder (512 / 2048 / 64 heads,
+  AdaLN-Zero on window positions) -> CE -> backward -> [RCCL all-reduce] -> Adam.
+value = image tokens trained per second, whole job (weak scaling: 64 latents / GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
+(the fp32 MFMA GEMM family, timed live with HIP events around every launch of the
+timed region) and `cpu_baseline` (the torch-CPU oracle of the same step on the host
+cores, a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "quantized-autoregression-image-generator_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBPS = 8000.0
+
+CFG = dict(batch=64, latent=(4, 32, 32), k_lr=512, k_hr=512, lr_patch=32, hr_patch=2, window=256,
+           in_dim=512, hidden=2048, heads=64, dec_layers=7, lr=1e-4)
+
+
+def build_models(device, cfg, seed=3):
+    from models.Codebook import Codebook
+    from models.Transformer import Transformer
+    g = torch.Generator().manual_seed(2)
+    C, H, W = cfg["latent"]
+    lr_cb = Codebook(patch_dim=(cfg["lr_patch"],) * 2, image_dim=(H, W), image_channel=C,
+                     num_embeddings=cfg["k_lr"], init_neighbour_range=4)
+    hr_cb = Codebook(patch_dim=(cfg["hr_patch"],) * 2, image_dim=(H, W), image_channel=C,
+                     num_embeddings=cfg["k_hr"], init_neighbour_range=4)
+    with torch.no_grad():  # trained-like codebooks: tanh(N(0,1))
+        lr_cb.codebook.weight.copy_(torch.tanh(torch.randn(lr_cb.codebook.weight.shape, generator=g)))
+        hr_cb.codebook.weight.copy_(torch.tanh(torch.randn(hr_cb.codebook.weight.shape, generator=g)))
+    torch.manual_seed(seed)
+    model = Transformer(use_encoder=False, use_pos_cond=True, num_enc_layers=None,
+                        num_dec_layers=cfg["dec_layers"], num_enc_embedding=None,
+                        num_dec_embedding=cfg["k_lr"] + cfg["k_hr"], self_attn_heads=cfg["heads"],
+                        cross_attn_heads=None, transformer_in_dim=cfg["in_dim"],
+                        transformer_out_dim=cfg["k_hr"] + 1, transformer_hidden_dim=cfg["hidden"],
+                        hidden_activation="silu")
+    return lr_cb.to(device), hr_cb.to(device), model.to(device)
+
+
+def cpu_baseline(cfg, budget_s=25.0):
+    """The oracle (torch-CPU restatement, oracle/ref_models.py) running the same train
+    step on the host cores: batch 2 sequences of 256 tokens, as many steps as fit the
+    budget (>= 1)."""
+    from oracle import ref_models as rm
+    from oracle import bmu as obmu
+    torch.manual_seed(3)
+    lr_cb, hr_cb, model = build_models("cpu", cfg)
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point)
+          for k, v in model.state_dict().items()}
+    names = [k for k, v in sd.items() if v.requires_grad]
+    m = [torch.zeros_like(sd[k]) for k in names]
+    v = [torch.zeros_like(sd[k]) for k in names]
+    mcfg = dict(use_encoder=False, use_pos_cond=True, num_dec_layers=cfg["dec_layers"],
+                self_attn_heads=cfg["heads"], hidden_activation="silu")
+    N, W = 2, cfg["window"]
+    g = torch.Generator().manual_seed(1)
+    C, H, Wd = cfg["latent"]
+    z = torch.tanh(torch.randn((N, C, H, Wd), generator=g))
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        lr_idx = torch.from_numpy(obmu.bmu(z.numpy(), lr_cb.codebook.weight.detach().numpy(),
+                                           (cfg["lr_patch"],) * 2)).reshape(N, -1)
+        hr_idx = torch.from_numpy(obmu.bmu(z.numpy(), hr_cb.codebook.weight.detach().numpy(),
+                                           (cfg["hr_patch"],) * 2)).reshape(N, -1)
+        x = torch.cat((lr_idx, hr_idx + cfg["k_lr"]), 1)[:, :W]
+        t = torch.cat((hr_idx, torch.full((N, 1), cfg["k_hr"])), 1)[:, :W]
+        pos = torch.arange(W)[None].repeat(N, 1)
+        for k in names:
+            sd[k].grad = None
+        loss = rm.cross_entropy(rm.transformer_forward(sd, mcfg, x, None, pos), t)
+        loss.backward()
+        with torch.no_grad():
+            rm.adam_step([sd[k] for k in names], [sd[k].grad for k in names], m, v, steps + 1,
+                         cfg["lr"])
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 8:
+            break
+    return {"value": round(steps * N * W / el, 2), "unit": "image-tokens/s",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} train steps (BMU + fwd + CE + bwd + Adam) of batch {N} x {W} "
+                      f"tokens, torch-CPU oracle, {torch.get_num_threads()} threads of "
+                      f"{os.cpu_count()} host cpus, {el:.1f} s"}
+
+
+def bmu_side_measure(device):
+    """BMU argmin GB/s on a C4-sized launch (65,536 patch rows, K=512, D=16), timed
+    with HIP events on the launch stream; algorithmic bytes = 4*D + 8 per row."""
+    from qarig import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.tanh(torch.randn((64, 4, 64, 64), generator=g)).to(device)
+    w = torch.tanh(torch.randn((512, 16), generator=g)).to(device)
+    for _ in range(2):
+        ops.bmu(x, w, (2, 2))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        ops.bmu(x, w, (2, 2))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    rows = 64 * 32 * 32
+    gb = rows * (4 * 16 + 8) / 1e9
+    fl = rows * 2.0 * 512 * (16 + 2)
+    return {"rows": rows, "K": 512, "D": 16, "ms": round(ms, 4),
+            "rows_per_s": round(rows / ms * 1e3, 1),
+            "algorithmic_GBps": round(gb / ms * 1e3, 2),
+            "frac_of_hbm_peak": round(gb / ms * 1e3 / HBM_PEAK_GBPS, 5),
+            "TFLOPs": round(fl / ms / 1e9, 2),
+            "frac_of_f32_peak": round(fl / ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    from qarig import ops, parallel, pipeline
+    from qarig.optim import FlatAdam
+
+    world, rank, local = parallel.init()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    cfg = CFG
+
+    lr_cb, hr_cb, model = build_models(device, cfg)
+    optim = FlatAdam(model.parameters(), lr=cfg["lr"], betas=(0.5, 0.999))
+    parallel.broadcast_params(optim.flat_param)
+
+    C, H, W = cfg["latent"]
+    N = cfg["batch"]
+    g = torch.Generator().manual_seed(1)
+    # global batch drawn once, sliced per rank; already resident in HBM when timing starts
+    z_all = torch.tanh(torch.randn((N * world, C, H, W), generator=g))
+    z = parallel.shard(z_all).contiguous().to(device)
+    seq = (H // cfg["hr_patch"]) * (W // cfg["hr_patch"]) + 1
+    nwin = pipeline.num_windows(seq, cfg["window"])
+    rng = torch.Generator().manual_seed(4)
+
+    def step():
+        rand = parallel.shard(torch.randint(0, nwin, (N * world,), generator=rng))
+        hr_in, lr_in, hr_tg = pipeline.tokenize(z, lr_cb, hr_cb, train_base_model=True)
+        hr_in, hr_tg, pos = pipeline.slide(hr_in, hr_tg, cfg["window"], rand)
+        return pipeline.train_step(model, optim, hr_in, lr_in, hr_tg, pos)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    if not args.no_kernel_events:
+        ops.GEMM_EVENTS = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
+    loss_val = float(loss.item())
+    ops.check_index_flag(device, "bench")
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    tokens = N * world * cfg["window"] * args.steps
+    out = {"metric": "image-tokens/sec (BMU quantize + base Transformer train step)",
+           "value": round(tokens / dt, 1), "unit": "image-tokens/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": "BASELINE configs[1]: BMU (K=512; LR patch 32, HR patch 2) + "
+                                  "base decoder-only Transformer train step, 32x32x4 latents "
+                                  "(128x128 images), 257-token sequences, window 256",
+                      "batch_per_gpu": N, "global_batch": N * world, "seq_len": cfg["window"],
+                      "in_dim": cfg["in_dim"], "hidden_dim": cfg["hidden"], "heads": cfg["heads"],
+                      "dec_layers": cfg["dec_layers"], "params": int(optim.total),
+                      "parallelism": f"dp{world}", "loss": round(loss_val, 5)}}
+    if rank == 0:
+        if events:
+            fl = sum(e[0] for e in events)
+            ms = sum(e[1].elapsed_time(e[2]) for e in events)
+            ach = fl / ms / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            out["roofline"] = {"bound": "mfma", "kernel": "qarig::gemm_kernel<*> (fp32 MFMA 32x32x2)",
+                               "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                               "traffic": traffic, "launches": len(events),
+                               "avg_launch_us": round(ms / len(events) * 1e3, 2),
+                               "avg_launch_gflop": round(fl / len(events) / 1e9, 3),
+                               "gemm_share_of_step": round(ms / (dt * 1e3), 3)}
+        out["bmu"] = bmu_side_measure(device)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,6 +47,10 @@ struct SrcPatch {
         valid = row < g.R;
         rowbase = valid ? patch_row_base(g, row) : 0;
     }
+    __device__ __forceinline__ bool interior(int, int, int) const { return false; }
+    __device__ __forceinline__ void load_fast(float (&r)[STAGE], int x0, int k0, int tid) const {
+        load(r, x0, k0, tid);
+    }
     __device__ __forceinline__ void load(float (&r)[STAGE], int /*x0*/, int k0, int tid) const {
         int e = k0 + (tid >> 7) * 8;
         int j = e % g.pW;

@@ -22,7 +22,9 @@ struct GemmEpilogue {
     int gact;
 };
 
-template <class SA, class SB>
+// FAST: every tile interior (M,N multiples of 128, every K split a multiple of 16,
+// vector-loadable operands) -- branch-free main loop, unguarded epilogue.
+template <class SA, class SB, bool FAST>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpilogue ep, int M,
                                                            int N, int K, int tiles_n, int splitk,
                                                            float* slabs) {
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpi
 
     Acc acc;
     acc_zero(acc);
-    contract(acc, sa, sb, m0, n0, k_begin, k_end, lds);
+    contract_loop<FAST>(acc, sa, sb, m0, n0, k_begin, k_end, lds);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -51,12 +53,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpi
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + cl;
-            if (col >= N) continue;
+            if (!FAST && col >= N) continue;
             const float b = (ep.bias && splitk == 1) ? ep.bias[col] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
-                if (row >= M) continue;
+                if (!FAST && row >= M) continue;
                 float t = acc.t[i][j][r];
                 if (splitk > 1) {
                     slabs[((int64_t)blockIdx.z * M + row) * N + col] = t;
@@ -139,27 +141,27 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
     hipStream_t st = (hipStream_t)stream;
     float* slabs = (float*)workspace;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    if (a_kcontig && b_kcontig) {
-        SrcKContig sa{A, lda, M, K, 1.0f, al16(A) && lda % 4 == 0};
-        SrcKContig sb{B, ldb, N, K, 1.0f, al16(B) && ldb % 4 == 0};
-        hipLaunchKernelGGL((gemm_kernel<SrcKContig, SrcKContig>), grid, block, 0, st, sa, sb, ep, M,
-                           N, K, tiles_n, splitk, slabs);
-    } else if (a_kcontig && !b_kcontig) {
-        SrcKContig sa{A, lda, M, K, 1.0f, al16(A) && lda % 4 == 0};
-        SrcXContig sb{B, ldb, N, K, 1.0f, al16(B) && ldb % 4 == 0};
-        hipLaunchKernelGGL((gemm_kernel<SrcKContig, SrcXContig>), grid, block, 0, st, sa, sb, ep, M,
-                           N, K, tiles_n, splitk, slabs);
-    } else if (!a_kcontig && !b_kcontig) {
-        SrcXContig sa{A, lda, M, K, 1.0f, al16(A) && lda % 4 == 0};
-        SrcXContig sb{B, ldb, N, K, 1.0f, al16(B) && ldb % 4 == 0};
-        hipLaunchKernelGGL((gemm_kernel<SrcXContig, SrcXContig>), grid, block, 0, st, sa, sb, ep, M,
-                           N, K, tiles_n, splitk, slabs);
-    } else {
-        SrcXContig sa{A, lda, M, K, 1.0f, al16(A) && lda % 4 == 0};
-        SrcKContig sb{B, ldb, N, K, 1.0f, al16(B) && ldb % 4 == 0};
-        hipLaunchKernelGGL((gemm_kernel<SrcXContig, SrcKContig>), grid, block, 0, st, sa, sb, ep, M,
-                           N, K, tiles_n, splitk, slabs);
-    }
+    const bool va = al16(A) && lda % 4 == 0, vb = al16(B) && ldb % 4 == 0;
+    int per = K;
+    if (splitk > 1) per = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
+    const bool fast = va && vb && M % BM == 0 && N % BN == 0 && K % BK == 0 &&
+                      (splitk == 1 || K % per == 0);
+#define QARIG_LAUNCH_GEMM(TA, TB)                                                              \
+    do {                                                                                       \
+        TA sa{A, lda, M, K, 1.0f, va};                                                         \
+        TB sb{B, ldb, N, K, 1.0f, vb};                                                         \
+        if (fast)                                                                              \
+            hipLaunchKernelGGL((gemm_kernel<TA, TB, true>), grid, block, 0, st, sa, sb, ep, M, \
+                               N, K, tiles_n, splitk, slabs);                                  \
+        else                                                                                   \
+            hipLaunchKernelGGL((gemm_kernel<TA, TB, false>), grid, block, 0, st, sa, sb, ep, M,\
+                               N, K, tiles_n, splitk, slabs);                                  \
+    } while (0)
+    if (a_kcontig && b_kcontig) QARIG_LAUNCH_GEMM(SrcKContig, SrcKContig);
+    else if (a_kcontig && !b_kcontig) QARIG_LAUNCH_GEMM(SrcKContig, SrcXContig);
+    else if (!a_kcontig && !b_kcontig) QARIG_LAUNCH_GEMM(SrcXContig, SrcXContig);
+    else QARIG_LAUNCH_GEMM(SrcXContig, SrcKContig);
+#undef QARIG_LAUNCH_GEMM
     QARIG_CHECK_LAUNCH("gemm");
     if (splitk > 1) {
         const int64_t total = (int64_t)M * N;

@@ -134,6 +134,17 @@ struct SrcKContig {
                 r[j] = (x < X && k + j < K) ? p[(int64_t)x * ld + k + j] : 0.0f;
         }
     }
+    // whole 128 x [k_begin,k_end) panel in range and vector-loadable (block-uniform)
+    __device__ __forceinline__ bool interior(int x0, int k_begin, int k_end) const {
+        return vec4 && x0 + 128 <= X && k_end <= K && ((k_end - k_begin) % BK) == 0;
+    }
+    __device__ __forceinline__ void load_fast(float (&r)[STAGE], int x0, int k0, int tid) const {
+        const float4* q = reinterpret_cast<const float4*>(
+            p + (int64_t)(x0 + (tid >> 1)) * ld + k0 + (tid & 1) * 8);
+        const float4 a = q[0], b = q[1];
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+        r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+    }
     __device__ __forceinline__ void store(const float (&r)[STAGE], float* T, int tid) const {
         const int x = tid >> 1;
         const int k = (tid & 1) * 8;
@@ -166,6 +177,16 @@ struct SrcXContig {
             }
         }
     }
+    __device__ __forceinline__ bool interior(int x0, int k_begin, int k_end) const {
+        return vec4 && x0 + 128 <= X && k_end <= K && ((k_end - k_begin) % BK) == 0;
+    }
+    __device__ __forceinline__ void load_fast(float (&r)[STAGE], int x0, int k0, int tid) const {
+        const float* q = p + (int64_t)(k0 + (tid >> 5)) * ld + x0 + (tid & 31) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(q);
+        const float4 b = *reinterpret_cast<const float4*>(q + 8 * ld);
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+        r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+    }
     __device__ __forceinline__ void store(const float (&r)[STAGE], float* T, int tid) const {
         const int x = (tid & 31) * 4;
 #pragma unroll
@@ -178,15 +199,41 @@ struct SrcXContig {
     }
 };
 
-// One BK-deep slab of MFMAs from staged tiles TA/TB for this wave.
-// ksteps = number of 2-deep MFMA steps that carry data (<= BK/2).
+// One BK-deep slab of MFMAs from staged tiles TA/TB for this wave.  KS = number of
+// 2-deep MFMA steps, a compile-time constant on the main path so the whole slab is
+// straight-line code: all fragment reads are issued up front and the compiler waits
+// with counted lgkmcnt, never on the global prefetch that is in flight.
+template <int KS>
 __device__ __forceinline__ void mma_tile(Acc& acc, const float* TA, const float* TB, int wm,
-                                         int wn, int lane, int ksteps) {
+                                         int wn, int lane) {
     const int x = lane & 31;
     const int h = lane >> 5;
     const float* pa = TA + h * LDT + wm * 64 + x;
     const float* pb = TB + h * LDT + wn * 64 + x;
-#pragma unroll 4
+    float a0[KS], a1[KS], b0[KS], b1[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        a0[s] = pa[(2 * s) * LDT];
+        a1[s] = pa[(2 * s) * LDT + 32];
+        b0[s] = pb[(2 * s) * LDT];
+        b1[s] = pb[(2 * s) * LDT + 32];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        acc.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc.t[0][0], 0, 0, 0);
+        acc.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc.t[0][1], 0, 0, 0);
+        acc.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc.t[1][0], 0, 0, 0);
+        acc.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc.t[1][1], 0, 0, 0);
+    }
+}
+
+// Ragged tail (reduction extent not a multiple of BK): runtime step count.
+__device__ __forceinline__ void mma_tile_tail(Acc& acc, const float* TA, const float* TB, int wm,
+                                              int wn, int lane, int ksteps) {
+    const int x = lane & 31;
+    const int h = lane >> 5;
+    const float* pa = TA + h * LDT + wm * 64 + x;
+    const float* pb = TB + h * LDT + wn * 64 + x;
     for (int s = 0; s < ksteps; ++s) {
         const float a0 = pa[(2 * s) * LDT];
         const float a1 = pa[(2 * s) * LDT + 32];
@@ -203,41 +250,78 @@ __device__ __forceinline__ void mma_tile(Acc& acc, const float* TA, const float*
 // double-buffered LDS tiles.  `lds` holds GEMM_LDS_FLOATS floats.  All threads of
 // the block must call it; it ends with the tiles no longer in use (a barrier has
 // been passed), so the caller may reuse `lds`.
-template <class SA, class SB>
-__device__ __forceinline__ void contract(Acc& acc, const SA& sa, const SB& sb, int m0, int n0,
-                                         int k_begin, int k_end, float* lds) {
+//
+// FAST (block-uniform): both panels are interior and vector-loadable, so the loop is
+// branch-free straight-line code -- the prefetch of tile t+1 is issued before the MFMA
+// slab of tile t and only waited for (vmcnt) at its LDS write, after the slab.
+template <bool FAST, class SA, class SB>
+__device__ __forceinline__ void contract_loop(Acc& acc, const SA& sa, const SB& sb, int m0, int n0,
+                                              int k_begin, int k_end, float* lds) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    float* TA[2] = {lds, lds + TILE_FLOATS};
-    float* TB[2] = {lds + 2 * TILE_FLOATS, lds + 3 * TILE_FLOATS};
+    float* TA0 = lds;
+    float* TA1 = lds + TILE_FLOATS;
+    float* TB0 = lds + 2 * TILE_FLOATS;
+    float* TB1 = lds + 3 * TILE_FLOATS;
 
     float ra[STAGE], rb[STAGE];
     const int nk = (k_end - k_begin + BK - 1) / BK;
     if (nk <= 0) return;
-    sa.load(ra, m0, k_begin, tid);
-    sb.load(rb, n0, k_begin, tid);
-    sa.store(ra, TA[0], tid);
-    sb.store(rb, TB[0], tid);
+    if (FAST) {
+        sa.load_fast(ra, m0, k_begin, tid);
+        sb.load_fast(rb, n0, k_begin, tid);
+    } else {
+        sa.load(ra, m0, k_begin, tid);
+        sb.load(rb, n0, k_begin, tid);
+    }
+    sa.store(ra, TA0, tid);
+    sb.store(rb, TB0, tid);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
         const int kb = k_begin + kt * BK;
         const bool more = kt + 1 < nk;
-        if (more) {
-            sa.load(ra, m0, kb + BK, tid);
-            sb.load(rb, n0, kb + BK, tid);
-        }
-        int rem = k_end - kb;
-        if (rem > BK) rem = BK;
-        mma_tile(acc, TA[cur], TB[cur], wm, wn, lane, (rem + 1) >> 1);
-        if (more) {
-            sa.store(ra, TA[cur ^ 1], tid);
-            sb.store(rb, TB[cur ^ 1], tid);
+        float* ta = (kt & 1) ? TA1 : TA0;
+        float* tb = (kt & 1) ? TB1 : TB0;
+        float* na = (kt & 1) ? TA0 : TA1;
+        float* nb = (kt & 1) ? TB0 : TB1;
+        if (FAST) {
+            // on the last tile re-load the same (valid) tile instead of branching
+            const int kn = more ? kb + BK : kb;
+            sa.load_fast(ra, m0, kn, tid);
+            sb.load_fast(rb, n0, kn, tid);
+            // keep the prefetch ABOVE the MFMA slab: hipcc's scheduler otherwise sinks
+            // the loads next to their use (the LDS write) and exposes their latency
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile<BK / 2>(acc, ta, tb, wm, wn, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            sa.store(ra, na, tid);
+            sb.store(rb, nb, tid);
+        } else {
+            if (more) {
+                sa.load(ra, m0, kb + BK, tid);
+                sb.load(rb, n0, kb + BK, tid);
+            }
+            const int rem = k_end - kb;
+            if (rem >= BK) mma_tile<BK / 2>(acc, ta, tb, wm, wn, lane);
+            else mma_tile_tail(acc, ta, tb, wm, wn, lane, (rem + 1) >> 1);
+            if (more) {
+                sa.store(ra, na, tid);
+                sb.store(rb, nb, tid);
+            }
         }
         __syncthreads();
     }
+}
+
+template <class SA, class SB>
+__device__ __forceinline__ void contract(Acc& acc, const SA& sa, const SB& sb, int m0, int n0,
+                                         int k_begin, int k_end, float* lds) {
+    if (sa.interior(m0, k_begin, k_end) && sb.interior(n0, k_begin, k_end))
+        contract_loop<true>(acc, sa, sb, m0, n0, k_begin, k_end, lds);
+    else
+        contract_loop<false>(acc, sa, sb, m0, n0, k_begin, k_end, lds);
 }
 
 // XCD-aware remap of a linear block id (T1 of the CDNA4 guide, bijective form):

@@ -40,6 +40,11 @@ def bmu(x, codebook, patch_dim):
 
 
 # -------------------------------------------------------------------------- GEMM
+# bench.py sets this to a list to bracket every GEMM launch with HIP events on the
+# launch stream: entries are (flops, start_event, end_event).
+GEMM_EVENTS = None
+
+
 def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_preact=False,
          act=0, gradz=None, gact=0, splitk=1, out=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/qarig.h qarig_gemm_f32.
@@ -67,6 +72,9 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
         nws = lib.qarig_gemm_workspace_bytes(M, N, splitk)
         ws = workspace(nws, A.device, "gemm")
         nws = ws.numel()
+    if GEMM_EVENTS is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib.qarig_gemm_f32(
         ptr(A), A.stride(0), int(a_kcontig), ptr(B), B.stride(0), int(b_kcontig),
         ptr(C), C.stride(0), M, N, K, ptr(bias),
@@ -74,6 +82,10 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
         ptr(pre), pre.stride(0) if pre is not None else 0, act,
         ptr(gradz), gradz.stride(0) if gradz is not None else 0, gact,
         splitk, ptr(ws), nws, stream()), "qarig_gemm_f32")
+    if GEMM_EVENTS is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        GEMM_EVENTS.append((2.0 * M * N * K, ev0, ev1))
     return (C, pre) if want_preact else C
 
 

@@ -1,0 +1,75 @@
+"""Data parallelism: one process per GPU, replicas of all weights, the minibatch
+sharded across ranks, and ONE exchange per step -- a sum all-reduce of the flat fp32
+gradient buffer over RCCL/xGMI (backend "nccl" on ROCm), divided by world size inside
+the Adam kernel (grad_scale).  Nothing else crosses GPUs (BASELINE.json north_star).
+
+The reference has no distributed code at all; equal shards + mean-CE make this
+reproduce the single-process gradient on the concatenated batch.
+On CPU (tests) the same code runs over gloo.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), \
+        int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialises torch.distributed from the torchrun environment (no-op at world 1)."""
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return world, rank, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+# xGMI is point-to-point (7 links per GPU): a few large messages keep every link busy;
+# 64 MiB buckets let the tail of one overlap the head of the next.
+BUCKET_ELEMS = 16 * 1024 * 1024
+
+
+def allreduce_flat(flat, async_op=False):
+    """Sum all-reduce of a flat tensor in large buckets.  Returns the work handles when
+    async_op (caller waits before the optimiser step)."""
+    if world_size() == 1:
+        return []
+    works = []
+    n = flat.numel()
+    for o in range(0, n, BUCKET_ELEMS):
+        w = dist.all_reduce(flat[o:min(n, o + BUCKET_ELEMS)], op=dist.ReduceOp.SUM,
+                            async_op=async_op)
+        if async_op:
+            works.append(w)
+    return works
+
+
+def shard(t, dim=0):
+    """This rank's equal slice of a globally drawn tensor (RNG drawn once, globally,
+    then sliced -- SURVEY.md 7-9)."""
+    w, r = world_size(), rank()
+    if w == 1:
+        return t
+    per = t.shape[dim] // w
+    return t.narrow(dim, r * per, per)
+
+
+def broadcast_params(flat_param, src=0):
+    if world_size() > 1:
+        dist.broadcast(flat_param, src=src)
