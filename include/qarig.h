@@ -149,6 +149,23 @@ int qarig_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);
 int qarig_act_bwd(const float* dy, const float* z, float* dz, int64_t n, int act, void* stream);
 int qarig_scale_by(const float* x, const float* s, float* y, int64_t n, void* stream);
 
+/* ---- Conv autoencoder ----------------------------------------------------------- */
+
+/* nn.Conv2d(k<=4, stride, padding) + bias + activation, NCHW -- ConvLayer /
+ * DownsampleConvLayer, models/layers.py:157-184, 211-230 (3x3, stride 1|2, pad 1 in the
+ * reference).  x (N,Cin,H,W); w (Cout,Cin,k,k); y (N,Cout,Ho,Wo); preact (optional,
+ * same shape as y) receives the pre-activation. */
+int qarig_conv2d_fwd(const float* x, int N, int Cin, int H, int W, const float* w,
+                     const float* bias, int Cout, int k, int stride, int pad, int act, float* y,
+                     float* preact, void* stream);
+
+/* nn.ConvTranspose2d(4, stride 2, padding 1) + bias + activation -- UpsampleConvLayer,
+ * models/layers.py:188-207.  x (N,Cin,H,W); w (Cin,Cout,4,4); y (N,Cout,2H,2W). */
+size_t qarig_conv_transpose2d_workspace_bytes(int Cin, int Cout);
+int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H, int W, const float* w,
+                               const float* bias, int Cout, int act, float* y, float* preact,
+                               void* workspace, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

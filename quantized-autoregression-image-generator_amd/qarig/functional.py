@@ -263,3 +263,56 @@ class _Activation(torch.autograd.Function):
 
 def activation(x, act):
     return _Activation.apply(x, act) if act else x
+
+
+class _Conv2dAct(torch.autograd.Function):
+    """Conv2d + bias + activation (reference models/layers.py:157-184, 211-230)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act):
+        need = any(ctx.needs_input_grad)
+        if need and act:
+            y, pre = ops.conv2d_fwd(x, weight, bias, stride, pad, act, want_preact=True)
+        else:
+            y, pre = ops.conv2d_fwd(x, weight, bias, stride, pad, act), None
+        ctx.save_for_backward(x, weight, pre)
+        ctx.cfg = (stride, pad, act, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import conv_backward
+        x, weight, pre = ctx.saved_tensors
+        stride, pad, act, has_bias = ctx.cfg
+        return conv_backward.conv2d_bwd(ctx, dy, x, weight, pre, stride, pad, act, has_bias) + \
+            (None, None, None)
+
+
+def conv2d_act(x, weight, bias, stride=1, pad=1, act=0):
+    return _Conv2dAct.apply(x, weight, bias, stride, pad, act)
+
+
+class _ConvT2dAct(torch.autograd.Function):
+    """ConvTranspose2d(4,2,1) + bias + activation (reference models/layers.py:188-207)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        need = any(ctx.needs_input_grad)
+        if need and act:
+            y, pre = ops.conv_transpose2d_fwd(x, weight, bias, act, want_preact=True)
+        else:
+            y, pre = ops.conv_transpose2d_fwd(x, weight, bias, act), None
+        ctx.save_for_backward(x, weight, pre)
+        ctx.cfg = (act, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import conv_backward
+        x, weight, pre = ctx.saved_tensors
+        act, has_bias = ctx.cfg
+        return conv_backward.conv_transpose2d_bwd(ctx, dy, x, weight, pre, act, has_bias) + (None,)
+
+
+def conv_transpose2d_act(x, weight, bias, act=0):
+    return _ConvT2dAct.apply(x, weight, bias, act)

@@ -358,3 +358,36 @@ def scale_by(x, s):
     y = torch.empty_like(x)
     check(_lib.load().qarig_scale_by(ptr(x), ptr(s), ptr(y), x.numel(), stream()), "qarig_scale_by")
     return y
+
+
+# -------------------------------------------------------------------------- conv
+def conv2d_fwd(x, weight, bias, stride, pad, act, want_preact=False):
+    """nn.Conv2d + bias + activation (reference models/layers.py:157-184, 211-230)."""
+    require_cuda(x, weight, bias)
+    x = f32c(x)
+    N, Cin, H, W = x.shape
+    Cout, Cin2, k, k2 = weight.shape
+    assert Cin == Cin2 and k == k2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    pre = torch.empty_like(y) if want_preact else None
+    check(_lib.load().qarig_conv2d_fwd(ptr(x), N, Cin, H, W, ptr(weight), ptr(bias), Cout, k, stride,
+                                       pad, act, ptr(y), ptr(pre), stream()), "qarig_conv2d_fwd")
+    return (y, pre) if want_preact else y
+
+
+def conv_transpose2d_fwd(x, weight, bias, act, want_preact=False):
+    """nn.ConvTranspose2d(4, 2, 1) + bias + activation (reference layers.py:188-207)."""
+    require_cuda(x, weight, bias)
+    x = f32c(x)
+    N, Cin, H, W = x.shape
+    Cin2, Cout, k, k2 = weight.shape
+    assert Cin == Cin2 and k == 4 and k2 == 4
+    y = torch.empty((N, Cout, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    pre = torch.empty_like(y) if want_preact else None
+    lib = _lib.load()
+    ws = workspace(lib.qarig_conv_transpose2d_workspace_bytes(Cin, Cout), x.device, "convt")
+    check(lib.qarig_conv_transpose2d_fwd(ptr(x), N, Cin, H, W, ptr(weight), ptr(bias), Cout, act,
+                                         ptr(y), ptr(pre), ptr(ws), ws.numel(), stream()),
+          "qarig_conv_transpose2d_fwd")
+    return (y, pre) if want_preact else y
