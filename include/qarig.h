@@ -166,6 +166,21 @@ int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H, int W, con
                                const float* bias, int Cout, int act, float* y, float* preact,
                                void* workspace, size_t ws_bytes, void* stream);
 
+/* autograd of the conv layers (dT = dy * act'(preact), via qarig_act_bwd, first) */
+size_t qarig_conv2d_bwd_data_workspace_bytes(int Cin, int Cout, int k);
+int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, int Wo, const float* w, int Cin,
+                          int k, int stride, int pad, int H, int W, float* dx, void* workspace,
+                          size_t ws_bytes, void* stream);
+int qarig_conv_transpose2d_bwd_data(const float* dT, int N, int Cout, int H, int W, const float* w,
+                                    int Cin, float* dx, void* stream);
+/* G (N,Cg,Gh,Gw) correlated with im2col_{k,stride,pad}(X (N,Cx,H,W)) -> dw (Cg, Cx*k*k).
+ * Conv2d: G=dT, X=input.  ConvTranspose2d(4,2,1): G=input, X=dT, k=4, stride=2, pad=1. */
+size_t qarig_conv_wgrad_workspace_bytes(int Cg, int K2, int P);
+int qarig_conv_wgrad(const float* G, int N, int Cg, int Gh, int Gw, const float* X, int Cx, int H,
+                     int W, int k, int stride, int pad, float* dw, void* workspace, size_t ws_bytes,
+                     void* stream);
+int qarig_conv_bias_grad(const float* G, int N, int C, int HW, float* db, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -188,9 +188,168 @@ __global__ void convt_pack_kernel(const float* __restrict__ w, int Cin, int Cout
     }
 }
 
+// ---------------------------------------------------------------------------
+// Backward: weight gradient.  dW[cg][(cx,kh,kw)] = sum over pixels p=(n,gy,gx) of
+//   G[n][cg][gy][gx] * X[n][cx][gy*s + kh - pad][gx*s + kw - pad]
+// a GEMM whose reduction runs over pixels (split over grid.z through fp32 slabs).
+// Conv2d: G = dT (N,Cout,Ho,Wo), X = input -> dW in (Cout,Cin,k,k) order.
+// ConvTranspose2d(4,2,1): G = input (N,Cin,H,W), X = dT (N,Cout,2H,2W), k=4,s=2,p=1
+//   -> dW in (Cin,Cout,4,4) order.  Same kernel.
+// ---------------------------------------------------------------------------
+struct WgradGeom {
+    const float* G; int Cg, Gh, Gw;      // gradient-like tensor (N, Cg, Gh, Gw)
+    const float* X; int Cx, H, W;        // tensor that is im2col'ed (N, Cx, H, W)
+    int N, k, stride, pad;
+    int P;                               // N*Gh*Gw
+    int K2;                              // Cx*k*k
+};
+
+// A side: x index = cg, reduction index = pixel.
+struct SrcGradPix {
+    WgradGeom g;
+    __device__ __forceinline__ bool interior(int, int, int) const { return false; }
+    __device__ __forceinline__ void load_fast(float (&r)[STAGE], int x0, int k0, int tid) const {
+        load(r, x0, k0, tid);
+    }
+    __device__ __forceinline__ void load(float (&r)[STAGE], int x0, int k0, int tid) const {
+        const int cg = x0 + (tid >> 1);
+        const int p0 = k0 + (tid & 1) * 8;
+        const int per = g.Gh * g.Gw;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int p = p0 + q;
+            float v = 0.0f;
+            if (cg < g.Cg && p < g.P) {
+                const int n = p / per, sp = p - n * per;
+                v = g.G[((int64_t)n * g.Cg + cg) * per + sp];
+            }
+            r[q] = v;
+        }
+    }
+    __device__ __forceinline__ void store(const float (&r)[STAGE], float* T, int tid) const {
+        const int x = tid >> 1, k = (tid & 1) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) T[(k + q) * LDT + x] = r[q];
+    }
+};
+
+// B side: x index = (cx,kh,kw), reduction index = pixel.
+struct SrcIm2colPix {
+    WgradGeom g;
+    int cx, kh, kw;
+    bool valid;
+    __device__ __forceinline__ void init(int x0, int tid) {
+        const int kidx = x0 + (tid >> 1);
+        valid = kidx < g.K2;
+        const int kk = g.k * g.k;
+        cx = valid ? kidx / kk : 0;
+        const int rem = valid ? kidx - cx * kk : 0;
+        kh = rem / g.k;
+        kw = rem - kh * g.k;
+    }
+    __device__ __forceinline__ bool interior(int, int, int) const { return false; }
+    __device__ __forceinline__ void load_fast(float (&r)[STAGE], int x0, int k0, int tid) const {
+        load(r, x0, k0, tid);
+    }
+    __device__ __forceinline__ void load(float (&r)[STAGE], int, int k0, int tid) const {
+        const int p0 = k0 + (tid & 1) * 8;
+        const int per = g.Gh * g.Gw;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int p = p0 + q;
+            float v = 0.0f;
+            if (valid && p < g.P) {
+                const int n = p / per, sp = p - n * per;
+                const int gy = sp / g.Gw, gx = sp - gy * g.Gw;
+                const int iy = gy * g.stride + kh - g.pad, ix = gx * g.stride + kw - g.pad;
+                if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                    v = g.X[(((int64_t)n * g.Cx + cx) * g.H + iy) * g.W + ix];
+            }
+            r[q] = v;
+        }
+    }
+    __device__ __forceinline__ void store(const float (&r)[STAGE], float* T, int tid) const {
+        const int x = tid >> 1, k = (tid & 1) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) T[(k + q) * LDT + x] = r[q];
+    }
+};
+
+__global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(WgradGeom g, int tiles_n,
+                                                                 int per_split,
+                                                                 float* __restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) float lds[GEMM_LDS_FLOATS];
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int k_begin = blockIdx.z * per_split;
+    const int k_end = min(g.P, k_begin + per_split);
+    SrcGradPix sa{g};
+    SrcIm2colPix sb;
+    sb.g = g;
+    sb.init(n0, threadIdx.x);
+    Acc acc;
+    acc_zero(acc);
+    contract_loop<false>(acc, sa, sb, m0, n0, k_begin, k_end, lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, cl = lane & 31;
+    float* out = slabs + (int64_t)blockIdx.z * g.Cg * g.K2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + cl;
+        if (col >= g.K2) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if (row < g.Cg) out[(int64_t)row * g.K2 + col] = acc.t[i][j][r];
+            }
+    }
+}
+
+// db[c] = sum_{n,sp} G[n][c][sp]; one block per channel, fixed order.
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ G, int N, int C,
+                                                          int HW, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float s = 0.0f;
+    for (int n = 0; n < N; ++n) {
+        const float* p = G + ((int64_t)n * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = red[0];
+}
+
+// Backward-data weight packing for Conv2d: for output-parity class (ry,rx) of dx,
+// packed[ci][(co,ty,tx)] = W[co][ci][kh0y + s*ty][kh0x + s*tx].
+__global__ void conv_bwd_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int k, int s,
+                                     int kh0y, int kh0x, int nty, int ntx,
+                                     float* __restrict__ packed) {
+    const int64_t total = (int64_t)Cin * Cout * nty * ntx;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int tx = (int)(idx % ntx);
+        int64_t t = idx / ntx;
+        const int ty = (int)(t % nty);
+        t /= nty;
+        const int co = (int)(t % Cout);
+        const int ci = (int)(t / Cout);
+        packed[idx] = w[(((int64_t)co * Cin + ci) * k + kh0y + s * ty) * k + kh0x + s * tx];
+    }
+}
+
 }  // namespace qarig
 
 using namespace qarig;
+
+extern "C" int qarig_slab_reduce_f32(const float* slabs, float* out, int64_t ldc, int M, int N,
+                                     int nslab, void* stream);
 
 static int launch_conv(const float* wmat, const ConvGeom& g, const ConvOut& o, hipStream_t st) {
     if (o.Cout <= 8) {
@@ -265,5 +424,110 @@ extern "C" int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H,
         ConvOut o{y, preact, bias, Cout, 2 * H, 2 * W, 2, py, px, act};
         if (int e = launch_conv(packed + (int64_t)cls * Cout * Cin * 4, g, o, st)) return e;
     }
+    return QARIG_OK;
+}
+
+// ------------------------------------------------------------------ backward entry points
+
+extern "C" size_t qarig_conv2d_bwd_data_workspace_bytes(int Cin, int Cout, int k) {
+    return (size_t)Cin * Cout * k * k * sizeof(float);
+}
+
+// d(input) of Conv2d: dT (N,Cout,Ho,Wo) -> dx (N,Cin,H,W).  One stride-1 implicit-GEMM
+// launch per output-parity class of dx (1 class for stride 1, 4 for stride 2), each with
+// exactly the taps that hit it.
+extern "C" int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, int Wo, const float* w,
+                                     int Cin, int k, int stride, int pad, int H, int W, float* dx,
+                                     void* workspace, size_t ws_bytes, void* stream) {
+    QARIG_CHECK_ARG(dT && w && dx, "conv2d_bwd_data: null pointer");
+    QARIG_CHECK_ARG(k >= 1 && k <= 4 && stride >= 1 && stride <= 2 && pad >= 0 && pad < k,
+                    "conv2d_bwd_data: unsupported geometry");
+    if (!workspace || ws_bytes < qarig_conv2d_bwd_data_workspace_bytes(Cin, Cout, k)) {
+        qarig_set_error("conv2d_bwd_data: workspace too small");
+        return QARIG_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* packed = (float*)workspace;
+    const int s = stride;
+    for (int ry = 0; ry < s; ++ry)
+        for (int rx = 0; rx < s; ++rx) {
+            const int gh = (H - ry + s - 1) / s, gw = (W - rx + s - 1) / s;
+            if (gh <= 0 || gw <= 0) continue;
+            const int ky0 = (ry + pad) % s, kx0 = (rx + pad) % s;
+            const int nty = ky0 < k ? (k - ky0 + s - 1) / s : 0;
+            const int ntx = kx0 < k ? (k - kx0 + s - 1) / s : 0;
+            ConvGeom g{dT, N, Cout, Ho, Wo, gh, gw, 1, nty, ntx, {0, 0, 0, 0}, {0, 0, 0, 0},
+                       Cout * nty * ntx, N * gh * gw};
+            for (int t = 0; t < nty; ++t) g.offy[t] = (ry + pad - ky0) / s - t;
+            for (int t = 0; t < ntx; ++t) g.offx[t] = (rx + pad - kx0) / s - t;
+            ConvOut o{dx, nullptr, nullptr, Cin, H, W, s, ry, rx, ACT_NONE};
+            if (nty == 0 || ntx == 0) return QARIG_ERR_ARG;  // cannot happen for pad < k
+            const int64_t total = (int64_t)Cin * Cout * nty * ntx;
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(conv_bwd_pack_kernel, dim3(blocks), dim3(256), 0, st, w, Cout, Cin, k,
+                               s, ky0, kx0, nty, ntx, packed);
+            QARIG_CHECK_LAUNCH("conv2d_bwd_data pack");
+            if (int e = launch_conv(packed, g, o, st)) return e;
+        }
+    return QARIG_OK;
+}
+
+// d(input) of ConvTranspose2d(4,2,1): dT (N,Cout,2H,2W) -> dx (N,Cin,H,W) is a
+// Conv2d(k=4, stride 2, pad 1) over dT whose weight matrix [Cin][Cout*16] is the
+// ConvTranspose weight exactly as stored.
+extern "C" int qarig_conv_transpose2d_bwd_data(const float* dT, int N, int Cout, int H, int W,
+                                               const float* w, int Cin, float* dx, void* stream) {
+    QARIG_CHECK_ARG(dT && w && dx, "conv_transpose2d_bwd_data: null pointer");
+    ConvGeom g{dT, N, Cout, 2 * H, 2 * W, H, W, 2, 4, 4, {-1, 0, 1, 2}, {-1, 0, 1, 2}, Cout * 16,
+               N * H * W};
+    ConvOut o{dx, nullptr, nullptr, Cin, H, W, 1, 0, 0, ACT_NONE};
+    return launch_conv(w, g, o, (hipStream_t)stream);
+}
+
+static int wgrad_splits(int Cg, int K2, int P) {
+    const int tiles = ((Cg + BM - 1) / BM) * ((K2 + BN - 1) / BN);
+    int s = (768 + tiles - 1) / tiles;
+    const int maxs = (P + 4 * BK - 1) / (4 * BK);
+    if (s > maxs) s = maxs;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" size_t qarig_conv_wgrad_workspace_bytes(int Cg, int K2, int P) {
+    return (size_t)wgrad_splits(Cg, K2, P) * Cg * K2 * sizeof(float);
+}
+
+// Weight gradient of Conv2d (G = dT, X = input -> dw (Cout,Cin,k,k)) and of
+// ConvTranspose2d(4,2,1) (G = input, X = dT, k=4, stride=2, pad=1 -> dw (Cin,Cout,4,4)).
+// G: (N,Cg,Gh,Gw); X: (N,Cx,H,W); dw: (Cg, Cx*k*k) row-major.
+extern "C" int qarig_conv_wgrad(const float* G, int N, int Cg, int Gh, int Gw, const float* X,
+                                int Cx, int H, int W, int k, int stride, int pad, float* dw,
+                                void* workspace, size_t ws_bytes, void* stream) {
+    QARIG_CHECK_ARG(G && X && dw, "conv_wgrad: null pointer");
+    QARIG_CHECK_ARG(N > 0 && Cg > 0 && Cx > 0 && k >= 1 && k <= 4, "conv_wgrad: bad extents");
+    QARIG_CHECK_ARG((int64_t)N * Gh * Gw < INT32_MAX, "conv_wgrad: too many pixels");
+    WgradGeom g{G, Cg, Gh, Gw, X, Cx, H, W, N, k, stride, pad, N * Gh * Gw, Cx * k * k};
+    if (!workspace || ws_bytes < qarig_conv_wgrad_workspace_bytes(Cg, g.K2, g.P)) {
+        qarig_set_error("conv_wgrad: workspace too small");
+        return QARIG_ERR_WORKSPACE;
+    }
+    const int splits = wgrad_splits(Cg, g.K2, g.P);
+    const int per = ((g.P + splits - 1) / splits + BK - 1) / BK * BK;
+    const int nsp = (g.P + per - 1) / per;
+    const int tiles_m = (Cg + BM - 1) / BM, tiles_n = (g.K2 + BN - 1) / BN;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles_m * tiles_n, 1, nsp), dim3(NTHREADS), 0, st, g,
+                       tiles_n, per, (float*)workspace);
+    QARIG_CHECK_LAUNCH("conv_wgrad");
+    return qarig_slab_reduce_f32((const float*)workspace, dw, g.K2, Cg, g.K2, nsp, stream);
+}
+
+// db[c] = sum_{n,y,x} G[n][c][y][x]  (bias gradient of both conv kinds).
+extern "C" int qarig_conv_bias_grad(const float* G, int N, int C, int HW, float* db, void* stream) {
+    QARIG_CHECK_ARG(G && db && N > 0 && C > 0 && HW > 0, "conv_bias_grad: bad arguments");
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, G, N, C, HW,
+                       db);
+    QARIG_CHECK_LAUNCH("conv_bias_grad");
     return QARIG_OK;
 }

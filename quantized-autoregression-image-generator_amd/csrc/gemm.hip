@@ -174,6 +174,18 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
     return QARIG_OK;
 }
 
+// Internal helper shared with conv.hip: out[M][N] (ld ldc) = sum_z slabs[z][M][N].
+extern "C" int qarig_slab_reduce_f32(const float* slabs, float* out, int64_t ldc, int M, int N,
+                                     int nslab, void* stream) {
+    const int64_t total = (int64_t)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, out,
+                       ldc, M, N, nslab);
+    QARIG_CHECK_LAUNCH("slab reduce");
+    return QARIG_OK;
+}
+
 extern "C" size_t qarig_colsum_workspace_bytes(int M, int N) {
     const int chunks = (M + COLSUM_ROWS - 1) / COLSUM_ROWS;
     return (size_t)chunks * N * sizeof(float);

@@ -93,3 +93,67 @@ def test_decoder_readme_shape_pixels_vs_oracle_fp64():
         y = dec.cuda()(z.cuda())
     assert y.shape == (1, 3, 128, 128)
     assert rel_err(y, ref) < PIX_TOL
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,stride,act", [
+    (2, 3, 16, 16, 8, 1, 1), (1, 16, 9, 13, 20, 1, 0), (2, 8, 16, 16, 16, 2, 1),
+    (1, 32, 8, 8, 3, 1, 2), (2, 130, 12, 10, 140, 1, 1), (1, 4, 7, 9, 12, 2, 3)])
+def test_conv2d_bwd(N, Cin, H, W, Cout, stride, act):
+    from conftest import grad_err
+    from qarig import functional as QF
+    from oracle import ref_models as rm
+    g = torch.Generator().manual_seed(Cin + Cout + 1)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    name = {0: None, 1: "silu", 2: "tanh", 3: "sigmoid"}[act]
+    a = [t.double().requires_grad_(True) for t in (x, w, b)]
+    ya = rm.activation(torch.nn.functional.conv2d(a[0], a[1], a[2], stride=stride, padding=1), name)
+    dy = torch.randn(ya.shape, generator=g)
+    (ya * dy.double()).sum().backward()
+    c = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    yc = QF.conv2d_act(c[0], c[1], c[2], stride, 1, act)
+    (yc * dy.cuda()).sum().backward()
+    for p, q in zip(c, a):
+        assert grad_err(p.grad, q.grad) < 1e-5
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout", [(2, 8, 4, 4, 8), (1, 20, 5, 7, 12), (1, 64, 8, 8, 3),
+                                            (2, 16, 6, 6, 140)])
+def test_conv_transpose2d_bwd(N, Cin, H, W, Cout):
+    from conftest import grad_err
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(Cin * Cout + 1)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cin, Cout, 4, 4), generator=g) / (4 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    a = [t.double().requires_grad_(True) for t in (x, w, b)]
+    ya = torch.nn.functional.silu(torch.nn.functional.conv_transpose2d(a[0], a[1], a[2], stride=2,
+                                                                       padding=1))
+    dy = torch.randn(ya.shape, generator=g)
+    (ya * dy.double()).sum().backward()
+    c = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    yc = QF.conv_transpose2d_act(c[0], c[1], c[2], 1)
+    (yc * dy.cuda()).sum().backward()
+    for p, q in zip(c, a):
+        assert grad_err(p.grad, q.grad) < 1e-5
+
+
+def test_autoencoder_train_grads_vs_reference_golden():
+    """BASELINE config 1 shape family (tiny): MSE recon loss, every parameter gradient
+    and the input gradient against what the reference's autograd produced."""
+    from conftest import grad_err
+    from models.Autoencoder import Autoencoder
+    g = load_golden("autoencoder")
+    m = Autoencoder(num_layers=2, image_channel=3, min_channel=8, max_channel=16, latent_channel=4,
+                    encoder_activation_type="tanh")
+    m.custom_load_state_dict(g["sd"])
+    m = m.cuda()
+    x = g["x"].cuda().requires_grad_(True)
+    y = m(x)
+    loss = ((y - x.detach()) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-6
+    assert grad_err(x.grad, g["x_grad"]) < 2e-5
+    for n, p in m.named_parameters():
+        assert grad_err(p.grad, g["grads"][n]) < 2e-5, n
