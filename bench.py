@@ -68,6 +68,10 @@ def cpu_baseline(cfg, budget_s=25.0):
     budget (>= 1)."""
     from oracle import ref_models as rm
     from oracle import bmu as obmu
+    # the GPU box gives one GPU's share of the host: 16 cores (task statement)
+    threads = max(1, min(16, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    obmu.set_threads(threads)
     torch.manual_seed(3)
     lr_cb, hr_cb, model = build_models("cpu", cfg)
     sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point)
