@@ -27,7 +27,7 @@ struct GemmEpilogue {
 template <class SA, class SB, bool FAST>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpilogue ep, int M,
                                                            int N, int K, int tiles_n, int splitk,
-                                                           float* slabs) {
+                                                           float* slabs, int vec_epi) {
     __shared__ __attribute__((aligned(16))) float lds[GEMM_LDS_FLOATS];
     const int nwg = gridDim.x;
     const int tile = xcd_remap(blockIdx.x, nwg);
@@ -48,6 +48,56 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpi
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int cl = lane & 31;
+
+    if (FAST && vec_epi) {
+        // Wide epilogue: the wave's 64x64 tile goes through its private 8 KB of LDS in two
+        // 32-row halves, so that every global access of the epilogue (C, preact, residual,
+        // gradz, slabs) is a 16-B-per-lane, 256-B-per-row dwordx4 instead of 4x as many
+        // 4-B accesses (the epilogue is store-issue bound otherwise).
+        // 4 waves x 32 x 64 floats = 32 KB <= GEMM_LDS_FLOATS; unpadded rows are conflict-free
+        // for both the b32 writes (half-waves hit different rows) and the b128 reads
+        constexpr int EL = 64;
+        float* stage = lds + wave * (32 * EL);
+        const int er = lane >> 4, ec = (lane & 15) * 4;
+        const int gc = n0 + wn * 64 + ec;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ep.bias && splitk == 1) bv = *reinterpret_cast<const float4*>(ep.bias + gc);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[acc_row(r, lane) * EL + j * 32 + cl] = acc.t[i][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int lr = it * 4 + er;
+                const int64_t row = m0 + wm * 64 + i * 32 + lr;
+                float4 t = *reinterpret_cast<const float4*>(stage + lr * EL + ec);
+                if (splitk > 1) {
+                    *reinterpret_cast<float4*>(slabs + ((int64_t)blockIdx.z * M + row) * N + gc) = t;
+                    continue;
+                }
+                t.x += bv.x; t.y += bv.y; t.z += bv.z; t.w += bv.w;
+                if (ep.residual) {
+                    const float4 rv = *reinterpret_cast<const float4*>(ep.residual + row * ep.ldr + gc);
+                    t.x += rv.x; t.y += rv.y; t.z += rv.z; t.w += rv.w;
+                }
+                if (ep.preact) *reinterpret_cast<float4*>(ep.preact + row * ep.ldp + gc) = t;
+                float4 y = make_float4(act_fwd(t.x, ep.act), act_fwd(t.y, ep.act),
+                                       act_fwd(t.z, ep.act), act_fwd(t.w, ep.act));
+                if (ep.gradz) {
+                    const float4 z = *reinterpret_cast<const float4*>(ep.gradz + row * ep.ldz + gc);
+                    y.x *= act_grad(z.x, ep.gact); y.y *= act_grad(z.y, ep.gact);
+                    y.z *= act_grad(z.z, ep.gact); y.w *= act_grad(z.w, ep.gact);
+                }
+                *reinterpret_cast<float4*>(ep.C + row * ep.ldc + gc) = y;
+            }
+            __syncthreads();
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -146,16 +196,19 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
     if (splitk > 1) per = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
     const bool fast = va && vb && M % BM == 0 && N % BN == 0 && K % BK == 0 &&
                       (splitk == 1 || K % per == 0);
+    auto ok4 = [&](const void* p, int64_t ld) { return !p || (al16(p) && ld % 4 == 0); };
+    const int vec_epi = ok4(C, ldc) && ok4(bias, 4) && ok4(residual, ldr) && ok4(preact, ldp) &&
+                        ok4(gradz, ldz) && ok4(slabs, 4);
 #define QARIG_LAUNCH_GEMM(TA, TB)                                                              \
     do {                                                                                       \
         TA sa{A, lda, M, K, 1.0f, va};                                                         \
         TB sb{B, ldb, N, K, 1.0f, vb};                                                         \
         if (fast)                                                                              \
             hipLaunchKernelGGL((gemm_kernel<TA, TB, true>), grid, block, 0, st, sa, sb, ep, M, \
-                               N, K, tiles_n, splitk, slabs);                                  \
+                               N, K, tiles_n, splitk, slabs, vec_epi);                         \
         else                                                                                   \
             hipLaunchKernelGGL((gemm_kernel<TA, TB, false>), grid, block, 0, st, sa, sb, ep, M,\
-                               N, K, tiles_n, splitk, slabs);                                  \
+                               N, K, tiles_n, splitk, slabs, 0);                               \
     } while (0)
     if (a_kcontig && b_kcontig) QARIG_LAUNCH_GEMM(SrcKContig, SrcKContig);
     else if (a_kcontig && !b_kcontig) QARIG_LAUNCH_GEMM(SrcKContig, SrcXContig);

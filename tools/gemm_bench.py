@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fp32 MFMA GEMM on the shapes of the bench step (run on the GPU
+box: `python tools/gemm_bench.py`).  Interleaved rounds in one process, HIP events."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "quantized-autoregression-image-generator_amd"))
+import torch  # noqa: E402
+from qarig import ops  # noqa: E402
+
+M = 16384
+SHAPES = [  # (name, M, N, K, a_kcontig, b_kcontig, kwargs)
+    ("fwd 512->2048 +bias+silu+preact", M, 2048, 512, True, True, dict(bias=True, act=1, pre=True)),
+    ("fwd 2048->512 +bias", M, 512, 2048, True, True, dict(bias=True)),
+    ("fwd 512->512 +bias", M, 512, 512, True, True, dict(bias=True)),
+    ("fwd 512->2048 plain", M, 2048, 512, True, True, {}),
+    ("dX  [M,2048]@[2048,512]", M, 512, 2048, True, False, {}),
+    ("dH  [M,512]@[512,2048] *act'", M, 2048, 512, True, False, dict(gradz=True)),
+    ("dW  2048x512 over M (splitk)", 2048, 512, M, False, False, dict(splitk=-1)),
+    ("dW  512x2048 over M (splitk)", 512, 2048, M, False, False, dict(splitk=-1)),
+    ("dW  512x512 over M (splitk)", 512, 512, M, False, False, dict(splitk=-1)),
+]
+
+
+def main():
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    results = {}
+    cases = []
+    for name, m, n, k, ak, bk, kw in SHAPES:
+        A = torch.randn((m, k) if ak else (k, m), device=dev, generator=g)
+        B = torch.randn((n, k) if bk else (k, n), device=dev, generator=g)
+        bias = torch.randn(n, device=dev, generator=g) if kw.get("bias") else None
+        gz = torch.randn((m, n), device=dev, generator=g) if kw.get("gradz") else None
+        sk = kw.get("splitk", 1)
+        if sk == -1:
+            sk = ops.pick_splitk(m, n, k)
+        cases.append((name, m, n, k, dict(A=A, B=B, a_kcontig=ak, b_kcontig=bk, bias=bias,
+                                          want_preact=kw.get("pre", False), act=kw.get("act", 0),
+                                          gradz=gz, gact=1 if gz is not None else 0, splitk=sk)))
+    for rnd in range(4):
+        for name, m, n, k, kw in cases:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 10
+            ops.gemm(**kw)
+            e0.record()
+            for _ in range(reps):
+                ops.gemm(**kw)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            results.setdefault(name, []).append(2.0 * m * n * k / ms / 1e9)
+    for name, m, n, k, kw in cases:
+        r = sorted(results[name])
+        print(f"{name:36s} M={m:6d} N={n:5d} K={k:6d} splitk={kw['splitk']:2d}  "
+              f"median {r[len(r) // 2]:6.1f} TF  best {r[-1]:6.1f} TF")
+
+
+if __name__ == "__main__":
+    main()
