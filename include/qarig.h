@@ -58,20 +58,22 @@ int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH, int pW,
  * [K][M] (0); same for B over N.  Epilogue, in order: + bias[n]; + residual[m][n];
  * store to preact (if given); act(); * act'(gradz[m][n]) with activation id gact (if
  * gradz given); store to C.  splitk > 1 (plain epilogue only) splits the reduction
- * over grid.z through fp32 slabs in `workspace`, summed in fixed order.
+ * over grid.z through fp32 slabs in `workspace`, summed in fixed order.  accumulate != 0
+ * (plain epilogue only) adds the product to what C already holds (weight gradients are
+ * accumulated straight into the flat .grad buffer).
  * Replaces nn.Linear (+activation) inside LinearLayer / ResidualLinearLayer
  * (models/layers.py:234-304) forward, and the three autograd contractions. */
 size_t qarig_gemm_workspace_bytes(int M, int N, int splitk);
 int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const float* B, int64_t ldb,
                    int b_kcontig, float* C, int64_t ldc, int M, int N, int K, const float* bias,
                    const float* residual, int64_t ldr, float* preact, int64_t ldp, int act,
-                   const float* gradz, int64_t ldz, int gact, int splitk, void* workspace,
-                   size_t ws_bytes, void* stream);
+                   const float* gradz, int64_t ldz, int gact, int splitk, int accumulate,
+                   void* workspace, size_t ws_bytes, void* stream);
 
 /* out[N] = column sums of X[M][N] in a fixed order (bias / LayerNorm-affine grads). */
 size_t qarig_colsum_workspace_bytes(int M, int N);
-int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, void* workspace,
-                     size_t ws_bytes, void* stream);
+int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,
+                     void* workspace, size_t ws_bytes, void* stream);
 
 /* ---- Codebook (continued) ------------------------------------------------------ */
 

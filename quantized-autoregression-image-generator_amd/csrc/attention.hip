@@ -11,6 +11,12 @@
 // v_fma directly; online softmax over chunks of 8 keys; nothing crosses lanes.
 // Backward = two such passes (lane per query for dQ, lane per key for dK/dV), scores
 // recomputed from the saved log-sum-exp: deterministic, no atomics.
+//
+// Softmax runs in base 2: scores are scaled by c = log2(e)/sqrt(d) in one multiply and
+// exponentiated with v_exp_f32 (2^x).  Against exp((q.k)/sqrt(d) - m) this perturbs each
+// probability by <= ~1e-7 absolute (the product rounding is |x| * 2^-24 in the exponent
+// and terms with large |x| are themselves tiny), two orders inside the 1e-5 tolerance
+// stated for attention tensors; the saved LSE is kept in base-2 units (internal).
 #include "qarig_common.h"
 
 namespace qarig {
@@ -19,8 +25,11 @@ constexpr int KC = 8;  // keys per online-softmax chunk
 
 struct AttnDims {
     int N, Sq, Sk, H, causal;
-    float sqrt_d;
+    float c2;   // log2(e) / sqrt(d)
+    float rsd;  // 1 / sqrt(d)
 };
+
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q,
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                 float dot = 0.0f;
 #pragma unroll
                 for (int c = 0; c < HD; ++c) dot = fmaf(qv[c], kr[c], dot);
-                t = dot / a.sqrt_d;
+                t = dot * a.c2;
                 if (a.causal && j > i) t = -INFINITY;
             }
             s[jj] = t;
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         }
         const float mn = fmaxf(m, mc);
         if (mn == -INFINITY) continue;  // only lanes whose every key so far is masked
-        const float alpha = expf(m - mn);
+        const float alpha = exp2_fast(m - mn);
         l *= alpha;
 #pragma unroll
         for (int c = 0; c < HD; ++c) ov[c] *= alpha;
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         for (int jj = 0; jj < KC; ++jj) {
             const int j = j0 + jj;
             if (j < jend) {
-                const float p = expf(s[jj] - mn);
+                const float p = exp2_fast(s[jj] - mn);
                 l += p;
                 const float* vr = vb + (int64_t)j * D;
 #pragma unroll
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         float* op = o + ((int64_t)n * a.Sq + i) * D + h * HD;
 #pragma unroll
         for (int c = 0; c < HD; ++c) op[c] = ov[c] / l;
-        lse[((int64_t)n * a.H + h) * a.Sq + i] = m + logf(l);
+        lse[((int64_t)n * a.H + h) * a.Sq + i] = m + log2f(l);   // base-2 units
     }
 }
 
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
             dot = fmaf(qv[c], kr[c], dot);
             dp = fmaf(dov[c], vr[c], dp);
         }
-        float p = expf(dot / a.sqrt_d - L);
+        float p = exp2_fast(fmaf(dot, a.c2, -L));
         if (a.causal && j > i) p = 0.0f;
         const float ds = p * (dp - dl);
 #pragma unroll
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     }
     if (active) {
 #pragma unroll
-        for (int c = 0; c < HD; ++c) dq[roff + c] = acc[c] / a.sqrt_d;
+        for (int c = 0; c < HD; ++c) dq[roff + c] = acc[c] * a.rsd;
         delta[((int64_t)n * a.H + h) * a.Sq + i] = dl;
     }
 }
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
             dot = fmaf(qr[c], kv[c], dot);
             dp = fmaf(dor[c], vv[c], dp);
         }
-        float p = expf(dot / a.sqrt_d - lb[i]);
+        float p = exp2_fast(fmaf(dot, a.c2, -lb[i]));
         if (a.causal && j > i) p = 0.0f;
         const float ds = p * (dp - db[i]);
 #pragma unroll
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
     if (active) {
 #pragma unroll
         for (int c = 0; c < HD; ++c) {
-            dk[roff + c] = dka[c] / a.sqrt_d;
+            dk[roff + c] = dka[c] * a.rsd;
             dv[roff + c] = dva[c];
         }
     }
@@ -234,7 +243,7 @@ extern "C" int qarig_attention_fwd(const float* q, const float* k, const float* 
                                    float* lse, void* stream) {
     QARIG_CHECK_ARG(q && k && v && o && lse, "attention_fwd: null pointer");
     if (int e = attn_check(N, Sq, Sk, H, d, causal)) return e;
-    AttnDims a{N, Sq, Sk, H, causal, sqrt_d};
+    AttnDims a{N, Sq, Sk, H, causal, 1.4426950408889634f / sqrt_d, 1.0f / sqrt_d};
     const int tasks = N * H * ((Sq + 63) / 64);
     dim3 grid((tasks + 3) / 4), block(256);
     QARIG_HD_DISPATCH(d, hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, block, 0,
@@ -251,7 +260,7 @@ extern "C" int qarig_attention_bwd(const float* q, const float* k, const float* 
     QARIG_CHECK_ARG(q && k && v && o && dO && lse && dq && dk && dv && delta,
                     "attention_bwd: null pointer");
     if (int e = attn_check(N, Sq, Sk, H, d, causal)) return e;
-    AttnDims a{N, Sq, Sk, H, causal, sqrt_d};
+    AttnDims a{N, Sq, Sk, H, causal, 1.4426950408889634f / sqrt_d, 1.0f / sqrt_d};
     const int qtasks = N * H * ((Sq + 63) / 64);
     const int ktasks = N * H * ((Sk + 63) / 64);
     dim3 block(256);

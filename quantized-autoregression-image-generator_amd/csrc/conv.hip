@@ -349,7 +349,7 @@ __global__ void conv_bwd_pack_kernel(const float* __restrict__ w, int Cout, int 
 using namespace qarig;
 
 extern "C" int qarig_slab_reduce_f32(const float* slabs, float* out, int64_t ldc, int M, int N,
-                                     int nslab, void* stream);
+                                     int nslab, int accumulate, void* stream);
 
 static int launch_conv(const float* wmat, const ConvGeom& g, const ConvOut& o, hipStream_t st) {
     if (o.Cout <= 8) {
@@ -520,7 +520,7 @@ extern "C" int qarig_conv_wgrad(const float* G, int N, int Cg, int Gh, int Gw, c
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles_m * tiles_n, 1, nsp), dim3(NTHREADS), 0, st, g,
                        tiles_n, per, (float*)workspace);
     QARIG_CHECK_LAUNCH("conv_wgrad");
-    return qarig_slab_reduce_f32((const float*)workspace, dw, g.K2, Cg, g.K2, nsp, stream);
+    return qarig_slab_reduce_f32((const float*)workspace, dw, g.K2, Cg, g.K2, nsp, 0, stream);
 }
 
 // db[c] = sum_{n,y,x} G[n][c][y][x]  (bias gradient of both conv kinds).

@@ -41,17 +41,25 @@ __global__ void embedding_fwd_kernel(const int64_t* __restrict__ ids, int M, int
     }
 }
 
-// dtable[v][:] = sum over m with ids[m]==v of dy[m][:], m ascending (deterministic).
-// One block per vocabulary row; the id stream is wave-uniform (scalar loads).
+// dtable[v][:] = sum over m with ids[m]==v of dy[m][:], m ascending (deterministic, no
+// atomics).  One block per vocabulary row; every wave scans the id stream 64 ids at a
+// time (coalesced) and walks only the set bits of the match ballot.
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ ids, int M,
                                                             int D, const float* __restrict__ dy,
                                                             float* __restrict__ dtable) {
     const int v = blockIdx.x;
+    const int lane = threadIdx.x & 63;
     for (int c0 = 0; c0 < D; c0 += 256) {
         const int c = c0 + threadIdx.x;
         float acc = 0.0f;
-        for (int m = 0; m < M; ++m) {
-            if (ids[m] == v && c < D) acc += dy[(int64_t)m * D + c];
+        for (int base = 0; base < M; base += 64) {
+            const int m = base + lane;
+            unsigned long long hit = __ballot(m < M && ids[m] == v);
+            while (hit) {
+                const int b = __ffsll((long long)hit) - 1;
+                hit &= hit - 1;
+                if (c < D) acc += dy[(int64_t)(base + b) * D + c];
+            }
         }
         if (c < D) dtable[(int64_t)v * D + c] = acc;
     }

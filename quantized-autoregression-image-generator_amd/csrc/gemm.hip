@@ -127,14 +127,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpi
 
 // out[i] (+ld handling) = sum_z slabs[z][i], z ascending: deterministic.
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
-                                   int64_t ldc, int M, int N, int nslab) {
+                                   int64_t ldc, int M, int N, int nslab, int accumulate) {
     const int64_t total = (int64_t)M * N;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.0f;
         for (int z = 0; z < nslab; ++z) s += slabs[(int64_t)z * total + i];
         const int64_t row = i / N, col = i - row * N;
-        out[row * ldc + col] = s;
+        out[row * ldc + col] = accumulate ? out[row * ldc + col] + s : s;
     }
 }
 
@@ -170,12 +170,18 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
                               int64_t ldb, int b_kcontig, float* C, int64_t ldc, int M, int N,
                               int K, const float* bias, const float* residual, int64_t ldr,
                               float* preact, int64_t ldp, int act, const float* gradz,
-                              int64_t ldz, int gact, int splitk, void* workspace,
+                              int64_t ldz, int gact, int splitk, int accumulate, void* workspace,
                               size_t ws_bytes, void* stream) {
     QARIG_CHECK_ARG(A && B && C, "gemm: null operand");
     QARIG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad extents M=%d N=%d K=%d", M, N, K);
     QARIG_CHECK_ARG(act >= 0 && act <= 3 && gact >= 0 && gact <= 3, "gemm: bad activation id");
     if (splitk < 1) splitk = 1;
+    if (accumulate) {
+        // C += A B^T (gradient accumulation straight into a parameter's .grad)
+        QARIG_CHECK_ARG(!bias && !residual && !preact && !gradz && act == ACT_NONE,
+                        "gemm: accumulate supports the plain epilogue only");
+        if (splitk == 1) { residual = C; ldr = ldc; }   // read-modify-write by the same lane
+    }
     if (splitk > 1) {
         QARIG_CHECK_ARG(!bias && !residual && !preact && !gradz && act == ACT_NONE,
                         "gemm: split-K supports the plain epilogue only");
@@ -221,7 +227,7 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, C, ldc, M, N,
-                           splitk);
+                           splitk, accumulate);
         QARIG_CHECK_LAUNCH("gemm slab reduce");
     }
     return QARIG_OK;
@@ -229,12 +235,12 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
 
 // Internal helper shared with conv.hip: out[M][N] (ld ldc) = sum_z slabs[z][M][N].
 extern "C" int qarig_slab_reduce_f32(const float* slabs, float* out, int64_t ldc, int M, int N,
-                                     int nslab, void* stream) {
+                                     int nslab, int accumulate, void* stream) {
     const int64_t total = (int64_t)M * N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, out,
-                       ldc, M, N, nslab);
+                       ldc, M, N, nslab, accumulate);
     QARIG_CHECK_LAUNCH("slab reduce");
     return QARIG_OK;
 }
@@ -246,7 +252,7 @@ extern "C" size_t qarig_colsum_workspace_bytes(int M, int N) {
 
 // out[N] = sum over rows of X[M][N]; fixed summation order (bit-reproducible).
 extern "C" int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out,
-                                void* workspace, size_t ws_bytes, void* stream) {
+                                int accumulate, void* workspace, size_t ws_bytes, void* stream) {
     QARIG_CHECK_ARG(X && out && M > 0 && N > 0, "colsum: bad arguments");
     if (!workspace || ws_bytes < qarig_colsum_workspace_bytes(M, N)) {
         qarig_set_error("colsum: workspace too small");
@@ -260,7 +266,7 @@ extern "C" int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float
     QARIG_CHECK_LAUNCH("colsum partial");
     int blocks = (N + 255) / 256;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, out, (int64_t)N, 1,
-                       N, chunks);
+                       N, chunks, accumulate);
     QARIG_CHECK_LAUNCH("colsum reduce");
     return QARIG_OK;
 }

@@ -270,12 +270,41 @@ __device__ __forceinline__ void contract_loop(Acc& acc, const SA& sa, const SB& 
     const int nk = (k_end - k_begin + BK - 1) / BK;
     if (nk <= 0) return;
     if (FAST) {
+        // Software pipeline, one register set, two LDS buffers:
+        //   slab t, first half | write tile t+1 (loaded half a slab + one slab ago) to the
+        //   other buffer | issue the loads of tile t+2 | slab t, second half | barrier.
+        // The LDS write and the global latency both sit under MFMAs; only the barrier and
+        // the first fragment read separate two slabs.
+        const int last = k_begin + (nk - 1) * BK;
         sa.load_fast(ra, m0, k_begin, tid);
         sb.load_fast(rb, n0, k_begin, tid);
-    } else {
-        sa.load(ra, m0, k_begin, tid);
-        sb.load(rb, n0, k_begin, tid);
+        sa.store(ra, TA0, tid);
+        sb.store(rb, TB0, tid);
+        const int k1 = min(k_begin + BK, last);
+        sa.load_fast(ra, m0, k1, tid);
+        sb.load_fast(rb, n0, k1, tid);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int kb = k_begin + kt * BK;
+            float* ta = (kt & 1) ? TA1 : TA0;
+            float* tb = (kt & 1) ? TB1 : TB0;
+            float* na = (kt & 1) ? TA0 : TA1;
+            float* nb = (kt & 1) ? TB0 : TB1;
+            mma_tile<BK / 4>(acc, ta, tb, wm, wn, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            sa.store(ra, na, tid);       // tile kt+1 (or a harmless repeat of the last tile)
+            sb.store(rb, nb, tid);
+            const int kn = min(kb + 2 * BK, last);
+            sa.load_fast(ra, m0, kn, tid);
+            sb.load_fast(rb, n0, kn, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tile<BK / 4>(acc, ta + (BK / 2) * LDT, tb + (BK / 2) * LDT, wm, wn, lane);
+            __syncthreads();
+        }
+        return;
     }
+    sa.load(ra, m0, k_begin, tid);
+    sb.load(rb, n0, k_begin, tid);
     sa.store(ra, TA0, tid);
     sb.store(rb, TB0, tid);
     __syncthreads();
@@ -286,30 +315,16 @@ __device__ __forceinline__ void contract_loop(Acc& acc, const SA& sa, const SB& 
         float* tb = (kt & 1) ? TB1 : TB0;
         float* na = (kt & 1) ? TA0 : TA1;
         float* nb = (kt & 1) ? TB0 : TB1;
-        if (FAST) {
-            // on the last tile re-load the same (valid) tile instead of branching
-            const int kn = more ? kb + BK : kb;
-            sa.load_fast(ra, m0, kn, tid);
-            sb.load_fast(rb, n0, kn, tid);
-            // keep the prefetch ABOVE the MFMA slab: hipcc's scheduler otherwise sinks
-            // the loads next to their use (the LDS write) and exposes their latency
-            __builtin_amdgcn_sched_barrier(0);
-            mma_tile<BK / 2>(acc, ta, tb, wm, wn, lane);
-            __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            sa.load(ra, m0, kb + BK, tid);
+            sb.load(rb, n0, kb + BK, tid);
+        }
+        const int rem = k_end - kb;
+        if (rem >= BK) mma_tile<BK / 2>(acc, ta, tb, wm, wn, lane);
+        else mma_tile_tail(acc, ta, tb, wm, wn, lane, (rem + 1) >> 1);
+        if (more) {
             sa.store(ra, na, tid);
             sb.store(rb, nb, tid);
-        } else {
-            if (more) {
-                sa.load(ra, m0, kb + BK, tid);
-                sb.load(rb, n0, kb + BK, tid);
-            }
-            const int rem = k_end - kb;
-            if (rem >= BK) mma_tile<BK / 2>(acc, ta, tb, wm, wn, lane);
-            else mma_tile_tail(acc, ta, tb, wm, wn, lane, (rem + 1) >> 1);
-            if (more) {
-                sa.store(ra, na, tid);
-                sb.store(rb, nb, tid);
-            }
         }
         __syncthreads();
     }

@@ -27,9 +27,9 @@ SIGNATURES = {
     "qarig_bmu_workspace_bytes": (Z, [L, I]),
     "qarig_bmu_fwd": (I, [P, I, I, I, I, I, I, P, I, I, P, P, Z, P]),
     "qarig_gemm_workspace_bytes": (Z, [I, I, I]),
-    "qarig_gemm_f32": (I, [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, P, Z, P]),
+    "qarig_gemm_f32": (I, [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, I, P, Z, P]),
     "qarig_colsum_workspace_bytes": (Z, [I, I]),
-    "qarig_colsum_f32": (I, [P, L, I, I, P, P, Z, P]),
+    "qarig_colsum_f32": (I, [P, L, I, I, P, I, P, Z, P]),
     "qarig_patchify_fwd": (I, [P, I, I, I, I, I, I, P, P]),
     "qarig_unpatchify_fwd": (I, [P, I, I, I, I, I, I, P, P]),
     "qarig_codebook_gather_image": (I, [P, I, I, I, I, I, I, P, I, P, P, P]),

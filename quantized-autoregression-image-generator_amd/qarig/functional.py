@@ -16,11 +16,40 @@ def _2d(t):
     return t.reshape(-1, t.shape[-1])
 
 
-def _wgrad(dT, X):
-    """dW[N,K] = dT^T X over the row dimension, split-K through fp32 slabs."""
+# When a parameter already owns a contiguous .grad (FlatAdam points every .grad into its
+# flat buffer), weight/bias gradients are accumulated there by the kernel itself and the
+# autograd node returns None for them: no temporary, no elementwise add pass.
+FUSED_GRAD_ACCUMULATE = True
+
+
+def _grad_slot(param):
+    if not FUSED_GRAD_ACCUMULATE or not isinstance(param, torch.nn.Parameter):
+        return None
+    g = param.grad
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.shape != param.shape:
+        return None
+    return g
+
+
+def _wgrad(dT, X, param=None):
+    """dW[N,K] = dT^T X over the row dimension, split-K through fp32 slabs.  Returns the
+    gradient, or None after accumulating it into param.grad."""
     M, N = dT.shape
     K = X.shape[1]
-    return ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=ops.pick_splitk(N, K, M))
+    sk = ops.pick_splitk(N, K, M)
+    slot = _grad_slot(param)
+    if slot is not None:
+        ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=sk, out=slot, accumulate=True)
+        return None
+    return ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=sk)
+
+
+def _bgrad(dT, param=None):
+    slot = _grad_slot(param)
+    if slot is not None:
+        ops.colsum(dT, out=slot, accumulate=True)
+        return None
+    return ops.colsum(dT)
 
 
 class _LinearAct(torch.autograd.Function):
@@ -41,6 +70,7 @@ class _LinearAct(torch.autograd.Function):
         ctx.act = act
         ctx.has_res = residual is not None
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         return y.reshape(*shp[:-1], weight.shape[0])
 
     @staticmethod
@@ -53,9 +83,9 @@ class _LinearAct(torch.autograd.Function):
             dx = ops.gemm(dT, weight, a_kcontig=True, b_kcontig=False).reshape(
                 *dy.shape[:-1], weight.shape[1])
         if ctx.needs_input_grad[1]:
-            dw = _wgrad(dT, x2)
+            dw = _wgrad(dT, x2, ctx.params[0])
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(dT)
+            db = _bgrad(dT, ctx.params[1])
         if ctx.has_res and ctx.needs_input_grad[3]:
             dr = dT.reshape(dy.shape)
         return dx, dw, db, dr, None
@@ -83,6 +113,7 @@ class _MLP2(torch.autograd.Function):
             y, t2 = ops.gemm(h, w2, bias=b2), None
         ctx.save_for_backward(x2, w1, w2, t1, h, t2)
         ctx.act1, ctx.act2 = act1, act2
+        ctx.params = (w1, b1, w2, b2)
         return y.reshape(*shp[:-1], w2.shape[0])
 
     @staticmethod
@@ -93,16 +124,16 @@ class _MLP2(torch.autograd.Function):
         dT1 = ops.gemm(dT2, w2, a_kcontig=True, b_kcontig=False, gradz=t1, gact=ctx.act1)
         dx = dw1 = db1 = dw2 = db2 = None
         if ctx.needs_input_grad[3]:
-            dw2 = _wgrad(dT2, h)
+            dw2 = _wgrad(dT2, h, ctx.params[2])
         if ctx.needs_input_grad[4]:
-            db2 = ops.colsum(dT2)
+            db2 = _bgrad(dT2, ctx.params[3])
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dT1, w1, a_kcontig=True, b_kcontig=False).reshape(
                 *dy.shape[:-1], w1.shape[1])
         if ctx.needs_input_grad[1]:
-            dw1 = _wgrad(dT1, x2)
+            dw1 = _wgrad(dT1, x2, ctx.params[0])
         if ctx.needs_input_grad[2]:
-            db1 = ops.colsum(dT1)
+            db1 = _bgrad(dT1, ctx.params[1])
         return dx, dw1, db1, dw2, db2, None, None
 
 

@@ -46,7 +46,7 @@ GEMM_EVENTS = None
 
 
 def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_preact=False,
-         act=0, gradz=None, gact=0, splitk=1, out=None):
+         act=0, gradz=None, gact=0, splitk=1, out=None, accumulate=False):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/qarig.h qarig_gemm_f32.
 
     A is (M,K) if a_kcontig else (K,M); B is (N,K) if b_kcontig else (K,N).
@@ -81,7 +81,7 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
         ptr(residual), residual.stride(0) if residual is not None else 0,
         ptr(pre), pre.stride(0) if pre is not None else 0, act,
         ptr(gradz), gradz.stride(0) if gradz is not None else 0, gact,
-        splitk, ptr(ws), nws, stream()), "qarig_gemm_f32")
+        splitk, int(accumulate), ptr(ws), nws, stream()), "qarig_gemm_f32")
     if GEMM_EVENTS is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
@@ -89,17 +89,19 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
     return (C, pre) if want_preact else C
 
 
-def colsum(X):
-    """(N,) column sums of X (M,N) in a fixed order."""
+def colsum(X, out=None, accumulate=False):
+    """(N,) column sums of X (M,N) in a fixed order (optionally added into `out`)."""
     require_cuda(X)
     assert X.dim() == 2 and X.stride(1) == 1 and X.dtype == torch.float32
     M, N = X.shape
-    out = torch.empty(N, dtype=torch.float32, device=X.device)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(N, dtype=torch.float32, device=X.device)
     lib = _lib.load()
     nb = lib.qarig_colsum_workspace_bytes(M, N)
     ws = workspace(nb, X.device, "colsum")
-    check(lib.qarig_colsum_f32(ptr(X), X.stride(0), M, N, ptr(out), ptr(ws), ws.numel(), stream()),
-          "qarig_colsum_f32")
+    check(lib.qarig_colsum_f32(ptr(X), X.stride(0), M, N, ptr(out), int(accumulate), ptr(ws),
+                               ws.numel(), stream()), "qarig_colsum_f32")
     return out
 
 
