@@ -138,6 +138,11 @@ int qarig_attention_bwd(const float* q, const float* k, const float* v, const fl
 int qarig_cross_entropy_fwd(const float* logits, const int64_t* target, int M, int C, float* loss,
                             float* dlogits, float* row_ws, int* bad_flag, void* stream);
 
+/* F.mse_loss (mean) + d/dpred -- train_autoencoder.py:215-217, train_codebook.py:233-235. */
+size_t qarig_mse_workspace_bytes(void);
+int qarig_mse_fwd(const float* pred, const float* target, int64_t n, float* loss, float* dpred,
+                  float* part_ws, void* stream);
+
 /* torch.optim.Adam step on a flat buffer -- train_quantized_transformer.py:317-320. */
 int qarig_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
                     float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale,

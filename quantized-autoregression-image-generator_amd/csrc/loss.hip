@@ -52,9 +52,49 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, 
     if (threadIdx.x == 0) out[0] = red[0] * inv_m;
 }
 
+// F.mse_loss(pred, target) (mean) and d/dpred = 2 (pred - target) / n, fixed-order sum.
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ a,
+                                                          const float* __restrict__ b, int64_t n,
+                                                          float inv_n, float* __restrict__ part,
+                                                          float* __restrict__ da) {
+    __shared__ float red[256];
+    float s = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = a[i] - b[i];
+        s = fmaf(d, d, s);
+        if (da) da[i] = 2.0f * d * inv_n;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
 }  // namespace qarig
 
 using namespace qarig;
+
+constexpr int MSE_BLOCKS = 1024;
+
+extern "C" size_t qarig_mse_workspace_bytes(void) { return MSE_BLOCKS * sizeof(float); }
+
+// F.mse_loss (train_autoencoder.py:215-217, train_codebook.py:233-235): loss (1 float),
+// dpred (n floats or NULL).  part_ws: qarig_mse_workspace_bytes().
+extern "C" int qarig_mse_fwd(const float* pred, const float* target, int64_t n, float* loss,
+                             float* dpred, float* part_ws, void* stream) {
+    QARIG_CHECK_ARG(pred && target && loss && part_ws && n > 0, "mse: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const float inv_n = 1.0f / (float)n;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(MSE_BLOCKS), dim3(256), 0, st, pred, target, n,
+                       inv_n, part_ws, dpred);
+    QARIG_CHECK_LAUNCH("mse partial");
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, part_ws, MSE_BLOCKS, inv_n, loss);
+    QARIG_CHECK_LAUNCH("mse mean");
+    return QARIG_OK;
+}
 
 // logits (M,C) fp32, target int64 (M,).  loss: 1 float.  dlogits (M,C) or NULL =
 // d(mean CE)/d(logits).  row_ws: M floats of scratch.  *bad_flag set on a target

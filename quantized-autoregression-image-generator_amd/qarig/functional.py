@@ -347,3 +347,23 @@ class _ConvT2dAct(torch.autograd.Function):
 
 def conv_transpose2d_act(x, weight, bias, act=0):
     return _ConvT2dAct.apply(x, weight, bias, act)
+
+
+class _MSELoss(torch.autograd.Function):
+    """F.mse_loss(pred, target) with gradient to pred (the target is data)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        require_cuda(pred, target)
+        loss, dp = ops.mse_fwd(f32c(pred), f32c(target.detach()), want_grad=True)
+        ctx.save_for_backward(dp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dp,) = ctx.saved_tensors
+        return ops.scale_by(dp, f32c(dloss).reshape(1)), None
+
+
+def mse_loss(pred, target):
+    return _MSELoss.apply(pred, target)

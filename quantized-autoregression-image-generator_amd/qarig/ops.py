@@ -393,3 +393,16 @@ def conv_transpose2d_fwd(x, weight, bias, act, want_preact=False):
                                          ptr(y), ptr(pre), ptr(ws), ws.numel(), stream()),
           "qarig_conv_transpose2d_fwd")
     return (y, pre) if want_preact else y
+
+
+def mse_fwd(pred, target, want_grad=True):
+    """mean((pred-target)^2) and its gradient w.r.t. pred."""
+    require_cuda(pred, target)
+    assert pred.shape == target.shape
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    dp = torch.empty_like(pred) if want_grad else None
+    lib = _lib.load()
+    part = torch.empty(lib.qarig_mse_workspace_bytes() // 4, dtype=torch.float32, device=pred.device)
+    check(lib.qarig_mse_fwd(ptr(pred), ptr(target), pred.numel(), ptr(loss), ptr(dp), ptr(part),
+                            stream()), "qarig_mse_fwd")
+    return loss, dp

@@ -73,3 +73,16 @@ def shard(t, dim=0):
 def broadcast_params(flat_param, src=0):
     if world_size() > 1:
         dist.broadcast(flat_param, src=src)
+
+
+def broadcast_host_tensor(t, src=0):
+    """Makes a host-side (CPU) tensor identical on every rank: drawn on rank `src`, sent
+    through the device when the backend is RCCL (which moves device buffers only)."""
+    if world_size() == 1:
+        return t
+    if dist.get_backend() == "nccl":
+        d = t.cuda()
+        dist.broadcast(d, src=src)
+        return d.cpu()
+    dist.broadcast(t, src=src)
+    return t

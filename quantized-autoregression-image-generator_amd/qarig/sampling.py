@@ -1,0 +1,67 @@
+"""Autoregressive token sampling as the reference does it, on the device:
+ - best-of-`num_beam` chunks of `beam_width` tokens with temperature sampling and the
+   <end> probability zeroed (generate_images.py:256-345)           -> mode "generate";
+ - plain ancestral sampling with the <end> -> 0 hack (the periodic sample inside
+   train_quantized_transformer.py:581-656)                          -> mode "train".
+The encoder half runs ONCE per stage (its input is constant across decode steps; the
+reference recomputes it on every call).  Sampling uses torch.multinomial on the device
+generator exactly like the reference on --device cuda, so a given --seed reproduces the
+reference's draw sequence as long as the logits agree.
+
+Reference quirks kept on purpose (drop-in behaviour):
+ - "generate" numbers the appended window positions cur_len + tok + 1 (position 1 is
+   never used: 0, 2, 3, ...), "train" numbers them 0, 1, 2, ...;
+ - "generate" loops while len < total_seq, so beam_width must divide total_seq."""
+import torch
+
+
+@torch.no_grad()
+def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_sliding_window,
+                    sliding_window, end_token, shift=0, num_beam=1, beam_width=1, mode="generate",
+                    progress=None):
+    """hr_input: (N, S0) int64 conditioning/start tokens.  Returns the extended (N, S) tensor
+    (first tokens included; callers strip them and undo `shift`)."""
+    assert mode in ("generate", "train")
+    device = hr_input.device
+    N = hr_input.shape[0]
+    enc = model.encode(lr_input) if model.use_encoder else None
+    pos = torch.zeros((N, 1), device=device) if use_sliding_window else None
+    start = 0
+    rows = torch.arange(N, device=device)
+    stop_len = total_seq if mode == "generate" else hr_input.shape[1] + total_seq
+    pos_off = 1 if mode == "generate" else 0
+    while hr_input.shape[1] < stop_len:
+        cur = hr_input.shape[1]
+        best_in = best_p = None
+        for _ in range(num_beam):
+            comb = torch.ones(N, device=device)
+            t_start, t_in, t_pos = start, hr_input, pos
+            for tok in range(beam_width):
+                if use_sliding_window and t_in.shape[1] >= sliding_window:
+                    t_start += 1
+                    t_pos = t_pos[:, 1:]
+                logits = model.decode(t_in[:, t_start:].contiguous(), enc, t_pos)[:, -1, :]
+                probs = torch.softmax(logits / temperature, dim=1)
+                if mode == "generate":
+                    probs[:, end_token] = 0.0          # <end> removed from consideration
+                nxt = torch.multinomial(probs, 1)
+                comb = comb * probs[rows, nxt.squeeze(1)]
+                if mode == "train":
+                    nxt[nxt == end_token] = 0          # reference HACK: <end> -> index 0
+                t_in = torch.cat((t_in, nxt + shift), dim=1)
+                if use_sliding_window:
+                    t_pos = torch.cat((t_pos, torch.full((N, 1), float(cur + tok + pos_off),
+                                                         device=device)), dim=1)
+            if best_p is None:
+                best_in, best_p = t_in, comb
+            else:  # keep, per sample, the candidate chunk with the larger probability product
+                keep = best_p >= comb
+                best_p = torch.where(keep, best_p, comb)
+                best_in = torch.where(keep[:, None], best_in, t_in)
+        start = t_start
+        hr_input = best_in.long()
+        if use_sliding_window:
+            pos = t_pos
+        if progress is not None:
+            progress(hr_input.shape[1] - 1, total_seq)
+    return hr_input

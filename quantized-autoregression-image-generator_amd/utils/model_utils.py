@@ -1,0 +1,27 @@
+"""Checkpoint I/O with the reference's on-disk contract (reference utils/model_utils.py:
+6-52): a plain dict written with torch.save to <dest>/models_checkpoint/<file_name>;
+load_model returns (ok, dict-on-CPU).  Dict schemas are the callers' (SURVEY.md 5)."""
+import os
+
+import torch
+
+
+def save_model(dest_path, file_name, model_dict, logging=print):
+    try:
+        folder = os.path.join(dest_path, "models_checkpoint")
+        os.makedirs(folder, exist_ok=True)
+        torch.save(model_dict, os.path.join(folder, file_name))
+        return True
+    except Exception as e:  # the reference swallows and reports
+        logging(f"Exception occured while saving model: {e}.")
+        return False
+
+
+def load_model(checkpoint_path, logging=print, weights_only=False):
+    """weights_only=False mirrors the reference (its checkpoints hold plain python
+    containers + tensors; pass True for files from an untrusted source)."""
+    if not os.path.exists(checkpoint_path):
+        logging("Checkpoint does not exist.")
+        return False, None
+    ckpt = torch.load(checkpoint_path, map_location=torch.device("cpu"), weights_only=weights_only)
+    return True, ckpt
