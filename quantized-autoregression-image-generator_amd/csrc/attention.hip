@@ -6,9 +6,11 @@
 //
 // The reference runs 64 heads on a 512-wide model: head dim 8.  That is too thin for
 // MFMA (K=8 / N=8 tiles) and only ~2 % of the layer's FLOPs, so the kernel is a VALU
-// one shaped for the wave: one lane per query row (q, o, m, l in registers), key/value
-// rows are wave-uniform so they come through the scalar cache (s_load) and feed
-// v_fma directly; online softmax over chunks of 8 keys; nothing crosses lanes.
+// one shaped for the wave: one lane per query row (q, o, m, l in registers); key/value
+// rows are staged through LDS per block and read back as wave-wide broadcasts (same
+// address in every lane: conflict-free), online softmax over chunks of 8 keys; nothing
+// crosses lanes.  (A first version fed K/V through s_load: each key's scalar-load latency
+// sat exposed in front of its 8 FMAs -- 4x slower than this one.)
 // Backward = two such passes (lane per query for dQ, lane per key for dK/dV), scores
 // recomputed from the saved log-sum-exp: deterministic, no atomics.
 //
@@ -31,21 +33,40 @@ struct AttnDims {
 
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Cooperative stage of `rows` consecutive (n,h) rows [row0, row0+rows) of a (N,S,H*HD)
+// tensor into LDS as dst[r][HD]; rows at or beyond `limit` are zero-filled.
+template <int HD>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ base, int D, int row0,
+                                           int rows, int limit, float* dst) {
+    constexpr int V4 = HD / 4;
+    for (int idx = threadIdx.x; idx < rows * V4; idx += 256) {
+        const int r = idx / V4, c4 = idx - r * V4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < limit)
+            v = *reinterpret_cast<const float4*>(base + (int64_t)(row0 + r) * D + c4 * 4);
+        *reinterpret_cast<float4*>(dst + r * HD + c4 * 4) = v;
+    }
+}
+
+// Forward.  Block = 256 queries of one (n,h) (lane per query); K/V rows are staged through
+// LDS in chunks of KCH keys (8 KB each) and read back as wave-wide broadcasts, so the
+// inner loop is pure VALU with its operand reads pipelined (no per-key scalar-load wait).
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q,
                                                        const float* __restrict__ k,
                                                        const float* __restrict__ v, AttnDims a,
                                                        float* __restrict__ o,
                                                        float* __restrict__ lse) {
-    const int lane = threadIdx.x & 63;
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int qtiles = (a.Sq + 63) >> 6;
-    if (task >= a.N * a.H * qtiles) return;
-    const int qt = task % qtiles, nh = task / qtiles;
+    constexpr int KCH = 2048 / HD;
+    __shared__ __attribute__((aligned(16))) float Ks[KCH * HD];
+    __shared__ __attribute__((aligned(16))) float Vs[KCH * HD];
+    const int qblocks = (a.Sq + 255) >> 8;
+    const int qb = blockIdx.x % qblocks, nh = blockIdx.x / qblocks;
     const int h = nh % a.H, n = nh / a.H;
     const int D = a.H * HD;
-    const int i = qt * 64 + lane;
+    const int i = qb * 256 + threadIdx.x;
     const bool active = i < a.Sq;
+    const int wave_last = __builtin_amdgcn_readfirstlane(qb * 256 + (threadIdx.x >> 6) * 64 + 63);
 
     float qv[HD], ov[HD];
     const float* qp = q + ((int64_t)n * a.Sq + (active ? i : 0)) * D + h * HD;
@@ -57,68 +78,71 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     float m = -INFINITY, l = 0.0f;
     const float* kb = k + (int64_t)n * a.Sk * D + h * HD;
     const float* vb = v + (int64_t)n * a.Sk * D + h * HD;
-    const int jend = a.causal ? min(a.Sk, qt * 64 + 64) : a.Sk;
+    const int jend_blk = a.causal ? min(a.Sk, qb * 256 + 256) : a.Sk;
 
-    for (int j0 = 0; j0 < jend; j0 += KC) {
-        float s[KC];
-        float mc = -INFINITY;
+    for (int c0 = 0; c0 < jend_blk; c0 += KCH) {
+        __syncthreads();
+        stage_rows<HD>(kb, D, c0, KCH, a.Sk, Ks);
+        stage_rows<HD>(vb, D, c0, KCH, a.Sk, Vs);
+        __syncthreads();
+        const int jw = a.causal ? min(c0 + KCH, min(a.Sk, wave_last + 1)) : min(c0 + KCH, a.Sk);
+        for (int j0 = c0; j0 < jw; j0 += KC) {
+            float s[KC];
+            float mc = -INFINITY;
 #pragma unroll
-        for (int jj = 0; jj < KC; ++jj) {
-            const int j = j0 + jj;
-            float t = -INFINITY;
-            if (j < jend) {
-                const float* kr = kb + (int64_t)j * D;
+            for (int jj = 0; jj < KC; ++jj) {
+                const int j = j0 + jj;
+                const float* kr = Ks + (j - c0) * HD;
                 float dot = 0.0f;
 #pragma unroll
                 for (int c = 0; c < HD; ++c) dot = fmaf(qv[c], kr[c], dot);
-                t = dot * a.c2;
-                if (a.causal && j > i) t = -INFINITY;
+                float t = dot * a.c2;
+                if (j >= jw || (a.causal && j > i)) t = -INFINITY;
+                s[jj] = t;
+                mc = fmaxf(mc, t);
             }
-            s[jj] = t;
-            mc = fmaxf(mc, t);
-        }
-        const float mn = fmaxf(m, mc);
-        if (mn == -INFINITY) continue;  // only lanes whose every key so far is masked
-        const float alpha = exp2_fast(m - mn);
-        l *= alpha;
+            const float mn = fmaxf(m, mc);
+            const float msafe = mn == -INFINITY ? 0.0f : mn;  // fully masked so far: p = 0
+            const float alpha = exp2_fast(m - msafe);
+            l *= alpha;
 #pragma unroll
-        for (int c = 0; c < HD; ++c) ov[c] *= alpha;
+            for (int c = 0; c < HD; ++c) ov[c] *= alpha;
 #pragma unroll
-        for (int jj = 0; jj < KC; ++jj) {
-            const int j = j0 + jj;
-            if (j < jend) {
-                const float p = exp2_fast(s[jj] - mn);
+            for (int jj = 0; jj < KC; ++jj) {
+                const float p = exp2_fast(s[jj] - msafe);
                 l += p;
-                const float* vr = vb + (int64_t)j * D;
+                const float* vr = Vs + (j0 + jj - c0) * HD;
 #pragma unroll
                 for (int c = 0; c < HD; ++c) ov[c] = fmaf(p, vr[c], ov[c]);
             }
+            m = mn;
         }
-        m = mn;
     }
     if (active) {
         float* op = o + ((int64_t)n * a.Sq + i) * D + h * HD;
+        const float inv = 1.0f / l;
 #pragma unroll
-        for (int c = 0; c < HD; ++c) op[c] = ov[c] / l;
+        for (int c = 0; c < HD; ++c) op[c] = ov[c] * inv;
         lse[((int64_t)n * a.H + h) * a.Sq + i] = m + log2f(l);   // base-2 units
     }
 }
 
-// dQ pass: lane per query.  Also emits delta[i] = sum_c dO[i][c]*O[i][c].
+// dQ pass: lane per query, K/V through LDS.  Also emits delta[i] = sum_c dO[i][c]*O[i][c].
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ o, const float* __restrict__ dO, const float* __restrict__ lse,
     AttnDims a, float* __restrict__ dq, float* __restrict__ delta) {
-    const int lane = threadIdx.x & 63;
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int qtiles = (a.Sq + 63) >> 6;
-    if (task >= a.N * a.H * qtiles) return;
-    const int qt = task % qtiles, nh = task / qtiles;
+    constexpr int KCH = 2048 / HD;
+    __shared__ __attribute__((aligned(16))) float Ks[KCH * HD];
+    __shared__ __attribute__((aligned(16))) float Vs[KCH * HD];
+    const int qblocks = (a.Sq + 255) >> 8;
+    const int qb = blockIdx.x % qblocks, nh = blockIdx.x / qblocks;
     const int h = nh % a.H, n = nh / a.H;
     const int D = a.H * HD;
-    const int i = qt * 64 + lane;
+    const int i = qb * 256 + threadIdx.x;
     const bool active = i < a.Sq;
+    const int wave_last = __builtin_amdgcn_readfirstlane(qb * 256 + (threadIdx.x >> 6) * 64 + 63);
     const int64_t roff = ((int64_t)n * a.Sq + (active ? i : 0)) * D + h * HD;
 
     float qv[HD], dov[HD], acc[HD];
@@ -134,21 +158,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     const float L = active ? lse[((int64_t)n * a.H + h) * a.Sq + i] : 0.0f;
     const float* kb = k + (int64_t)n * a.Sk * D + h * HD;
     const float* vb = v + (int64_t)n * a.Sk * D + h * HD;
-    const int jend = a.causal ? min(a.Sk, qt * 64 + 64) : a.Sk;
-    for (int j = 0; j < jend; ++j) {
-        const float* kr = kb + (int64_t)j * D;
-        const float* vr = vb + (int64_t)j * D;
-        float dot = 0.0f, dp = 0.0f;
+    const int jend_blk = a.causal ? min(a.Sk, qb * 256 + 256) : a.Sk;
+    for (int c0 = 0; c0 < jend_blk; c0 += KCH) {
+        __syncthreads();
+        stage_rows<HD>(kb, D, c0, KCH, a.Sk, Ks);
+        stage_rows<HD>(vb, D, c0, KCH, a.Sk, Vs);
+        __syncthreads();
+        const int jw = a.causal ? min(c0 + KCH, min(a.Sk, wave_last + 1)) : min(c0 + KCH, a.Sk);
+#pragma unroll 4
+        for (int j = c0; j < jw; ++j) {
+            const float* kr = Ks + (j - c0) * HD;
+            const float* vr = Vs + (j - c0) * HD;
+            float dot = 0.0f, dp = 0.0f;
 #pragma unroll
-        for (int c = 0; c < HD; ++c) {
-            dot = fmaf(qv[c], kr[c], dot);
-            dp = fmaf(dov[c], vr[c], dp);
+            for (int c = 0; c < HD; ++c) {
+                dot = fmaf(qv[c], kr[c], dot);
+                dp = fmaf(dov[c], vr[c], dp);
+            }
+            float p = exp2_fast(fmaf(dot, a.c2, -L));
+            if (a.causal && j > i) p = 0.0f;
+            const float ds = p * (dp - dl);
+#pragma unroll
+            for (int c = 0; c < HD; ++c) acc[c] = fmaf(ds, kr[c], acc[c]);
         }
-        float p = exp2_fast(fmaf(dot, a.c2, -L));
-        if (a.causal && j > i) p = 0.0f;
-        const float ds = p * (dp - dl);
-#pragma unroll
-        for (int c = 0; c < HD; ++c) acc[c] = fmaf(ds, kr[c], acc[c]);
     }
     if (active) {
 #pragma unroll
@@ -157,21 +189,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     }
 }
 
-// dK/dV pass: lane per key; query rows are wave-uniform.
+// dK/dV pass: lane per key; Q, dO, LSE and delta rows come through LDS.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ delta,
     AttnDims a, float* __restrict__ dk, float* __restrict__ dv) {
-    const int lane = threadIdx.x & 63;
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int ktiles = (a.Sk + 63) >> 6;
-    if (task >= a.N * a.H * ktiles) return;
-    const int kt = task % ktiles, nh = task / ktiles;
+    constexpr int QCH = 2048 / HD;
+    __shared__ __attribute__((aligned(16))) float Qs[QCH * HD];
+    __shared__ __attribute__((aligned(16))) float Gs[QCH * HD];
+    __shared__ float Ls[QCH];
+    __shared__ float Ds[QCH];
+    const int kblocks = (a.Sk + 255) >> 8;
+    const int kbk = blockIdx.x % kblocks, nh = blockIdx.x / kblocks;
     const int h = nh % a.H, n = nh / a.H;
     const int D = a.H * HD;
-    const int j = kt * 64 + lane;
+    const int j = kbk * 256 + threadIdx.x;
     const bool active = j < a.Sk;
+    const int wave_first = __builtin_amdgcn_readfirstlane(kbk * 256 + (threadIdx.x >> 6) * 64);
     const int64_t roff = ((int64_t)n * a.Sk + (active ? j : 0)) * D + h * HD;
 
     float kv[HD], vv[HD], dka[HD], dva[HD];
@@ -186,23 +221,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
     const float* dob = dO + (int64_t)n * a.Sq * D + h * HD;
     const float* lb = lse + ((int64_t)n * a.H + h) * a.Sq;
     const float* db = delta + ((int64_t)n * a.H + h) * a.Sq;
-    const int ibeg = a.causal ? kt * 64 : 0;
-    for (int i = ibeg; i < a.Sq; ++i) {
-        const float* qr = qb + (int64_t)i * D;
-        const float* dor = dob + (int64_t)i * D;
-        float dot = 0.0f, dp = 0.0f;
-#pragma unroll
-        for (int c = 0; c < HD; ++c) {
-            dot = fmaf(qr[c], kv[c], dot);
-            dp = fmaf(dor[c], vv[c], dp);
+    // causal: only queries i >= first key of the block matter
+    const int ibeg_blk = a.causal ? (kbk * 256) / QCH * QCH : 0;
+    for (int c0 = ibeg_blk; c0 < a.Sq; c0 += QCH) {
+        __syncthreads();
+        stage_rows<HD>(qb, D, c0, QCH, a.Sq, Qs);
+        stage_rows<HD>(dob, D, c0, QCH, a.Sq, Gs);
+        for (int r = threadIdx.x; r < QCH; r += 256) {
+            Ls[r] = c0 + r < a.Sq ? lb[c0 + r] : 0.0f;
+            Ds[r] = c0 + r < a.Sq ? db[c0 + r] : 0.0f;
         }
-        float p = exp2_fast(fmaf(dot, a.c2, -lb[i]));
-        if (a.causal && j > i) p = 0.0f;
-        const float ds = p * (dp - db[i]);
+        __syncthreads();
+        const int i0 = a.causal ? max(c0, wave_first) : c0;
+        const int i1 = min(c0 + QCH, a.Sq);
+#pragma unroll 4
+        for (int i = i0; i < i1; ++i) {
+            const float* qr = Qs + (i - c0) * HD;
+            const float* dor = Gs + (i - c0) * HD;
+            float dot = 0.0f, dp = 0.0f;
 #pragma unroll
-        for (int c = 0; c < HD; ++c) {
-            dva[c] = fmaf(p, dor[c], dva[c]);
-            dka[c] = fmaf(ds, qr[c], dka[c]);
+            for (int c = 0; c < HD; ++c) {
+                dot = fmaf(qr[c], kv[c], dot);
+                dp = fmaf(dor[c], vv[c], dp);
+            }
+            float p = exp2_fast(fmaf(dot, a.c2, -Ls[i - c0]));
+            if (a.causal && j > i) p = 0.0f;
+            const float ds = p * (dp - Ds[i - c0]);
+#pragma unroll
+            for (int c = 0; c < HD; ++c) {
+                dva[c] = fmaf(p, dor[c], dva[c]);
+                dka[c] = fmaf(ds, qr[c], dka[c]);
+            }
         }
     }
     if (active) {
@@ -244,8 +293,7 @@ extern "C" int qarig_attention_fwd(const float* q, const float* k, const float* 
     QARIG_CHECK_ARG(q && k && v && o && lse, "attention_fwd: null pointer");
     if (int e = attn_check(N, Sq, Sk, H, d, causal)) return e;
     AttnDims a{N, Sq, Sk, H, causal, 1.4426950408889634f / sqrt_d, 1.0f / sqrt_d};
-    const int tasks = N * H * ((Sq + 63) / 64);
-    dim3 grid((tasks + 3) / 4), block(256);
+    dim3 grid(N * H * ((Sq + 255) / 256)), block(256);
     QARIG_HD_DISPATCH(d, hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, block, 0,
                                             (hipStream_t)stream, q, k, v, a, o, lse));
     QARIG_CHECK_LAUNCH("attention_fwd");
@@ -261,14 +309,14 @@ extern "C" int qarig_attention_bwd(const float* q, const float* k, const float* 
                     "attention_bwd: null pointer");
     if (int e = attn_check(N, Sq, Sk, H, d, causal)) return e;
     AttnDims a{N, Sq, Sk, H, causal, 1.4426950408889634f / sqrt_d, 1.0f / sqrt_d};
-    const int qtasks = N * H * ((Sq + 63) / 64);
-    const int ktasks = N * H * ((Sk + 63) / 64);
+    const int qblocks = N * H * ((Sq + 255) / 256);
+    const int kblocks = N * H * ((Sk + 255) / 256);
     dim3 block(256);
-    QARIG_HD_DISPATCH(d, hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), dim3((qtasks + 3) / 4), block,
+    QARIG_HD_DISPATCH(d, hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), dim3(qblocks), block,
                                             0, (hipStream_t)stream, q, k, v, o, dO, lse, a, dq,
                                             delta));
     QARIG_CHECK_LAUNCH("attention_bwd dq");
-    QARIG_HD_DISPATCH(d, hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD>), dim3((ktasks + 3) / 4), block,
+    QARIG_HD_DISPATCH(d, hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD>), dim3(kblocks), block,
                                             0, (hipStream_t)stream, q, k, v, dO, lse, delta, a, dk,
                                             dv));
     QARIG_CHECK_LAUNCH("attention_bwd dkv");
