@@ -162,6 +162,8 @@ def main():
     lr_cb, hr_cb, model = build_models(device, cfg)
     optim = FlatAdam(model.parameters(), lr=cfg["lr"], betas=(0.5, 0.999))
     parallel.broadcast_params(optim.flat_param)
+    if os.environ.get("QARIG_DP_OVERLAP", "1") == "1":
+        optim.enable_allreduce_overlap()     # no-op at world 1
 
     C, H, W = cfg["latent"]
     N = cfg["batch"]

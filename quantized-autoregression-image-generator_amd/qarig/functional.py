@@ -31,6 +31,14 @@ def _grad_slot(param):
     return g
 
 
+def _report_done(param):
+    """Tells an overlapping optimiser (FlatAdam.enable_allreduce_overlap) that this
+    parameter's gradient is final for the step."""
+    cb = getattr(param, "_qarig_grad_done", None)
+    if cb is not None:
+        cb(param)
+
+
 def _wgrad(dT, X, param=None):
     """dW[N,K] = dT^T X over the row dimension, split-K through fp32 slabs.  Returns the
     gradient, or None after accumulating it into param.grad."""
@@ -40,6 +48,7 @@ def _wgrad(dT, X, param=None):
     slot = _grad_slot(param)
     if slot is not None:
         ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=sk, out=slot, accumulate=True)
+        _report_done(param)
         return None
     return ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=sk)
 
@@ -48,6 +57,7 @@ def _bgrad(dT, param=None):
     slot = _grad_slot(param)
     if slot is not None:
         ops.colsum(dT, out=slot, accumulate=True)
+        _report_done(param)
         return None
     return ops.colsum(dT)
 

@@ -11,8 +11,13 @@ reference checkpoints load and save unchanged.
 import math
 
 import torch
+import torch.distributed as dist
 
 from . import ops
+
+# Gradient buckets for the overlapped data-parallel all-reduce: 16 Mi floats = 64 MiB keeps
+# each xGMI link busy with few, large messages (ring collectives are per-link bound).
+BUCKET_ELEMS = 16 * 1024 * 1024
 
 
 class FlatAdam:
@@ -37,12 +42,73 @@ class FlatAdam:
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self.step_count = 0
+        self._overlap = False
+        self._works = []
         with torch.no_grad():
             for p, o, s in zip(self.params, offs, sizes):
                 view = self.flat_param[o:o + s].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_grad[o:o + s].view(p.shape)
+
+    # -- data-parallel overlap ----------------------------------------------------------
+    def enable_allreduce_overlap(self):
+        """Launch the RCCL sum all-reduce of each gradient bucket as soon as the backward
+        pass has written every gradient in it (buckets are contiguous runs of the flat
+        buffer in parameter order, i.e. whole layers; backward completes them last layer
+        first), so the exchange overlaps the rest of backward.  Completion is tracked
+        exactly: the fused weight/bias-gradient kernels report each parameter they finish
+        (qarig.functional), every other parameter through a post-accumulate-grad hook.
+        Assumes each parameter receives its gradient once per step (true for the models
+        of this repository)."""
+        if self._overlap or not (dist.is_available() and dist.is_initialized()) \
+                or dist.get_world_size() == 1:
+            return
+        self._overlap = True
+        self._bucket_of, self._bucket_range, self._pending0 = {}, [], []
+        lo, count, start_i = 0, 0, 0
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            end = o + (p.numel() + 3) // 4 * 4
+            self._bucket_of[id(p)] = len(self._bucket_range)
+            count += 1
+            last = i == len(self.params) - 1
+            if end - lo >= BUCKET_ELEMS or last:
+                self._bucket_range.append((lo, end))
+                self._pending0.append(count)
+                lo, count = end, 0
+        self._pending = list(self._pending0)
+        self._done = set()
+        for p in self.params:
+            p._qarig_grad_done = self._grad_done
+            p.register_post_accumulate_grad_hook(self._grad_done)
+
+    def _grad_done(self, p):
+        # idempotent per step: a parameter may be reported both by the fused gradient
+        # kernel path and by autograd's post-accumulate hook
+        if id(p) in self._done:
+            return
+        self._done.add(id(p))
+        b = self._bucket_of[id(p)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            lo, hi = self._bucket_range[b]
+            self._works.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM,
+                                               async_op=True))
+
+    def finish_allreduce(self):
+        """Waits for the overlapped bucket all-reduces (no-op without overlap).  Returns
+        True if this step's gradients have been reduced by the overlapped path."""
+        if not self._overlap:
+            return False
+        if any(n != 0 for n in self._pending):
+            raise RuntimeError("overlapped all-reduce: some parameters never reported a gradient "
+                               f"(pending per bucket: {self._pending})")
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self._pending = list(self._pending0)
+        self._done = set()
+        return True
 
     # -- torch.optim API subset the reference's training loops use ------------------
     def zero_grad(self, set_to_none=False):

@@ -117,6 +117,7 @@ def main():
             for g in optim.param_groups:
                 g["lr"] = model_lr
     parallel.broadcast_params(optim.flat_param)
+    optim.enable_allreduce_overlap()     # no-op at world 1
 
     dataset = FeatureMapDataset(dataset_path=args["dataset_path"], load_image=False,
                                 return_filepaths=False)

@@ -1,0 +1,107 @@
+"""Data-parallel train step on the GPU with world_size 2 (two processes sharing the one
+GPU of the test box, gloo transport for CUDA tensors; production uses the same code over
+RCCL): after one DP step on two half-batches -- with the bucketed all-reduce overlapped
+with backward, and without -- the weights equal those of a single-process step on the
+whole batch."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build():
+    from models.Transformer import Transformer
+    torch.manual_seed(11)
+    m = Transformer(use_encoder=True, use_pos_cond=True, num_enc_layers=1, num_dec_layers=2,
+                    num_enc_embedding=24, num_dec_embedding=40, self_attn_heads=4, cross_attn_heads=2,
+                    transformer_in_dim=32, transformer_out_dim=33, transformer_hidden_dim=64)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.abs().max() == 0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    return m
+
+
+def _data():
+    g = torch.Generator().manual_seed(0)
+    N, S = 4, 12
+    return (torch.randint(0, 40, (N, S), generator=g), torch.randint(0, 24, (N, 5), generator=g),
+            torch.randint(0, 33, (N, S), generator=g),
+            torch.randint(0, 50, (N, 1), generator=g) + torch.arange(S)[None])
+
+
+def _worker(rank, world, port, overlap, q):
+    from conftest import PKG, ROOT
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from qarig import optim as qoptim
+    from qarig import parallel, pipeline
+    parallel.init(backend="gloo")
+    torch.cuda.set_device(0)
+    m = _build().cuda()
+    qoptim.BUCKET_ELEMS = 20_000                 # several buckets on this tiny model
+    opt = qoptim.FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    parallel.broadcast_params(opt.flat_param)
+    if overlap:
+        opt.enable_allreduce_overlap()
+        assert len(opt._bucket_range) > 2
+    x, e, t, pos = (parallel.shard(v).cuda() for v in _data())
+    for _ in range(2):
+        loss = pipeline.train_step(m, opt, x, e, t, pos)
+    if rank == 0:
+        q.put((opt.flat_param.detach().cpu(), float(loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_dp2_step_equals_single_process(overlap):
+    from qarig import pipeline
+    from qarig.optim import FlatAdam
+    m = _build().cuda()
+    opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    x, e, t, pos = (v.cuda() for v in _data())
+    for _ in range(2):
+        pipeline.train_step(m, opt, x, e, t, pos, dp=False)
+    want = opt.flat_param.detach().cpu()
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue
+    got = None
+    for _ in range(120):                      # poll: a crashed worker must not cost minutes
+        try:
+            got, _ = q.get(timeout=1)
+            break
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()
+    assert got is not None and all(p.exitcode == 0 for p in procs)
+    # two Adam steps: the second one sees weights that already differ by summation-order noise
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
