@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_mma_kernel(PatchGeom g,
                                                               const float* __restrict__ w, int K,
                                                               const float* __restrict__ w2,
                                                               const float* __restrict__ x2,
-                                                              int tiles_per_split,
+                                                              int fused_norms, int tiles_per_split,
                                                               float* __restrict__ part_s,
                                                               int* __restrict__ part_i,
                                                               int64_t* __restrict__ out) {
@@ -122,10 +122,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_mma_kernel(PatchGeom g,
     float best_s[2] = {INFINITY, INFINITY};
     int best_i[2] = {INT_MAX, INT_MAX};
     float x2v[2];
+    __shared__ float norms[128];   // |x|^2 of the block's rows, then |w|^2 of each code tile
+    if (fused_norms) {
+        // small D: the norm chains (same sequential fma order as the stand-alone kernels)
+        // are computed here, saving two launches and their boundaries
+        if (tid < 128) {
+            float acc = 0.0f;
+            if (sb.valid)
+                for (int c = 0; c < g.C; ++c)
+                    for (int i = 0; i < g.pH; ++i) {
+                        const float* p = g.x + sb.rowbase + ((int64_t)c * g.H + i) * g.W;
+                        for (int j = 0; j < g.pW; ++j) acc = fmaf(p[j], p[j], acc);
+                    }
+            norms[tid] = acc;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int prow = p0 + wn * 64 + j * 32 + cl;
-        x2v[j] = prow < g.R ? x2[prow] : 0.0f;
+        x2v[j] = fused_norms ? norms[wn * 64 + j * 32 + cl] : (prow < g.R ? x2[prow] : 0.0f);
     }
 
     const int code_tiles = (K + BM - 1) / BM;
@@ -133,13 +149,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_mma_kernel(PatchGeom g,
     const int ct1 = min(code_tiles, ct0 + tiles_per_split);
     for (int ct = ct0; ct < ct1; ++ct) {
         const int c0 = ct * BM;
+        if (fused_norms) {
+            __syncthreads();           // previous users of norms[] are done
+            if (tid < 128) {
+                float a2 = 0.0f;
+                if (c0 + tid < K) {
+                    const float* p = w + (int64_t)(c0 + tid) * g.D;
+                    for (int e = 0; e < g.D; ++e) a2 = fmaf(p[e], p[e], a2);
+                }
+                norms[tid] = a2;
+            }
+            __syncthreads();
+        }
         Acc acc;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int code = c0 + wm * 64 + i * 32 + acc_row(r, lane);
-                const float v = code < K ? w2[code] : 0.0f;
+                const int lc = wm * 64 + i * 32 + acc_row(r, lane);
+                const float v = fused_norms ? norms[lc] : (c0 + lc < K ? w2[c0 + lc] : 0.0f);
                 acc.t[i][0][r] = v;
                 acc.t[i][1][r] = v;
             }
@@ -273,10 +301,14 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
     float* part_s = x2 + g.R;
     int* part_i = (int*)(part_s + (size_t)bmu_code_tiles(K) * g.R);
 
-    hipLaunchKernelGGL(bmu_code_norm_kernel, dim3((K + 63) / 64), dim3(64), 0, st, codebook, K, D, w2);
-    QARIG_CHECK_LAUNCH("bmu code norm");
-    hipLaunchKernelGGL(bmu_patch_norm_kernel, dim3((g.R + 63) / 64), dim3(64), 0, st, g, x2);
-    QARIG_CHECK_LAUNCH("bmu patch norm");
+    const int fused_norms = D <= 256;
+    if (!fused_norms) {
+        hipLaunchKernelGGL(bmu_code_norm_kernel, dim3((K + 63) / 64), dim3(64), 0, st, codebook, K, D,
+                           w2);
+        QARIG_CHECK_LAUNCH("bmu code norm");
+        hipLaunchKernelGGL(bmu_patch_norm_kernel, dim3((g.R + 63) / 64), dim3(64), 0, st, g, x2);
+        QARIG_CHECK_LAUNCH("bmu patch norm");
+    }
 
     const int ptiles = (g.R + BN - 1) / BN;
     const int ctiles = bmu_code_tiles(K);
@@ -286,7 +318,8 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
     const int per = (ctiles + nsplit - 1) / nsplit;
     nsplit = (ctiles + per - 1) / per;
     hipLaunchKernelGGL(bmu_mma_kernel, dim3(ptiles, nsplit), dim3(NTHREADS), 0, st, g, codebook, K,
-                       w2, x2, per, part_s, part_i, nsplit == 1 ? out_idx : (int64_t*)nullptr);
+                       w2, x2, fused_norms, per, part_s, part_i,
+                       nsplit == 1 ? out_idx : (int64_t*)nullptr);
     QARIG_CHECK_LAUNCH("bmu mma");
     if (nsplit > 1) {
         hipLaunchKernelGGL(bmu_finalize_kernel, dim3((g.R + 255) / 256), dim3(256), 0, st, part_s,
