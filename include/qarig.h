@@ -60,7 +60,9 @@ int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH, int pW,
  * gradz given); store to C.  splitk > 1 (plain epilogue only) splits the reduction
  * over grid.z through fp32 slabs in `workspace`, summed in fixed order.  accumulate != 0
  * (plain epilogue only) adds the product to what C already holds (weight gradients are
- * accumulated straight into the flat .grad buffer).
+ * accumulated straight into the flat .grad buffer).  a_rowsum (optional, [M]) receives
+ * sum_k A(m,k) (added to it when accumulate): with A = dT^T this is the bias gradient,
+ * computed from the A tiles the weight-gradient GEMM stages anyway.
  * Replaces nn.Linear (+activation) inside LinearLayer / ResidualLinearLayer
  * (models/layers.py:234-304) forward, and the three autograd contractions. */
 size_t qarig_gemm_workspace_bytes(int M, int N, int splitk);
@@ -68,7 +70,7 @@ int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const float* B, i
                    int b_kcontig, float* C, int64_t ldc, int M, int N, int K, const float* bias,
                    const float* residual, int64_t ldr, float* preact, int64_t ldp, int act,
                    const float* gradz, int64_t ldz, int gact, int splitk, int accumulate,
-                   void* workspace, size_t ws_bytes, void* stream);
+                   float* a_rowsum, void* workspace, size_t ws_bytes, void* stream);
 
 /* out[N] = column sums of X[M][N] in a fixed order (bias / LayerNorm-affine grads). */
 size_t qarig_colsum_workspace_bytes(int M, int N);

@@ -11,7 +11,8 @@
  *     torch.argmin(dim=-1)     models/Codebook.py:91-94 (first minimal index, int64)
  * torch's sgemm summation order is not part of any contract and cannot be restated;
  * this oracle fixes a sequential fp32 fma order (the one the HIP kernel's
- * v_mfma_f32_32x32x2_f32 chain produces) and is pinned to the reference by
+ * v_mfma_f32_32x32x2_f32 chain produces):  d2 = (chain(-2 w.x) + |w|^2) + |x|^2,
+ * each norm its own ascending fma chain; it is pinned to the reference by
  * tests/golden/bmu_*.npz (indices produced by the reference's own Codebook class in
  * the build container, oracle/make_goldens.py).
  *
@@ -76,9 +77,9 @@ int oracle_bmu(const float* x, int N, int C, int H, int W, int pH, int pW, const
             const float* wk = w + (int64_t)k * D;
             float d;
             if (mm_form) {
-                float acc = w2[k];
+                float acc = 0.0f;
                 for (int e = 0; e < D; ++e) acc = fmaf(-2.0f * wk[e], buf[e], acc);
-                float d2 = acc + x2;
+                float d2 = (acc + w2[k]) + x2;
                 d = sqrtf(d2 > 0.0f ? d2 : 0.0f);
             } else {
                 float acc = 0.0f;

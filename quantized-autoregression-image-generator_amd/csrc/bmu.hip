@@ -10,10 +10,17 @@
 // Arithmetic definition (what oracle/bmu_oracle.c restates; all fp32):
 //   w2[k] = fma-chain_e  w[k][e]^2            (e ascending, from 0)
 //   x2[r] = fma-chain_e  x[r][e]^2
-//   acc   = w2[k]; for e ascending: acc = fmaf(-2*w[k][e], x[r][e], acc)
-//   d     = sqrtf(max(acc + x2[r], 0));  index = first k with minimal d.
-// The sqrt is only evaluated when a candidate beats the running squared
-// distance; since sqrtf is monotone that gives the same first-minimum of d.
+//   acc   = 0; for e ascending: acc = fmaf(-2*w[k][e], x[r][e], acc)     (the MFMA chain)
+//   d     = sqrtf(max((acc + w2[k]) + x2[r], 0));  index = first k with minimal d.
+// Both norm chains are computed from the operand tiles while they sit in LDS for the
+// MFMAs (a hook of the contraction loop): the codebook and the latent are read once.
+// The scan itself is branch-free in the SQUARED distance: each lane keeps (min d2, its
+// first index, second-smallest d2).  sqrtf is monotone, so argmin over d equals argmin
+// over d2 unless another candidate's d2 rounds to the same sqrt as the minimum (sqrt
+// collapses ~2 neighbouring floats: ~1 row in 65k).  Exactly those rows -- sqrtf(second)
+// == sqrtf(min) -- are re-scanned by the whole block with the literal definition above,
+// so the result is bit-identical to it on every input while the common path costs
+// 7 VALU ops per candidate and no divergent branch.
 #include <limits.h>
 
 #include "qarig_common.h"
@@ -74,40 +81,106 @@ struct SrcPatch {
     }
 };
 
-// |w_k|^2 per codeword, sequential fma chain.
-__global__ void bmu_code_norm_kernel(const float* __restrict__ w, int K, int D,
-                                     float* __restrict__ w2) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    const float* p = w + (int64_t)k * D;
-    float acc = 0.0f;
-    for (int e = 0; e < D; ++e) acc = fmaf(p[e], p[e], acc);
-    w2[k] = acc;
+// |w|^2 (threads 0..127: one code each) and |x|^2 (threads 128..255: one patch row each)
+// as sequential fma chains over the staged tiles: TA holds -2*w, TB holds x.
+struct NormHook {
+    float acc;
+    int tid;
+    __device__ __forceinline__ void operator()(const float* ta, const float* tb) {
+        if (tid < 128) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) {
+                const float wv = ta[kk * LDT + tid] * -0.5f;   // exact
+                acc = fmaf(wv, wv, acc);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) {
+                const float xv = tb[kk * LDT + tid - 128];
+                acc = fmaf(xv, xv, acc);
+            }
+        }
+    }
+};
+
+struct BmuState {
+    float d2;   // smallest squared distance
+    int idx;    // its first index
+    float sec;  // smallest squared distance among all OTHER candidates
+};
+
+__device__ __forceinline__ BmuState bmu_merge(BmuState a, BmuState b) {
+    if (b.d2 < a.d2 || (b.d2 == a.d2 && b.idx < a.idx)) {
+        const BmuState t = a; a = b; b = t;
+    }
+    a.sec = fminf(a.sec, b.d2);   // b.sec >= b.d2
+    return a;
 }
 
-// |x_r|^2 per patch row, sequential fma chain over the patch order.
-__global__ void bmu_patch_norm_kernel(PatchGeom g, float* __restrict__ x2) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= g.R) return;
-    const int64_t base = patch_row_base(g, row);
-    float acc = 0.0f;
-    for (int c = 0; c < g.C; ++c)
-        for (int i = 0; i < g.pH; ++i) {
-            const float* p = g.x + base + ((int64_t)c * g.H + i) * g.W;
-            for (int j = 0; j < g.pW; ++j) acc = fmaf(p[j], p[j], acc);
+// Another candidate shares the minimum's sqrt: the first-index rule over d must decide.
+__device__ __forceinline__ int bmu_needs_exact(const BmuState& s) {
+    return s.sec < INFINITY && sqrtf(s.sec) == sqrtf(s.d2);
+}
+
+// Literal re-scan of the flagged rows of a 128-row block, all 256 threads per row:
+// thread t takes codes t, t+256, ... (ascending), the block reduces (d, index) with the
+// first-index rule.  Same fp32 chains as the MFMA path and the oracle.
+__device__ __noinline__ void bmu_exact_rows(const PatchGeom& g, const float* __restrict__ w, int K, int p0,
+                               const int* flags, float* lds, int64_t* __restrict__ out) {
+    float* rs = lds;                                  // [256]
+    int* ri = reinterpret_cast<int*>(lds + 256);      // [256]
+    const int tid = threadIdx.x;
+    for (int r = 0; r < 128; ++r) {
+        if (!flags[r]) continue;                      // block-uniform (LDS broadcast)
+        const int row = p0 + r;
+        const int64_t base = patch_row_base(g, row);
+        float x2 = 0.0f;
+        for (int c = 0; c < g.C; ++c)
+            for (int i = 0; i < g.pH; ++i) {
+                const float* p = g.x + base + ((int64_t)c * g.H + i) * g.W;
+                for (int j = 0; j < g.pW; ++j) x2 = fmaf(p[j], p[j], x2);
+            }
+        float best = INFINITY;
+        int bidx = INT_MAX;
+        for (int k = tid; k < K; k += 256) {
+            const float* wk = w + (int64_t)k * g.D;
+            float w2 = 0.0f;
+            for (int e = 0; e < g.D; ++e) w2 = fmaf(wk[e], wk[e], w2);
+            float acc = 0.0f;
+            int e = 0;
+            for (int c = 0; c < g.C; ++c)
+                for (int i = 0; i < g.pH; ++i) {
+                    const float* p = g.x + base + ((int64_t)c * g.H + i) * g.W;
+                    for (int j = 0; j < g.pW; ++j, ++e) acc = fmaf(-2.0f * wk[e], p[j], acc);
+                }
+            const float d = sqrtf(fmaxf((acc + w2) + x2, 0.0f));
+            if (d < best) { best = d; bidx = k; }
         }
-    x2[row] = acc;
+        __syncthreads();
+        rs[tid] = best;
+        ri[tid] = bidx;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                const float s2 = rs[tid + o];
+                const int i2 = ri[tid + o];
+                if (s2 < rs[tid] || (s2 == rs[tid] && i2 < ri[tid])) { rs[tid] = s2; ri[tid] = i2; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) out[row] = ri[0] == INT_MAX ? 0 : (int64_t)ri[0];
+    }
 }
 
 __global__ __launch_bounds__(NTHREADS, 2) void bmu_mma_kernel(PatchGeom g,
                                                               const float* __restrict__ w, int K,
-                                                              const float* __restrict__ w2,
-                                                              const float* __restrict__ x2,
-                                                              int fused_norms, int tiles_per_split,
-                                                              float* __restrict__ part_s,
+                                                              int tiles_per_split,
+                                                              float* __restrict__ part_d,
                                                               int* __restrict__ part_i,
+                                                              float* __restrict__ part_s,
                                                               int64_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float lds[GEMM_LDS_FLOATS];
+    __shared__ float norms[256];   // [0,128): |w|^2 of the code tile, [128,256): |x|^2 of the rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, cl = lane & 31;
     const int p0 = blockIdx.x * BN;  // first patch row of this block
@@ -119,119 +192,109 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_mma_kernel(PatchGeom g,
     sb.init(p0, tid);
 
     float best_d2[2] = {INFINITY, INFINITY};
-    float best_s[2] = {INFINITY, INFINITY};
+    float sec_d2[2] = {INFINITY, INFINITY};
     int best_i[2] = {INT_MAX, INT_MAX};
-    float x2v[2];
-    __shared__ float norms[128];   // |x|^2 of the block's rows, then |w|^2 of each code tile
-    if (fused_norms) {
-        // small D: the norm chains (same sequential fma order as the stand-alone kernels)
-        // are computed here, saving two launches and their boundaries
-        if (tid < 128) {
-            float acc = 0.0f;
-            if (sb.valid)
-                for (int c = 0; c < g.C; ++c)
-                    for (int i = 0; i < g.pH; ++i) {
-                        const float* p = g.x + sb.rowbase + ((int64_t)c * g.H + i) * g.W;
-                        for (int j = 0; j < g.pW; ++j) acc = fmaf(p[j], p[j], acc);
-                    }
-            norms[tid] = acc;
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int prow = p0 + wn * 64 + j * 32 + cl;
-        x2v[j] = fused_norms ? norms[wn * 64 + j * 32 + cl] : (prow < g.R ? x2[prow] : 0.0f);
-    }
 
     const int code_tiles = (K + BM - 1) / BM;
     const int ct0 = blockIdx.y * tiles_per_split;
     const int ct1 = min(code_tiles, ct0 + tiles_per_split);
     for (int ct = ct0; ct < ct1; ++ct) {
         const int c0 = ct * BM;
-        if (fused_norms) {
-            __syncthreads();           // previous users of norms[] are done
-            if (tid < 128) {
-                float a2 = 0.0f;
-                if (c0 + tid < K) {
-                    const float* p = w + (int64_t)(c0 + tid) * g.D;
-                    for (int e = 0; e < g.D; ++e) a2 = fmaf(p[e], p[e], a2);
-                }
-                norms[tid] = a2;
-            }
-            __syncthreads();
-        }
         Acc acc;
+        acc_zero(acc);
+        NormHook hook{0.0f, tid};
+        contract_loop<false>(acc, sa, sb, c0, p0, 0, g.D, lds, hook);
+        norms[tid] = hook.acc;
+        __syncthreads();
+        float x2v[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) x2v[j] = norms[128 + wn * 64 + j * 32 + cl];
+        const bool full = c0 + BM <= K;   // block-uniform: no code of this tile is padding
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int lc = wm * 64 + i * 32 + acc_row(r, lane);
-                const float v = fused_norms ? norms[lc] : (c0 + lc < K ? w2[c0 + lc] : 0.0f);
-                acc.t[i][0][r] = v;
-                acc.t[i][1][r] = v;
-            }
-        contract(acc, sa, sb, c0, p0, 0, g.D, lds);
+                const int code = c0 + lc;
+                const float w2 = norms[lc];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int code = c0 + wm * 64 + i * 32 + acc_row(r, lane);
-                    const float d2 = fmaxf(acc.t[i][j][r] + x2v[j], 0.0f);
-                    if (code < K && d2 < best_d2[j]) {
-                        const float s = sqrtf(d2);
-                        if (s < best_s[j]) { best_s[j] = s; best_i[j] = code; }
-                        best_d2[j] = d2;
-                    }
+                for (int j = 0; j < 2; ++j) {
+                    float d2 = fmaxf((acc.t[i][j][r] + w2) + x2v[j], 0.0f);
+                    if (!full) d2 = code < K ? d2 : INFINITY;
+                    const bool lt = d2 < best_d2[j];
+                    sec_d2[j] = lt ? best_d2[j] : fminf(sec_d2[j], d2);
+                    best_i[j] = lt ? code : best_i[j];
+                    best_d2[j] = lt ? d2 : best_d2[j];
                 }
+            }
+        __syncthreads();   // norms[] is rewritten by the next code tile
     }
 
     // Combine the 4 holders of each patch column: lane halves (h) x waves (wm).
-    float* cs = lds;                                   // [4][128]
-    int* ci = reinterpret_cast<int*>(lds + 4 * 128);   // [4][128]
+    float* cd = lds;                                   // [4][128] min d2
+    int* ci = reinterpret_cast<int*>(lds + 4 * 128);   // [4][128] its first index
+    float* cs = lds + 8 * 128;                         // [4][128] second-smallest d2
     const int slot = wm * 2 + (lane >> 5);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = wn * 64 + j * 32 + cl;
-        cs[slot * 128 + col] = best_s[j];
+        cd[slot * 128 + col] = best_d2[j];
         ci[slot * 128 + col] = best_i[j];
+        cs[slot * 128 + col] = sec_d2[j];
     }
     __syncthreads();
+    int* flags = reinterpret_cast<int*>(lds + 12 * 128);   // [128] rows needing the exact scan
     if (tid < 128) {
         const int prow = p0 + tid;
+        int flag = 0;
         if (prow < g.R) {
-            float s = cs[tid];
-            int idx = ci[tid];
+            BmuState st{cd[tid], ci[tid], cs[tid]};
 #pragma unroll
-            for (int q = 1; q < 4; ++q) {
-                const float s2 = cs[q * 128 + tid];
-                const int i2 = ci[q * 128 + tid];
-                if (s2 < s || (s2 == s && i2 < idx)) { s = s2; idx = i2; }
-            }
+            for (int q = 1; q < 4; ++q) st = bmu_merge(st, BmuState{cd[q * 128 + tid], ci[q * 128 + tid],
+                                                                   cs[q * 128 + tid]});
             if (out) {
-                out[prow] = idx == INT_MAX ? 0 : (int64_t)idx;
+                flag = bmu_needs_exact(st);
+                out[prow] = st.idx == INT_MAX ? 0 : (int64_t)st.idx;
             } else {
-                part_s[(int64_t)blockIdx.y * g.R + prow] = s;
-                part_i[(int64_t)blockIdx.y * g.R + prow] = idx;
+                const int64_t o = (int64_t)blockIdx.y * g.R + prow;
+                part_d[o] = st.d2;
+                part_i[o] = st.idx;
+                part_s[o] = st.sec;
             }
         }
+        flags[tid] = flag;
     }
+    __syncthreads();
+    if (out) bmu_exact_rows(g, w, K, p0, flags, lds, out);
 }
 
-__global__ void bmu_finalize_kernel(const float* __restrict__ part_s, const int* __restrict__ part_i,
-                                    int R, int nsplit, int64_t* __restrict__ out) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= R) return;
-    float s = part_s[row];
-    int idx = part_i[row];
-    for (int z = 1; z < nsplit; ++z) {
-        const float s2 = part_s[(int64_t)z * R + row];
-        const int i2 = part_i[(int64_t)z * R + row];
-        if (s2 < s || (s2 == s && i2 < idx)) { s = s2; idx = i2; }
+// Merge of the per-split partial states (splits cover ascending code ranges), then the
+// exact re-scan of flagged rows.  One block per 128 rows.
+__global__ __launch_bounds__(256) void bmu_finalize_kernel(PatchGeom g, const float* __restrict__ w,
+                                                           int K, const float* __restrict__ part_d,
+                                                           const int* __restrict__ part_i,
+                                                           const float* __restrict__ part_s,
+                                                           int nsplit, int64_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float lds[512];
+    __shared__ int flags[128];
+    const int p0 = blockIdx.x * 128;
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+        const int row = p0 + tid;
+        int flag = 0;
+        if (row < g.R) {
+            BmuState st{part_d[row], part_i[row], part_s[row]};
+            for (int z = 1; z < nsplit; ++z) {
+                const int64_t o = (int64_t)z * g.R + row;
+                st = bmu_merge(st, BmuState{part_d[o], part_i[o], part_s[o]});
+            }
+            flag = bmu_needs_exact(st);
+            out[row] = st.idx == INT_MAX ? 0 : (int64_t)st.idx;
+        }
+        flags[tid] = flag;
     }
-    out[row] = idx == INT_MAX ? 0 : (int64_t)idx;
+    __syncthreads();
+    bmu_exact_rows(g, w, K, p0, flags, lds, out);
 }
 
 // torch.cdist's small-input branch (both operands <= 25 rows): direct
@@ -266,9 +329,8 @@ using namespace qarig;
 static int bmu_code_tiles(int K) { return (K + BM - 1) / BM; }
 
 extern "C" size_t qarig_bmu_workspace_bytes(int64_t rows, int K) {
-    // w2[K] + x2[R] + per-split (float, int) partials for up to code_tiles splits.
-    const size_t R = (size_t)rows;
-    return sizeof(float) * ((size_t)K + R) + (size_t)bmu_code_tiles(K) * R * 8 + 64;
+    // per-split (d2, idx, second) partials for up to code_tiles splits
+    return (size_t)bmu_code_tiles(K) * (size_t)rows * 12 + 64;
 }
 
 extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH, int pW,
@@ -296,19 +358,9 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
                         qarig_bmu_workspace_bytes(rows, K));
         return QARIG_ERR_WORKSPACE;
     }
-    float* w2 = (float*)workspace;
-    float* x2 = w2 + K;
-    float* part_s = x2 + g.R;
-    int* part_i = (int*)(part_s + (size_t)bmu_code_tiles(K) * g.R);
-
-    const int fused_norms = D <= 256;
-    if (!fused_norms) {
-        hipLaunchKernelGGL(bmu_code_norm_kernel, dim3((K + 63) / 64), dim3(64), 0, st, codebook, K, D,
-                           w2);
-        QARIG_CHECK_LAUNCH("bmu code norm");
-        hipLaunchKernelGGL(bmu_patch_norm_kernel, dim3((g.R + 63) / 64), dim3(64), 0, st, g, x2);
-        QARIG_CHECK_LAUNCH("bmu patch norm");
-    }
+    float* part_d = (float*)workspace;
+    int* part_i = (int*)(part_d + (size_t)bmu_code_tiles(K) * g.R);
+    float* part_s = (float*)(part_i + (size_t)bmu_code_tiles(K) * g.R);
 
     const int ptiles = (g.R + BN - 1) / BN;
     const int ctiles = bmu_code_tiles(K);
@@ -318,12 +370,11 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
     const int per = (ctiles + nsplit - 1) / nsplit;
     nsplit = (ctiles + per - 1) / per;
     hipLaunchKernelGGL(bmu_mma_kernel, dim3(ptiles, nsplit), dim3(NTHREADS), 0, st, g, codebook, K,
-                       w2, x2, fused_norms, per, part_s, part_i,
-                       nsplit == 1 ? out_idx : (int64_t*)nullptr);
+                       per, part_d, part_i, part_s, nsplit == 1 ? out_idx : (int64_t*)nullptr);
     QARIG_CHECK_LAUNCH("bmu mma");
     if (nsplit > 1) {
-        hipLaunchKernelGGL(bmu_finalize_kernel, dim3((g.R + 255) / 256), dim3(256), 0, st, part_s,
-                           part_i, g.R, nsplit, out_idx);
+        hipLaunchKernelGGL(bmu_finalize_kernel, dim3((g.R + 127) / 128), dim3(256), 0, st, g, codebook,
+                           K, part_d, part_i, part_s, nsplit, out_idx);
         QARIG_CHECK_LAUNCH("bmu finalize");
     }
     return QARIG_OK;

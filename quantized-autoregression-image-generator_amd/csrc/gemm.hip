@@ -20,6 +20,20 @@ struct GemmEpilogue {
     int act;                              // activation applied to what goes to C
     const float* gradz; int64_t ldz;      // C *= act'(gradz[m][n]) (backward fusion), or null
     int gact;
+    float* rowsum;                        // [splitk][M]: sum_k A(m,k) per K split, or null
+};
+
+// sum_k A(m0 + tid, k) from the staged A tiles (bias gradient riding on the dW GEMM).
+struct RowSumHook {
+    float rs;
+    bool on;
+    int tid;
+    __device__ __forceinline__ void operator()(const float* ta, const float*) {
+        if (on) {
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) rs += ta[kk * LDT + tid];
+        }
+    }
 };
 
 // FAST: every tile interior (M,N multiples of 128, every K split a multiple of 16,
@@ -43,7 +57,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpi
 
     Acc acc;
     acc_zero(acc);
-    contract_loop<FAST>(acc, sa, sb, m0, n0, k_begin, k_end, lds);
+    RowSumHook hook{0.0f, ep.rowsum != nullptr && tn == 0 && threadIdx.x < 128, (int)threadIdx.x};
+    contract_loop<FAST>(acc, sa, sb, m0, n0, k_begin, k_end, lds, hook);
+    if (hook.on && m0 + (int)threadIdx.x < M)
+        ep.rowsum[(int64_t)blockIdx.z * M + m0 + threadIdx.x] = hook.rs;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -163,15 +180,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 using namespace qarig;
 
 extern "C" size_t qarig_gemm_workspace_bytes(int M, int N, int splitk) {
-    return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0;
+    // split-K slabs + (always) room for the per-split A row sums
+    const size_t sk = splitk > 1 ? splitk : 1;
+    return (splitk > 1 ? sk * M * N * sizeof(float) : 0) + sk * M * sizeof(float);
 }
 
 extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const float* B,
                               int64_t ldb, int b_kcontig, float* C, int64_t ldc, int M, int N,
                               int K, const float* bias, const float* residual, int64_t ldr,
                               float* preact, int64_t ldp, int act, const float* gradz,
-                              int64_t ldz, int gact, int splitk, int accumulate, void* workspace,
-                              size_t ws_bytes, void* stream) {
+                              int64_t ldz, int gact, int splitk, int accumulate, float* a_rowsum,
+                              void* workspace, size_t ws_bytes, void* stream) {
     QARIG_CHECK_ARG(A && B && C, "gemm: null operand");
     QARIG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad extents M=%d N=%d K=%d", M, N, K);
     QARIG_CHECK_ARG(act >= 0 && act <= 3 && gact >= 0 && gact <= 3, "gemm: bad activation id");
@@ -182,8 +201,8 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
                         "gemm: accumulate supports the plain epilogue only");
         if (splitk == 1) { residual = C; ldr = ldc; }   // read-modify-write by the same lane
     }
-    if (splitk > 1) {
-        QARIG_CHECK_ARG(!bias && !residual && !preact && !gradz && act == ACT_NONE,
+    if (splitk > 1 || a_rowsum) {
+        QARIG_CHECK_ARG(splitk == 1 || (!bias && !residual && !preact && !gradz && act == ACT_NONE),
                         "gemm: split-K supports the plain epilogue only");
         if (ws_bytes < qarig_gemm_workspace_bytes(M, N, splitk) || !workspace) {
             qarig_set_error("gemm: workspace too small (%zu < %zu)", ws_bytes,
@@ -193,9 +212,11 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, splitk), block(NTHREADS);
-    GemmEpilogue ep{C, ldc, bias, residual, ldr, preact, ldp, act, gradz, ldz, gact};
     hipStream_t st = (hipStream_t)stream;
     float* slabs = (float*)workspace;
+    // per-split A row sums live behind the slabs
+    float* rs_part = a_rowsum ? slabs + (splitk > 1 ? (size_t)splitk * M * N : 0) : nullptr;
+    GemmEpilogue ep{C, ldc, bias, residual, ldr, preact, ldp, act, gradz, ldz, gact, rs_part};
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     const bool va = al16(A) && lda % 4 == 0, vb = al16(B) && ldb % 4 == 0;
     int per = K;
@@ -222,6 +243,11 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
     else QARIG_LAUNCH_GEMM(SrcXContig, SrcKContig);
 #undef QARIG_LAUNCH_GEMM
     QARIG_CHECK_LAUNCH("gemm");
+    if (a_rowsum) {   // a_rowsum[m] (+)= sum over splits, fixed order
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, rs_part,
+                           a_rowsum, (int64_t)M, 1, M, splitk, accumulate);
+        QARIG_CHECK_LAUNCH("gemm rowsum reduce");
+    }
     if (splitk > 1) {
         const int64_t total = (int64_t)M * N;
         int blocks = (int)((total + 255) / 256);

@@ -254,9 +254,18 @@ __device__ __forceinline__ void mma_tile_tail(Acc& acc, const float* TA, const f
 // FAST (block-uniform): both panels are interior and vector-loadable, so the loop is
 // branch-free straight-line code -- the prefetch of tile t+1 is issued before the MFMA
 // slab of tile t and only waited for (vmcnt) at its LDS write, after the slab.
-template <bool FAST, class SA, class SB>
+//
+// hook(TA, TB) is called once per staged tile pair (tiles in ascending k order, zero-filled
+// past the extents), between barriers, by every thread: side reductions that need the
+// operands anyway ride along with the contraction -- the bias gradient (row sums of
+// A = dT^T) in the weight-gradient GEMM, the |w|^2 / |x|^2 chains in the BMU search.
+struct NoHook {
+    __device__ __forceinline__ void operator()(const float*, const float*) {}
+};
+
+template <bool FAST, class SA, class SB, class Hook>
 __device__ __forceinline__ void contract_loop(Acc& acc, const SA& sa, const SB& sb, int m0, int n0,
-                                              int k_begin, int k_end, float* lds) {
+                                              int k_begin, int k_end, float* lds, Hook& hook) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -291,6 +300,7 @@ __device__ __forceinline__ void contract_loop(Acc& acc, const SA& sa, const SB& 
             float* na = (kt & 1) ? TA0 : TA1;
             float* nb = (kt & 1) ? TB0 : TB1;
             mma_tile<BK / 4>(acc, ta, tb, wm, wn, lane);
+            hook(ta, tb);
             __builtin_amdgcn_sched_barrier(0);
             sa.store(ra, na, tid);       // tile kt+1 (or a harmless repeat of the last tile)
             sb.store(rb, nb, tid);
@@ -322,6 +332,7 @@ __device__ __forceinline__ void contract_loop(Acc& acc, const SA& sa, const SB& 
         const int rem = k_end - kb;
         if (rem >= BK) mma_tile<BK / 2>(acc, ta, tb, wm, wn, lane);
         else mma_tile_tail(acc, ta, tb, wm, wn, lane, (rem + 1) >> 1);
+        hook(ta, tb);
         if (more) {
             sa.store(ra, na, tid);
             sb.store(rb, nb, tid);
@@ -330,13 +341,11 @@ __device__ __forceinline__ void contract_loop(Acc& acc, const SA& sa, const SB& 
     }
 }
 
-template <class SA, class SB>
-__device__ __forceinline__ void contract(Acc& acc, const SA& sa, const SB& sb, int m0, int n0,
-                                         int k_begin, int k_end, float* lds) {
-    if (sa.interior(m0, k_begin, k_end) && sb.interior(n0, k_begin, k_end))
-        contract_loop<true>(acc, sa, sb, m0, n0, k_begin, k_end, lds);
-    else
-        contract_loop<false>(acc, sa, sb, m0, n0, k_begin, k_end, lds);
+template <bool FAST, class SA, class SB>
+__device__ __forceinline__ void contract_loop(Acc& acc, const SA& sa, const SB& sb, int m0, int n0,
+                                              int k_begin, int k_end, float* lds) {
+    NoHook none;
+    contract_loop<FAST>(acc, sa, sb, m0, n0, k_begin, k_end, lds, none);
 }
 
 // XCD-aware remap of a linear block id (T1 of the CDNA4 guide, bijective form):

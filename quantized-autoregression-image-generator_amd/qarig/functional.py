@@ -39,18 +39,26 @@ def _report_done(param):
         cb(param)
 
 
-def _wgrad(dT, X, param=None):
-    """dW[N,K] = dT^T X over the row dimension, split-K through fp32 slabs.  Returns the
-    gradient, or None after accumulating it into param.grad."""
+def _wgrad(dT, X, param=None, bias_param=None, want_bias=False):
+    """dW[N,K] = dT^T X over the row dimension (split-K through fp32 slabs) and, riding on
+    the same launch, db[N] = column sums of dT (the row sums of the A operand dT^T).
+    Returns (dW, db); an entry is None when it was accumulated into the parameter's .grad
+    (or not requested)."""
     M, N = dT.shape
     K = X.shape[1]
     sk = ops.pick_splitk(N, K, M)
-    slot = _grad_slot(param)
-    if slot is not None:
-        ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=sk, out=slot, accumulate=True)
+    wslot = _grad_slot(param)
+    bslot = _grad_slot(bias_param) if want_bias else None
+    if wslot is not None and (not want_bias or bslot is not None):
+        ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=sk, out=wslot, accumulate=True,
+                 a_rowsum=bslot)
         _report_done(param)
-        return None
-    return ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=sk)
+        if want_bias:
+            _report_done(bias_param)
+        return None, None
+    db = torch.zeros(N, dtype=torch.float32, device=dT.device) if want_bias else None
+    dw = ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=sk, a_rowsum=db)
+    return dw, db
 
 
 def _bgrad(dT, param=None):
@@ -92,9 +100,10 @@ class _LinearAct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dT, weight, a_kcontig=True, b_kcontig=False).reshape(
                 *dy.shape[:-1], weight.shape[1])
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = _wgrad(dT, x2, ctx.params[0])
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dw, db = _wgrad(dT, x2, ctx.params[0], ctx.params[1], want_b)
+        elif want_b:
             db = _bgrad(dT, ctx.params[1])
         if ctx.has_res and ctx.needs_input_grad[3]:
             dr = dT.reshape(dy.shape)
@@ -134,15 +143,15 @@ class _MLP2(torch.autograd.Function):
         dT1 = ops.gemm(dT2, w2, a_kcontig=True, b_kcontig=False, gradz=t1, gact=ctx.act1)
         dx = dw1 = db1 = dw2 = db2 = None
         if ctx.needs_input_grad[3]:
-            dw2 = _wgrad(dT2, h, ctx.params[2])
-        if ctx.needs_input_grad[4]:
+            dw2, db2 = _wgrad(dT2, h, ctx.params[2], ctx.params[3], ctx.needs_input_grad[4])
+        elif ctx.needs_input_grad[4]:
             db2 = _bgrad(dT2, ctx.params[3])
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dT1, w1, a_kcontig=True, b_kcontig=False).reshape(
                 *dy.shape[:-1], w1.shape[1])
         if ctx.needs_input_grad[1]:
-            dw1 = _wgrad(dT1, x2, ctx.params[0])
-        if ctx.needs_input_grad[2]:
+            dw1, db1 = _wgrad(dT1, x2, ctx.params[0], ctx.params[1], ctx.needs_input_grad[2])
+        elif ctx.needs_input_grad[2]:
             db1 = _bgrad(dT1, ctx.params[1])
         return dx, dw1, db1, dw2, db2, None, None
 

@@ -46,7 +46,7 @@ GEMM_EVENTS = None
 
 
 def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_preact=False,
-         act=0, gradz=None, gact=0, splitk=1, out=None, accumulate=False):
+         act=0, gradz=None, gact=0, splitk=1, out=None, accumulate=False, a_rowsum=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/qarig.h qarig_gemm_f32.
 
     A is (M,K) if a_kcontig else (K,M); B is (N,K) if b_kcontig else (K,N).
@@ -68,7 +68,9 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
     lib = _lib.load()
     ws = None
     nws = 0
-    if splitk > 1:
+    if a_rowsum is not None:
+        assert a_rowsum.shape == (M,) and a_rowsum.is_contiguous() and a_rowsum.dtype == torch.float32
+    if splitk > 1 or a_rowsum is not None:
         nws = lib.qarig_gemm_workspace_bytes(M, N, splitk)
         ws = workspace(nws, A.device, "gemm")
         nws = ws.numel()
@@ -81,7 +83,7 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
         ptr(residual), residual.stride(0) if residual is not None else 0,
         ptr(pre), pre.stride(0) if pre is not None else 0, act,
         ptr(gradz), gradz.stride(0) if gradz is not None else 0, gact,
-        splitk, int(accumulate), ptr(ws), nws, stream()), "qarig_gemm_f32")
+        splitk, int(accumulate), ptr(a_rowsum), ptr(ws), nws, stream()), "qarig_gemm_f32")
     if GEMM_EVENTS is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()

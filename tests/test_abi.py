@@ -28,7 +28,7 @@ def test_header_symbols_exported_and_bound():
     assert h.qarig_target_arch() == b"gfx950"
     # argument validation works without touching a GPU
     assert h.qarig_gemm_f32(None, 0, 1, None, 0, 1, None, 0, 1, 1, 1, None, None, 0, None, 0, 0, None,
-                            0, 0, 1, 0, None, 0, None) == -1
+                            0, 0, 1, 0, None, None, 0, None) == -1
     assert "null operand" in _lib.last_error()
 
 
