@@ -57,8 +57,9 @@ int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH, int pW,
 /* C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  a_kcontig: A stored [M][K] (1) or
  * [K][M] (0); same for B over N.  Epilogue, in order: + bias[n]; + residual[m][n];
  * store to preact (if given); act(); * act'(gradz[m][n]) with activation id gact (if
- * gradz given); store to C.  splitk > 1 (plain epilogue only) splits the reduction
- * over grid.z through fp32 slabs in `workspace`, summed in fixed order.  accumulate != 0
+ * gradz given); store to C.  splitk > 1 splits the reduction
+ * over grid.z through fp32 slabs in `workspace`, summed in fixed order (the epilogue then
+ * runs in the reduce pass; used for skinny-M decode GEMMs).  accumulate != 0
  * (plain epilogue only) adds the product to what C already holds (weight gradients are
  * accumulated straight into the flat .grad buffer).  a_rowsum (optional, [M]) receives
  * sum_k A(m,k) (added to it when accumulate): with A = dT^T this is the bias gradient,

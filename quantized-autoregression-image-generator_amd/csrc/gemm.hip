@@ -155,6 +155,26 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
     }
 }
 
+// Split-K reduce with the full GEMM epilogue: skinny-M GEMMs (autoregressive decode:
+// M = a few dozen rows) have too few output tiles to fill the chip, so their reduction
+// is split over grid.z and bias / residual / activation are applied here.
+__global__ void slab_reduce_epilogue_kernel(const float* __restrict__ slabs, GemmEpilogue ep, int M,
+                                            int N, int nslab) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float t = 0.0f;
+        for (int z = 0; z < nslab; ++z) t += slabs[(int64_t)z * total + i];
+        const int64_t row = i / N, col = i - row * N;
+        if (ep.bias) t += ep.bias[col];
+        if (ep.residual) t += ep.residual[row * ep.ldr + col];
+        if (ep.preact) ep.preact[row * ep.ldp + col] = t;
+        float y = act_fwd(t, ep.act);
+        if (ep.gradz) y *= act_grad(ep.gradz[row * ep.ldz + col], ep.gact);
+        ep.C[row * ep.ldc + col] = y;
+    }
+}
+
 // Column sums of X[M][N] (bias gradients; LayerNorm gamma/beta gradients).
 // Stage 1: one block per (64 columns x COLSUM_ROWS rows), fixed order inside.
 constexpr int COLSUM_ROWS = 512;
@@ -201,9 +221,8 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
                         "gemm: accumulate supports the plain epilogue only");
         if (splitk == 1) { residual = C; ldr = ldc; }   // read-modify-write by the same lane
     }
+    const bool plain = !bias && !residual && !preact && !gradz && act == ACT_NONE;
     if (splitk > 1 || a_rowsum) {
-        QARIG_CHECK_ARG(splitk == 1 || (!bias && !residual && !preact && !gradz && act == ACT_NONE),
-                        "gemm: split-K supports the plain epilogue only");
         if (ws_bytes < qarig_gemm_workspace_bytes(M, N, splitk) || !workspace) {
             qarig_set_error("gemm: workspace too small (%zu < %zu)", ws_bytes,
                             qarig_gemm_workspace_bytes(M, N, splitk));
@@ -252,8 +271,12 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
         const int64_t total = (int64_t)M * N;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, C, ldc, M, N,
-                           splitk, accumulate);
+        if (plain)
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, C, ldc, M, N,
+                               splitk, accumulate);
+        else
+            hipLaunchKernelGGL(slab_reduce_epilogue_kernel, dim3(blocks), dim3(256), 0, st, slabs, ep,
+                               M, N, splitk);
         QARIG_CHECK_LAUNCH("gemm slab reduce");
     }
     return QARIG_OK;

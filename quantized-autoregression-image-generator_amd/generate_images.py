@@ -26,6 +26,9 @@ def parse_args():
     p.add_argument("--config-path", required=True, type=pathlib.Path,
                    help="File path to load json config file.")
     p.add_argument("--out-dir", required=True, type=pathlib.Path, help="File path to output directory.")
+    p.add_argument("--batch-beams", action="store_true",
+                   help="(additive) evaluate the num_beam candidate chunks as one batch per model "
+                        "call; different RNG consumption order than the sequential reference loop.")
     return vars(p.parse_args())
 
 
@@ -87,7 +90,7 @@ def main():
                 model, hr_input, lr_input, total_Seq, data["temperature"], md["use_sliding_window"],
                 md["sliding_window"], end_token=k_hr, shift=shift, num_beam=data["num_beam"],
                 beam_width=data["beam_width"], mode="generate",
-                progress=lambda i, t: print(f"{i:,} / {t:,}"))
+                progress=lambda i, t: print(f"{i:,} / {t:,}"), batch_beams=args["batch_beams"])
             hr_input = hr_input[:, 1:] - shift
             recon = decoder_model(hr_codebook.get_quantized_image(indices=hr_input,
                                                                   unpatchify_input=True))

@@ -110,7 +110,16 @@ class _LinearAct(torch.autograd.Function):
         return dx, dw, db, dr, None
 
 
+def _no_grad():
+    return not torch.is_grad_enabled()
+
+
 def linear_act(x, weight, bias=None, residual=None, act=0):
+    if _no_grad():   # inference: straight to the kernel, no autograd node, no saved tensors
+        require_cuda(x, weight)
+        r2 = _2d(f32c(residual)) if residual is not None else None
+        y = ops.gemm(_2d(f32c(x)), weight, bias=bias, residual=r2, act=act)
+        return y.reshape(*x.shape[:-1], weight.shape[0])
     return _LinearAct.apply(x, weight, bias, residual, act)
 
 
@@ -157,6 +166,10 @@ class _MLP2(torch.autograd.Function):
 
 
 def mlp2(x, w1, b1, w2, b2, act1, act2=0):
+    if _no_grad():
+        require_cuda(x, w1, w2)
+        h = ops.gemm(_2d(f32c(x)), w1, bias=b1, act=act1)
+        return ops.gemm(h, w2, bias=b2, act=act2).reshape(*x.shape[:-1], w2.shape[0])
     return _MLP2.apply(x, w1, b1, w2, b2, act1, act2)
 
 
@@ -176,6 +189,9 @@ class _Mul(torch.autograd.Function):
 
 
 def mul(a, b):
+    if _no_grad():
+        require_cuda(a, b)
+        return ops.mul_fwd(f32c(a), f32c(b))
     return _Mul.apply(a, b)
 
 
@@ -199,6 +215,9 @@ class _LayerNormAffine(torch.autograd.Function):
 
 
 def layernorm_affine(x, gamma, beta, eps=1e-5):
+    if _no_grad():
+        require_cuda(x, gamma, beta)
+        return ops.layernorm_fwd(_2d(f32c(x)), gamma=gamma, beta=beta, eps=eps)[0].reshape(x.shape)
     return _LayerNormAffine.apply(x, gamma, beta, eps)
 
 
@@ -224,6 +243,10 @@ class _LayerNormMod(torch.autograd.Function):
 
 
 def layernorm_mod(x, scale, shift, eps=1e-5):
+    if _no_grad():
+        require_cuda(x, scale, shift)
+        return ops.layernorm_fwd(_2d(f32c(x)), scale=_2d(f32c(scale)), shift=_2d(f32c(shift)),
+                                 eps=eps)[0].reshape(x.shape)
     return _LayerNormMod.apply(x, scale, shift, eps)
 
 
@@ -248,6 +271,9 @@ class _Attention(torch.autograd.Function):
 
 
 def attention(q, k, v, heads, causal):
+    if _no_grad():
+        require_cuda(q, k, v)
+        return ops.attention_fwd(f32c(q), f32c(k), f32c(v), heads, causal)[0]
     return _Attention.apply(q, k, v, heads, causal)
 
 
@@ -268,6 +294,9 @@ class _EmbeddingPos(torch.autograd.Function):
 
 
 def embedding_pos(ids, table, pe=None):
+    if _no_grad():
+        require_cuda(ids, table)
+        return ops.embedding_fwd(ids, table, pe)
     return _EmbeddingPos.apply(ids, table, pe)
 
 

@@ -46,7 +46,7 @@ GEMM_EVENTS = None
 
 
 def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_preact=False,
-         act=0, gradz=None, gact=0, splitk=1, out=None, accumulate=False, a_rowsum=None):
+         act=0, gradz=None, gact=0, splitk=None, out=None, accumulate=False, a_rowsum=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/qarig.h qarig_gemm_f32.
 
     A is (M,K) if a_kcontig else (K,M); B is (N,K) if b_kcontig else (K,N).
@@ -65,6 +65,8 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
     for t in (residual, gradz):
         if t is not None:
             assert t.shape == (M, N) and t.stride(1) == 1
+    if splitk is None:
+        splitk = auto_splitk(M, N, K)
     lib = _lib.load()
     ws = None
     nws = 0
@@ -105,6 +107,15 @@ def colsum(X, out=None, accumulate=False):
     check(lib.qarig_colsum_f32(ptr(X), X.stride(0), M, N, ptr(out), int(accumulate), ptr(ws),
                                ws.numel(), stream()), "qarig_colsum_f32")
     return out
+
+
+def auto_splitk(M, N, K):
+    """Skinny GEMMs (few output tiles, e.g. the M = batch*beams rows of autoregressive
+    decode) spread their reduction over the chip; the epilogue then runs in the reduce."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 64 or K < 256 or K % 64:
+        return 1
+    return max(1, min(256 // tiles, K // 64))
 
 
 def pick_splitk(M, N, K):

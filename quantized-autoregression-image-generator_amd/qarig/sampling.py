@@ -18,7 +18,7 @@ import torch
 @torch.no_grad()
 def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_sliding_window,
                     sliding_window, end_token, shift=0, num_beam=1, beam_width=1, mode="generate",
-                    progress=None):
+                    progress=None, batch_beams=False):
     """hr_input: (N, S0) int64 conditioning/start tokens.  Returns the extended (N, S) tensor
     (first tokens included; callers strip them and undo `shift`)."""
     assert mode in ("generate", "train")
@@ -30,6 +30,10 @@ def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_slidi
     rows = torch.arange(N, device=device)
     stop_len = total_seq if mode == "generate" else hr_input.shape[1] + total_seq
     pos_off = 1 if mode == "generate" else 0
+    if batch_beams and num_beam > 1:
+        return _generate_batched(model, hr_input, enc, total_seq, temperature, use_sliding_window,
+                                 sliding_window, end_token, shift, num_beam, beam_width, mode,
+                                 progress, stop_len, pos_off)
     while hr_input.shape[1] < stop_len:
         cur = hr_input.shape[1]
         best_in = best_p = None
@@ -62,6 +66,53 @@ def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_slidi
         hr_input = best_in.long()
         if use_sliding_window:
             pos = t_pos
+        if progress is not None:
+            progress(hr_input.shape[1] - 1, total_seq)
+    return hr_input
+
+
+def _generate_batched(model, hr_input, enc, total_seq, temperature, use_sliding_window,
+                      sliding_window, end_token, shift, num_beam, beam_width, mode, progress,
+                      stop_len, pos_off):
+    """Same search, with the `num_beam` independent candidate chunks evaluated as ONE batch
+    of N*num_beam sequences per model call (the reference runs them one after the other).
+    Additive option: 1/num_beam of the model calls; the device generator is consumed in a
+    different order, so samples differ from the sequential loop for a given seed."""
+    device = hr_input.device
+    N, B = hr_input.shape[0], num_beam
+    enc_b = enc.repeat_interleave(B, dim=0) if enc is not None else None
+    pos = torch.zeros((N, 1), device=device) if use_sliding_window else None
+    start = 0
+    rows = torch.arange(N * B, device=device)
+    while hr_input.shape[1] < stop_len:
+        cur = hr_input.shape[1]
+        t_in = hr_input.repeat_interleave(B, dim=0)                 # (N*B, S): beams of image n adjacent
+        t_pos = pos.repeat_interleave(B, dim=0) if use_sliding_window else None
+        comb = torch.ones(N * B, device=device)
+        t_start = start
+        for tok in range(beam_width):
+            if use_sliding_window and t_in.shape[1] >= sliding_window:
+                t_start += 1
+                t_pos = t_pos[:, 1:]
+            logits = model.decode(t_in[:, t_start:].contiguous(), enc_b, t_pos)[:, -1, :]
+            probs = torch.softmax(logits / temperature, dim=1)
+            if mode == "generate":
+                probs[:, end_token] = 0.0
+            nxt = torch.multinomial(probs, 1)
+            comb = comb * probs[rows, nxt.squeeze(1)]
+            if mode == "train":
+                nxt[nxt == end_token] = 0
+            t_in = torch.cat((t_in, nxt + shift), dim=1)
+            if use_sliding_window:
+                t_pos = torch.cat((t_pos, torch.full((N * B, 1), float(cur + tok + pos_off),
+                                                     device=device)), dim=1)
+        # first beam with the maximal product wins (the sequential loop keeps the earlier one on ties)
+        best = comb.view(N, B).argmax(dim=1)
+        pick = torch.arange(N, device=device) * B + best
+        hr_input = t_in[pick].long()
+        start = t_start
+        if use_sliding_window:
+            pos = t_pos[pick]
         if progress is not None:
             progress(hr_input.shape[1] - 1, total_seq)
     return hr_input

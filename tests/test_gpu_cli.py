@@ -256,3 +256,21 @@ def test_generation_loop_logic_matches_reference_restatement(use_enc, use_sw, nu
                                    use_sw, sw, end_token=32, shift=shift, num_beam=num_beam,
                                    beam_width=bw, mode="generate")
     assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("use_enc,use_sw", [(False, True), (True, True), (True, False)])
+def test_batched_beams_match_sequential_search_when_deterministic(use_enc, use_sw):
+    """With argmax sampling every candidate chunk is identical, so the batched-beam
+    variant must reproduce the sequential loop's tokens exactly."""
+    from qarig import sampling
+    fake = _FakeModel(use_enc)
+    N, total, sw, T = 3, 24, 10, 1e-4
+    gen = torch.Generator().manual_seed(2)
+    lr_in = torch.randint(0, 24, (N, 5), generator=gen).cuda() if use_enc else None
+    shift = 0 if use_enc else 7
+    first = (torch.full((N, 1), 32) if use_enc else torch.randint(0, 7, (N, 1), generator=gen)).cuda()
+    a = sampling.generate_tokens(fake, first, lr_in, total, T, use_sw, sw, end_token=32, shift=shift,
+                                 num_beam=3, beam_width=4, mode="generate")
+    b = sampling.generate_tokens(fake, first, lr_in, total, T, use_sw, sw, end_token=32, shift=shift,
+                                 num_beam=3, beam_width=4, mode="generate", batch_beams=True)
+    assert torch.equal(a, b)

@@ -138,3 +138,23 @@ def test_cpu_tensor_is_refused():
     from qarig import ops
     with pytest.raises(RuntimeError):
         ops.bmu(torch.zeros(1, 4, 4, 4), torch.zeros(8, 16), (2, 2))
+
+
+def test_gemm_skinny_splitk_with_epilogue():
+    """Decode-shaped GEMMs (M = a few dozen rows): the reduction is split over the chip and
+    bias / residual / activation run in the reduce pass; same results as the one-pass path."""
+    from qarig import ops
+    from oracle import ref_models as rm
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 16, 512, 2048
+    A = torch.randn((M, K), generator=g).cuda()
+    W = (torch.randn((N, K), generator=g) * 0.05).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    R = torch.randn((M, N), generator=g).cuda()
+    assert ops.auto_splitk(M, N, K) > 1
+    y_auto, pre_auto = ops.gemm(A, W, bias=b, residual=R, want_preact=True, act=1)
+    y_one, pre_one = ops.gemm(A, W, bias=b, residual=R, want_preact=True, act=1, splitk=1)
+    t = A.double().cpu() @ W.double().cpu().t() + b.double().cpu() + R.double().cpu()
+    assert rel_err(pre_auto, t) < 2e-6 and rel_err(pre_one, t) < 2e-6
+    assert rel_err(y_auto, rm.activation(t, "silu")) < 4e-6
+    assert rel_err(y_auto, y_one) < 2e-6
