@@ -210,21 +210,32 @@ __device__ __forceinline__ void mma_tile(Acc& acc, const float* TA, const float*
     const int h = lane >> 5;
     const float* pa = TA + h * LDT + wm * 64 + x;
     const float* pb = TB + h * LDT + wn * 64 + x;
-    float a0[KS], a1[KS], b0[KS], b1[KS];
+    // fragment reads run one k-step ahead of the MFMAs that consume them
+    float a0 = pa[0], a1 = pa[32], b0 = pb[0], b1 = pb[32];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        a0[s] = pa[(2 * s) * LDT];
-        a1[s] = pa[(2 * s) * LDT + 32];
-        b0[s] = pb[(2 * s) * LDT];
-        b1[s] = pb[(2 * s) * LDT + 32];
+        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+        if (s + 1 < KS) {
+            na0 = pa[(2 * s + 2) * LDT];
+            na1 = pa[(2 * s + 2) * LDT + 32];
+            nb0 = pb[(2 * s + 2) * LDT];
+            nb1 = pb[(2 * s + 2) * LDT + 32];
+        }
+        acc.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc.t[0][0], 0, 0, 0);
+        acc.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc.t[0][1], 0, 0, 0);
+        acc.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc.t[1][0], 0, 0, 0);
+        acc.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc.t[1][1], 0, 0, 0);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
+    // pin that order (hipcc otherwise sinks each read pair back in front of its MFMAs):
+    // reads(0) | { reads(s+1), 4 MFMA(s) } x (KS-1) | 4 MFMA(KS-1)
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        acc.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc.t[0][0], 0, 0, 0);
-        acc.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc.t[0][1], 0, 0, 0);
-        acc.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc.t[1][0], 0, 0, 0);
-        acc.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc.t[1][1], 0, 0, 0);
+    for (int s = 0; s + 1 < KS; ++s) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
 }
 
 // Ragged tail (reduction extent not a multiple of BK): runtime step count.

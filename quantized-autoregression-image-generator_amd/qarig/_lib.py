@@ -10,7 +10,8 @@ from ctypes import c_int, c_int64, c_size_t, c_void_p, c_float, c_char_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libqarig_hip.so")
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib",
+                        os.environ.get("QARIG_LIB", "libqarig_hip.so"))   # QARIG_LIB: ablation builds
 
 P = c_void_p
 I = c_int
