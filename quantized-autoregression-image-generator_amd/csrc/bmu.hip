@@ -14,13 +14,14 @@
 //   d     = sqrtf(max((acc + w2[k]) + x2[r], 0));  index = first k with minimal d.
 // Both norm chains are computed from the operand tiles while they sit in LDS for the
 // MFMAs (a hook of the contraction loop): the codebook and the latent are read once.
-// The scan itself is branch-free in the SQUARED distance: each lane keeps (min d2, its
-// first index, second-smallest d2).  sqrtf is monotone, so argmin over d equals argmin
-// over d2 unless another candidate's d2 rounds to the same sqrt as the minimum (sqrt
-// collapses ~2 neighbouring floats: ~1 row in 65k).  Exactly those rows -- sqrtf(second)
-// == sqrtf(min) -- are re-scanned by the whole block with the literal definition above,
-// so the result is bit-identical to it on every input while the common path costs
-// 7 VALU ops per candidate and no divergent branch.
+// The scan itself is branch-free on t = acc + w2[k] (x2[r] is the same for every candidate
+// of a row): each lane keeps (min t, its first index, second-smallest t) at 5 VALU ops per
+// candidate (add, v_med3, cmp, cndmask, min).  d = f(t) = sqrtf(max(t + x2, 0)) is monotone
+// non-decreasing, so argmin-first over d equals argmin-first over t unless another candidate
+// maps to the same d as the minimum (the add's rounding, the clamp or sqrt collapsing
+// neighbouring floats: ~1 row in 65k).  Exactly those rows -- f(second) == f(min) -- are
+// re-scanned by the whole block with the literal definition above, so the result is
+// bit-identical to it on every input.
 #include <limits.h>
 
 #include "qarig_common.h"
@@ -104,10 +105,19 @@ struct NormHook {
 };
 
 struct BmuState {
-    float d2;   // smallest squared distance
+    float d2;   // smallest t = acc + |w|^2
     int idx;    // its first index
-    float sec;  // smallest squared distance among all OTHER candidates
+    float sec;  // smallest t among all OTHER candidates
 };
+
+__device__ __forceinline__ float bmu_dist(float t, float x2) { return sqrtf(fmaxf(t + x2, 0.0f)); }
+
+// One candidate of the branch-free scan.
+__device__ __forceinline__ void bmu_scan(float t, int code, float& best, int& idx, float& sec) {
+    sec = __builtin_amdgcn_fmed3f(best, t, sec);   // sec >= best always: the median is the new second
+    idx = t < best ? code : idx;
+    best = fminf(best, t);
+}
 
 __device__ __forceinline__ BmuState bmu_merge(BmuState a, BmuState b) {
     if (b.d2 < a.d2 || (b.d2 == a.d2 && b.idx < a.idx)) {
@@ -117,9 +127,9 @@ __device__ __forceinline__ BmuState bmu_merge(BmuState a, BmuState b) {
     return a;
 }
 
-// Another candidate shares the minimum's sqrt: the first-index rule over d must decide.
-__device__ __forceinline__ int bmu_needs_exact(const BmuState& s) {
-    return s.sec < INFINITY && sqrtf(s.sec) == sqrtf(s.d2);
+// Another candidate maps to the minimum's distance: the first-index rule over d must decide.
+__device__ __forceinline__ int bmu_needs_exact(const BmuState& s, float x2) {
+    return s.sec < INFINITY && bmu_dist(s.sec, x2) == bmu_dist(s.d2, x2);
 }
 
 // Literal re-scan of the flagged rows of a 128-row block, all 256 threads per row:
@@ -130,8 +140,11 @@ __device__ __noinline__ void bmu_exact_rows(const PatchGeom& g, const float* __r
     float* rs = lds;                                  // [256]
     int* ri = reinterpret_cast<int*>(lds + 256);      // [256]
     const int tid = threadIdx.x;
-    for (int r = 0; r < 128; ++r) {
-        if (!flags[r]) continue;                      // block-uniform (LDS broadcast)
+    // flags[128] holds the two 64-bit ballots of the block's rows (block-uniform reads)
+    const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(flags);
+    for (int half = 0; half < 2; ++half)
+    for (unsigned long long m = masks[half]; m; m &= m - 1) {
+        const int r = half * 64 + __ffsll((long long)m) - 1;
         const int row = p0 + r;
         const int64_t base = patch_row_base(g, row);
         float x2 = 0.0f;
@@ -172,12 +185,68 @@ __device__ __noinline__ void bmu_exact_rows(const PatchGeom& g, const float* __r
     }
 }
 
+// Block epilogue shared by the BMU kernels: combine the 4 holders of each patch column
+// (lane halves x waves along the code axis), write the index (or the per-split partial
+// state), then re-scan exactly the rows whose minimum shares its sqrt with another candidate.
+// `lds` needs 13*128 + 512 floats and must no longer be in use as operand tiles.
+__device__ __forceinline__ void bmu_block_finish(const PatchGeom& g, const float* __restrict__ w,
+                                                 int K, int p0, const float (&best_d2)[2],
+                                                 const int (&best_i)[2], const float (&sec_d2)[2],
+                                                 float* lds, const float* x2rows,
+                                                 float* __restrict__ part_d,
+                                                 int* __restrict__ part_i,
+                                                 float* __restrict__ part_s,
+                                                 float* __restrict__ part_x2,
+                                                 int64_t* __restrict__ out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, cl = lane & 31;
+    // Combine the 4 holders of each patch column: lane halves (h) x waves (wm).
+    float* cd = lds;                                   // [4][128] min d2
+    int* ci = reinterpret_cast<int*>(lds + 4 * 128);   // [4][128] its first index
+    float* cs = lds + 8 * 128;                         // [4][128] second-smallest d2
+    const int slot = wm * 2 + (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = wn * 64 + j * 32 + cl;
+        cd[slot * 128 + col] = best_d2[j];
+        ci[slot * 128 + col] = best_i[j];
+        cs[slot * 128 + col] = sec_d2[j];
+    }
+    __syncthreads();
+    int* flags = reinterpret_cast<int*>(lds + 12 * 128);   // [128] rows needing the exact scan
+    if (tid < 128) {
+        const int prow = p0 + tid;
+        int flag = 0;
+        if (prow < g.R) {
+            BmuState st{cd[tid], ci[tid], cs[tid]};
+#pragma unroll
+            for (int q = 1; q < 4; ++q) st = bmu_merge(st, BmuState{cd[q * 128 + tid], ci[q * 128 + tid],
+                                                                   cs[q * 128 + tid]});
+            if (out) {
+                flag = bmu_needs_exact(st, x2rows[tid]);
+                out[prow] = st.idx == INT_MAX ? 0 : (int64_t)st.idx;
+            } else {
+                const int64_t o = (int64_t)blockIdx.y * g.R + prow;
+                part_d[o] = st.d2;
+                part_i[o] = st.idx;
+                part_s[o] = st.sec;
+                if (blockIdx.y == 0) part_x2[prow] = x2rows[tid];
+            }
+        }
+        const unsigned long long m = __ballot(flag);
+        if (lane == 0) reinterpret_cast<unsigned long long*>(flags)[wave] = m;
+    }
+    __syncthreads();
+    if (out) bmu_exact_rows(g, w, K, p0, flags, lds, out);
+}
+
 __global__ __launch_bounds__(NTHREADS, 2) void bmu_mma_kernel(PatchGeom g,
                                                               const float* __restrict__ w, int K,
                                                               int tiles_per_split,
                                                               float* __restrict__ part_d,
                                                               int* __restrict__ part_i,
                                                               float* __restrict__ part_s,
+                                                              float* __restrict__ part_x2,
                                                               int64_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float lds[GEMM_LDS_FLOATS];
     __shared__ float norms[256];   // [0,128): |w|^2 of the code tile, [128,256): |x|^2 of the rows
@@ -206,66 +275,135 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_mma_kernel(PatchGeom g,
         contract_loop<false>(acc, sa, sb, c0, p0, 0, g.D, lds, hook);
         norms[tid] = hook.acc;
         __syncthreads();
-        float x2v[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) x2v[j] = norms[128 + wn * 64 + j * 32 + cl];
-        const bool full = c0 + BM <= K;   // block-uniform: no code of this tile is padding
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int lc = wm * 64 + i * 32 + acc_row(r, lane);
                 const int code = c0 + lc;
-                const float w2 = norms[lc];
+                const float w2 = code < K ? norms[lc] : INFINITY;   // padding codes never win
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float d2 = fmaxf((acc.t[i][j][r] + w2) + x2v[j], 0.0f);
-                    if (!full) d2 = code < K ? d2 : INFINITY;
-                    const bool lt = d2 < best_d2[j];
-                    sec_d2[j] = lt ? best_d2[j] : fminf(sec_d2[j], d2);
-                    best_i[j] = lt ? code : best_i[j];
-                    best_d2[j] = lt ? d2 : best_d2[j];
-                }
+                for (int j = 0; j < 2; ++j)
+                    bmu_scan(acc.t[i][j][r] + w2, code, best_d2[j], best_i[j], sec_d2[j]);
             }
-        __syncthreads();   // norms[] is rewritten by the next code tile
+        __syncthreads();   // norms[0..127] is rewritten by the next code tile
     }
 
-    // Combine the 4 holders of each patch column: lane halves (h) x waves (wm).
-    float* cd = lds;                                   // [4][128] min d2
-    int* ci = reinterpret_cast<int*>(lds + 4 * 128);   // [4][128] its first index
-    float* cs = lds + 8 * 128;                         // [4][128] second-smallest d2
-    const int slot = wm * 2 + (lane >> 5);
+    bmu_block_finish(g, w, K, p0, best_d2, best_i, sec_d2, lds, norms + 128, part_d, part_i, part_s,
+                     part_x2, out);
+}
+
+// Small patch widths (D <= 16*NKT <= 64: every hierarchical patch size of the reference's
+// cascade except "whole latent").  The block's 128 patch rows are gathered into LDS ONCE
+// (with their |x|^2 chains); code tiles stream through a double-buffered LDS slot whose
+// next global loads are in flight under the current tile's MFMAs; the branch-free
+// (min, first index, second) scan follows each tile.  Nothing is re-read from HBM.
+template <int NKT, int KS>
+__global__ __launch_bounds__(NTHREADS, 2) void bmu_small_kernel(PatchGeom g,
+                                                                const float* __restrict__ w, int K,
+                                                                int tiles_per_split,
+                                                                float* __restrict__ part_d,
+                                                                int* __restrict__ part_i,
+                                                                float* __restrict__ part_s,
+                                                                float* __restrict__ part_x2,
+                                                                int64_t* __restrict__ out) {
+    // KS = 2-deep MFMA steps that carry data in the last k-tile (D <= 4 -> 2 ... D > 8 -> 8)
+    // TB[NKT] | TA[2][NKT]; the combine / exact-rescan scratch reuses TA after the loop
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float norms[256];
+    float* TB = lds;
+    float* TA = lds + NKT * TILE_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, cl = lane & 31;
+    const int p0 = blockIdx.x * BN;
+
+    SrcKContig sa{w, (int64_t)g.D, K, g.D, -2.0f,
+                  (((uintptr_t)w & 15) == 0) && (g.D % 4 == 0)};
+    SrcPatch sb;
+    sb.g = g;
+    sb.init(p0, tid);
+
+    const int code_tiles = (K + BM - 1) / BM;
+    const int ct0 = blockIdx.y * tiles_per_split;
+    const int ct1 = min(code_tiles, ct0 + tiles_per_split);
+
+    float ra[NKT][STAGE];
+    // patches: staged once
+    {
+        float rb[STAGE];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = wn * 64 + j * 32 + cl;
-        cd[slot * 128 + col] = best_d2[j];
-        ci[slot * 128 + col] = best_i[j];
-        cs[slot * 128 + col] = sec_d2[j];
-    }
-    __syncthreads();
-    int* flags = reinterpret_cast<int*>(lds + 12 * 128);   // [128] rows needing the exact scan
-    if (tid < 128) {
-        const int prow = p0 + tid;
-        int flag = 0;
-        if (prow < g.R) {
-            BmuState st{cd[tid], ci[tid], cs[tid]};
-#pragma unroll
-            for (int q = 1; q < 4; ++q) st = bmu_merge(st, BmuState{cd[q * 128 + tid], ci[q * 128 + tid],
-                                                                   cs[q * 128 + tid]});
-            if (out) {
-                flag = bmu_needs_exact(st);
-                out[prow] = st.idx == INT_MAX ? 0 : (int64_t)st.idx;
-            } else {
-                const int64_t o = (int64_t)blockIdx.y * g.R + prow;
-                part_d[o] = st.d2;
-                part_i[o] = st.idx;
-                part_s[o] = st.sec;
-            }
+        for (int kt = 0; kt < NKT; ++kt) {
+            sb.load(rb, p0, kt * BK, tid);
+            sb.store(rb, TB + kt * TILE_FLOATS, tid);
         }
-        flags[tid] = flag;
     }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) sa.load(ra[kt], ct0 * BM, kt * BK, tid);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) sa.store(ra[kt], TA + kt * TILE_FLOATS, tid);
     __syncthreads();
-    if (out) bmu_exact_rows(g, w, K, p0, flags, lds, out);
+    if (tid >= 128) {   // |x|^2 chains, e ascending
+        float acc = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) {
+                const float xv = TB[kt * TILE_FLOATS + kk * LDT + tid - 128];
+                acc = fmaf(xv, xv, acc);
+            }
+        norms[tid] = acc;
+    }
+
+    float best_d2[2] = {INFINITY, INFINITY};
+    float sec_d2[2] = {INFINITY, INFINITY};
+    int best_i[2] = {INT_MAX, INT_MAX};
+
+    for (int ct = ct0; ct < ct1; ++ct) {
+        const int c0 = ct * BM;
+        float* ta = TA + ((ct - ct0) & 1) * NKT * TILE_FLOATS;
+        float* na = TA + (((ct - ct0) & 1) ^ 1) * NKT * TILE_FLOATS;
+        const bool more = ct + 1 < ct1;
+        if (more) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) sa.load(ra[kt], c0 + BM, kt * BK, tid);
+        }
+        if (tid < 128) {   // |w|^2 chain of this code tile (TA holds -2w)
+            float acc = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int kk = 0; kk < BK; ++kk) {
+                    const float wv = ta[kt * TILE_FLOATS + kk * LDT + tid] * -0.5f;
+                    acc = fmaf(wv, wv, acc);
+                }
+            norms[tid] = acc;
+        }
+        Acc acc;
+        acc_zero(acc);
+#pragma unroll
+        for (int kt = 0; kt < NKT - 1; ++kt)
+            mma_tile<BK / 2>(acc, ta + kt * TILE_FLOATS, TB + kt * TILE_FLOATS, wm, wn, lane);
+        mma_tile<KS>(acc, ta + (NKT - 1) * TILE_FLOATS, TB + (NKT - 1) * TILE_FLOATS, wm, wn, lane);
+        if (more) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) sa.store(ra[kt], na + kt * TILE_FLOATS, tid);
+        }
+        __syncthreads();   // norms[] visible; next code tile staged
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lc = wm * 64 + i * 32 + acc_row(r, lane);
+                const int code = c0 + lc;
+                const float w2 = code < K ? norms[lc] : INFINITY;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bmu_scan(acc.t[i][j][r] + w2, code, best_d2[j], best_i[j], sec_d2[j]);
+            }
+        __syncthreads();   // norms[0..127] is rewritten by the next tile
+    }
+    bmu_block_finish(g, w, K, p0, best_d2, best_i, sec_d2, TA, norms + 128, part_d, part_i, part_s,
+                     part_x2, out);
 }
 
 // Merge of the per-split partial states (splits cover ascending code ranges), then the
@@ -274,6 +412,7 @@ __global__ __launch_bounds__(256) void bmu_finalize_kernel(PatchGeom g, const fl
                                                            int K, const float* __restrict__ part_d,
                                                            const int* __restrict__ part_i,
                                                            const float* __restrict__ part_s,
+                                                           const float* __restrict__ part_x2,
                                                            int nsplit, int64_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float lds[512];
     __shared__ int flags[128];
@@ -288,10 +427,11 @@ __global__ __launch_bounds__(256) void bmu_finalize_kernel(PatchGeom g, const fl
                 const int64_t o = (int64_t)z * g.R + row;
                 st = bmu_merge(st, BmuState{part_d[o], part_i[o], part_s[o]});
             }
-            flag = bmu_needs_exact(st);
+            flag = bmu_needs_exact(st, part_x2[row]);
             out[row] = st.idx == INT_MAX ? 0 : (int64_t)st.idx;
         }
-        flags[tid] = flag;
+        const unsigned long long m = __ballot(flag);
+        if ((tid & 63) == 0) reinterpret_cast<unsigned long long*>(flags)[tid >> 6] = m;
     }
     __syncthreads();
     bmu_exact_rows(g, w, K, p0, flags, lds, out);
@@ -329,8 +469,8 @@ using namespace qarig;
 static int bmu_code_tiles(int K) { return (K + BM - 1) / BM; }
 
 extern "C" size_t qarig_bmu_workspace_bytes(int64_t rows, int K) {
-    // per-split (d2, idx, second) partials for up to code_tiles splits
-    return (size_t)bmu_code_tiles(K) * (size_t)rows * 12 + 64;
+    // per-split (min, idx, second) partials for up to code_tiles splits + |x|^2 per row
+    return (size_t)bmu_code_tiles(K) * (size_t)rows * 12 + (size_t)rows * 4 + 64;
 }
 
 extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH, int pW,
@@ -361,6 +501,7 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
     float* part_d = (float*)workspace;
     int* part_i = (int*)(part_d + (size_t)bmu_code_tiles(K) * g.R);
     float* part_s = (float*)(part_i + (size_t)bmu_code_tiles(K) * g.R);
+    float* part_x2 = part_s + (size_t)bmu_code_tiles(K) * g.R;
 
     const int ptiles = (g.R + BN - 1) / BN;
     const int ctiles = bmu_code_tiles(K);
@@ -369,12 +510,36 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
     if (nsplit < 1) nsplit = 1;
     const int per = (ctiles + nsplit - 1) / nsplit;
     nsplit = (ctiles + per - 1) / per;
-    hipLaunchKernelGGL(bmu_mma_kernel, dim3(ptiles, nsplit), dim3(NTHREADS), 0, st, g, codebook, K,
-                       per, part_d, part_i, part_s, nsplit == 1 ? out_idx : (int64_t*)nullptr);
+    int64_t* direct = nsplit == 1 ? out_idx : (int64_t*)nullptr;
+    if (D <= 64) {
+        const int nkt = D <= 16 ? 1 : (D <= 32 ? 2 : 4);
+        const size_t shm = (size_t)3 * nkt * TILE_FLOATS * sizeof(float);
+        dim3 grid(ptiles, nsplit), block(NTHREADS);
+#define QARIG_BMU_SMALL(NKT_, KS_)                                                              \
+        hipLaunchKernelGGL((bmu_small_kernel<NKT_, KS_>), grid, block, shm, st, g, codebook, K, per, \
+                           part_d, part_i, part_s, part_x2, direct)
+        if (D <= 4) QARIG_BMU_SMALL(1, 2);
+        else if (D <= 8) QARIG_BMU_SMALL(1, 4);
+        else if (D <= 16) QARIG_BMU_SMALL(1, 8);
+        else if (D <= 32) QARIG_BMU_SMALL(2, 8);
+        else {
+            static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once
+            if (!attr_set) {
+                hipFuncSetAttribute((const void*)bmu_small_kernel<4, 8>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                attr_set = true;
+            }
+            QARIG_BMU_SMALL(4, 8);
+        }
+#undef QARIG_BMU_SMALL
+    } else {
+        hipLaunchKernelGGL(bmu_mma_kernel, dim3(ptiles, nsplit), dim3(NTHREADS), 0, st, g, codebook, K,
+                           per, part_d, part_i, part_s, part_x2, direct);
+    }
     QARIG_CHECK_LAUNCH("bmu mma");
     if (nsplit > 1) {
         hipLaunchKernelGGL(bmu_finalize_kernel, dim3((g.R + 127) / 128), dim3(256), 0, st, g, codebook,
-                           K, part_d, part_i, part_s, nsplit, out_idx);
+                           K, part_d, part_i, part_s, part_x2, nsplit, out_idx);
         QARIG_CHECK_LAUNCH("bmu finalize");
     }
     return QARIG_OK;
