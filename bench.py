@@ -37,7 +37,18 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 HBM_PEAK_GBPS = 8000.0
 
 CFG = dict(batch=64, latent=(4, 32, 32), k_lr=512, k_hr=512, lr_patch=32, hr_patch=2, window=256,
-           in_dim=512, hidden=2048, heads=64, dec_layers=7, lr=1e-4)
+           in_dim=512, hidden=2048, heads=64, dec_layers=7, enc_layers=0, lr=1e-4, base=True,
+           name="BASELINE configs[1]: BMU (K=512; LR patch 32, HR patch 2) + base decoder-only "
+                "Transformer train step, 32x32x4 latents (128x128 images), 257-token sequences, "
+                "window 256")
+# BASELINE configs[3] per-GPU shard (a parity / scaling test case, not the headline line):
+# encoder-decoder stage on 64x64x4 latents, LR patch 4 (256 encoder tokens), HR patch 2
+# (1024 tokens, window 256), global batch 64 = 8 per GPU.
+CFG_C4 = dict(batch=8, latent=(4, 64, 64), k_lr=512, k_hr=512, lr_patch=4, hr_patch=2, window=256,
+              in_dim=512, hidden=2048, heads=64, dec_layers=7, enc_layers=5, lr=1e-4, base=False,
+              name="BASELINE configs[3] shard: BMU + encoder-decoder Transformer train step, "
+                   "64x64x4 latents (256x256 images), 256 encoder tokens, 1025-token sequences, "
+                   "window 256, 8 latents per GPU")
 
 
 def build_models(device, cfg, seed=3):
@@ -53,10 +64,15 @@ def build_models(device, cfg, seed=3):
         lr_cb.codebook.weight.copy_(torch.tanh(torch.randn(lr_cb.codebook.weight.shape, generator=g)))
         hr_cb.codebook.weight.copy_(torch.tanh(torch.randn(hr_cb.codebook.weight.shape, generator=g)))
     torch.manual_seed(seed)
-    model = Transformer(use_encoder=False, use_pos_cond=True, num_enc_layers=None,
-                        num_dec_layers=cfg["dec_layers"], num_enc_embedding=None,
-                        num_dec_embedding=cfg["k_lr"] + cfg["k_hr"], self_attn_heads=cfg["heads"],
-                        cross_attn_heads=None, transformer_in_dim=cfg["in_dim"],
+    base = cfg["base"]
+    model = Transformer(use_encoder=not base, use_pos_cond=True,
+                        num_enc_layers=None if base else cfg["enc_layers"],
+                        num_dec_layers=cfg["dec_layers"],
+                        num_enc_embedding=None if base else cfg["k_lr"],
+                        num_dec_embedding=cfg["k_lr"] + cfg["k_hr"] if base else cfg["k_hr"] + 1,
+                        self_attn_heads=cfg["heads"],
+                        cross_attn_heads=None if base else cfg["heads"],
+                        transformer_in_dim=cfg["in_dim"],
                         transformer_out_dim=cfg["k_hr"] + 1, transformer_hidden_dim=cfg["hidden"],
                         hidden_activation="silu")
     return lr_cb.to(device), hr_cb.to(device), model.to(device)
@@ -147,6 +163,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+                    help="c2 (default, the headline workload) or the config-4 per-GPU shard")
     args = ap.parse_args()
 
     from qarig import ops, parallel, pipeline
@@ -157,7 +175,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    cfg = CFG
+    cfg = CFG if args.config == "c2" else CFG_C4
 
     lr_cb, hr_cb, model = build_models(device, cfg)
     optim = FlatAdam(model.parameters(), lr=cfg["lr"], betas=(0.5, 0.999))
@@ -177,7 +195,7 @@ def main():
 
     def step():
         rand = parallel.shard(torch.randint(0, nwin, (N * world,), generator=rng))
-        hr_in, lr_in, hr_tg = pipeline.tokenize(z, lr_cb, hr_cb, train_base_model=True)
+        hr_in, lr_in, hr_tg = pipeline.tokenize(z, lr_cb, hr_cb, train_base_model=cfg["base"])
         hr_in, hr_tg, pos = pipeline.slide(hr_in, hr_tg, cfg["window"], rand)
         return pipeline.train_step(model, optim, hr_in, lr_in, hr_tg, pos)
 
@@ -210,9 +228,7 @@ def main():
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
-           "config": {"workload": "BASELINE configs[1]: BMU (K=512; LR patch 32, HR patch 2) + "
-                                  "base decoder-only Transformer train step, 32x32x4 latents "
-                                  "(128x128 images), 257-token sequences, window 256",
+           "config": {"workload": cfg["name"],
                       "batch_per_gpu": N, "global_batch": N * world, "seq_len": cfg["window"],
                       "in_dim": cfg["in_dim"], "hidden_dim": cfg["hidden"], "heads": cfg["heads"],
                       "dec_layers": cfg["dec_layers"], "params": int(optim.total),
@@ -234,7 +250,7 @@ def main():
                                "avg_launch_gflop": round(fl / len(events) / 1e9, 3),
                                "gemm_share_of_step": round(ms / (dt * 1e3), 3)}
         out["bmu"] = bmu_side_measure(device)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config == "c2":
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -110,12 +110,15 @@ def colsum(X, out=None, accumulate=False):
 
 
 def auto_splitk(M, N, K):
-    """Skinny GEMMs (few output tiles, e.g. the M = batch*beams rows of autoregressive
-    decode) spread their reduction over the chip; the epilogue then runs in the reduce."""
+    """GEMMs with fewer output tiles than CUs (the M = batch*beams rows of autoregressive
+    decode, small per-GPU batches) spread their reduction over the chip; the epilogue then
+    runs in the reduce pass."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 64 or K < 256 or K % 64:
+    if tiles >= 192 or K < 256 or K % 64:
         return 1
-    return max(1, min(256 // tiles, K // 64))
+    if tiles < 64:
+        return max(1, min(256 // tiles, K // 64))
+    return max(1, min(512 // tiles, K // 128))
 
 
 def pick_splitk(M, N, K):
