@@ -103,6 +103,11 @@ int qarig_gather_rows(const int64_t* ids, int64_t R, int D, int K, const float* 
 int qarig_som_weights_fwd(const int64_t* bmu, int64_t R, int K, float two_var, float* g,
                           void* stream);
 
+/* counts (int64 [K]) += histogram of ids -- the per-unit BMU usage count of
+ * prune_codebook.py:129-142. */
+int qarig_index_histogram(const int64_t* ids, int64_t n, int K, int64_t* counts, int* bad_flag,
+                          void* stream);
+
 /* ---- Transformer pieces ------------------------------------------------------- */
 
 /* get_positional_embeddings -- models/layers.py:83-96.  pos fp32 (R,), freq (D/2,)

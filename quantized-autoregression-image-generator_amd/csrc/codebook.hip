@@ -80,6 +80,18 @@ __global__ void som_weights_kernel(const int64_t* __restrict__ bmu, int64_t R, i
     }
 }
 
+// counts[id] += 1 over a stream of BMU indices (prune_codebook.py:129-142 keeps a Python
+// dict; here a device histogram).  Integer atomics: exact and order-independent.
+__global__ void histogram_kernel(const int64_t* __restrict__ ids, int64_t n, int K,
+                                 unsigned long long* __restrict__ counts, int* __restrict__ bad) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t id = ids[i];
+        if (id < 0 || id >= K) { atomicExch(bad, 1); continue; }
+        atomicAdd(counts + id, 1ULL);
+    }
+}
+
 }  // namespace qarig
 
 using namespace qarig;
@@ -151,5 +163,16 @@ extern "C" int qarig_som_weights_fwd(const int64_t* bmu, int64_t R, int K, float
     hipLaunchKernelGGL(som_weights_kernel, cb_grid(R * K), dim3(256), 0, (hipStream_t)stream, bmu, R,
                        K, two_var, g);
     QARIG_CHECK_LAUNCH("som_weights");
+    return QARIG_OK;
+}
+
+// counts (int64 [K], caller-initialised) += histogram of ids -- the BMU usage count of
+// prune_codebook.py:129-142.
+extern "C" int qarig_index_histogram(const int64_t* ids, int64_t n, int K, int64_t* counts,
+                                     int* bad_flag, void* stream) {
+    QARIG_CHECK_ARG(ids && counts && bad_flag && n > 0 && K > 0, "index_histogram: bad arguments");
+    hipLaunchKernelGGL(histogram_kernel, cb_grid(n), dim3(256), 0, (hipStream_t)stream, ids, n, K,
+                       (unsigned long long*)counts, bad_flag);
+    QARIG_CHECK_LAUNCH("index_histogram");
     return QARIG_OK;
 }

@@ -422,3 +422,14 @@ def mse_fwd(pred, target, want_grad=True):
     check(lib.qarig_mse_fwd(ptr(pred), ptr(target), pred.numel(), ptr(loss), ptr(dp), ptr(part),
                             stream()), "qarig_mse_fwd")
     return loss, dp
+
+
+def index_histogram(ids, counts):
+    """counts (int64 [K], on the device) += histogram of ids."""
+    require_cuda(ids, counts)
+    ids = _i64c(ids).reshape(-1)
+    assert counts.dtype == torch.int64 and counts.is_contiguous()
+    check(_lib.load().qarig_index_histogram(ptr(ids), ids.numel(), counts.numel(), ptr(counts),
+                                            ptr(_bad_flag(ids.device)), stream()),
+          "qarig_index_histogram")
+    return counts

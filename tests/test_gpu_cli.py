@@ -51,21 +51,24 @@ def test_cli_pipeline(tmp_path):
     assert ok and set(ae) == set(ae_cfg) - {"model_lr"} | {"model", "model_optimizer"}
     assert os.path.exists(f"{t}/ae/images/recon_2.jpg") and os.path.exists(f"{t}/ae/Autoencoder.log")
 
-    # latents with the trained encoder (generate_fmap_dataset.py's job: out of scope, done inline)
+    # latents with the trained encoder, through the re-hosted generate_fmap_dataset.py
+    out = run("generate_fmap_dataset.py", "--device", "cuda", "--batch-size", 5, "--num-files-folder",
+              8, "--dataset-path", f"{t}/dataset.json", "--model-path",
+              f"{t}/ae/models_checkpoint/model_2.pt", "--out-dir", f"{t}/fmaps", cwd=t)
+    assert "3 / 3" in out and os.path.exists(f"{t}/fmaps/1/8")     # folder roll-over at 8 files
+    from dataset_loader._tinydb_json import read_all
+    frecs = read_all(f"{t}/fmaps/all_dataset.json")
+    assert len(frecs) == 12 and frecs[0]["image_path"] == recs[0]["image_fpath"]
+    z0 = np.load(frecs[0]["fmap_path"])
+    assert z0.shape == (4, 8, 8) and z0.dtype == np.float32
     enc = FC_Encoder(num_layers=2, image_channel=3, min_channel=8, max_channel=16, latent_channel=4,
                      use_final_activation=True, final_activation_type="tanh")
     enc.custom_load_state_dict(ae["model"], ignore_msgs=True)
-    enc = enc.cuda()
-    frecs = []
     from dataset_loader.image_dataset import ImageDataset
-    ds = ImageDataset(f"{t}/dataset.json")
     with torch.no_grad():
-        for i in range(len(ds)):
-            z = enc(ds[i][None].cuda())[0].cpu().numpy()
-            assert z.shape == (4, 8, 8)
-            np.save(f"{t}/fmap{i}.npy", z)
-            frecs.append({"fmap_path": f"{t}/fmap{i}.npy", "image_path": recs[i]["image_fpath"]})
-    write_all(f"{t}/fmaps.json", frecs)
+        zz = enc.cuda()(ImageDataset(f"{t}/dataset.json")[0][None].cuda())[0].cpu().numpy()
+    assert np.array_equal(zz, z0)
+    os.replace(f"{t}/fmaps/all_dataset.json", f"{t}/fmaps.json")
 
     for name, p, k in (("lr", 8, 8), ("mid", 2, 16), ("hr", 1, 16)):
         json.dump(dict(model_lr=1e-2, neighbourhood_step=2, image_H=8, image_W=8, image_C=4, patch_H=p,
@@ -79,6 +82,17 @@ def test_cli_pipeline(tmp_path):
         assert ok and set(cb) == {"patch_dim", "image_dim", "image_C", "num_embeddings",
                                   "neighbourhood_range", "global_steps", "checkpoint"}
         assert cb["global_steps"] == 2 and list(cb["checkpoint"]) == ["codebook.weight"]
+
+    # prune: a device histogram of BMU indices; units below the threshold are dropped
+    out = run("prune_codebook.py", "--device", "cuda", "--dataset-path", f"{t}/fmaps.json",
+              "--codebook-path", f"{t}/cb_mid/models_checkpoint/codebook_2.pt", "--batch-size", 4,
+              "--prune-threshold", 3, "--out-dir", f"{t}/prune", cwd=t)
+    ok, pr = load_model(f"{t}/prune/models_checkpoint/pruned_codebook.pt")
+    counts = [int(l.split(": ")[1].replace(",", "")) for l in out.splitlines()
+              if ": " in l and l.split(": ")[0].isdigit()]
+    assert ok and len(counts) == 16 and sum(counts) == 12 * 16
+    assert pr["num_embeddings"] == sum(c >= 3 for c in counts) \
+        == pr["checkpoint"]["codebook.weight"].shape[0]
 
     tcfg = dict(model_lr=1e-3, num_enc_layers=1, num_dec_layers=2, cross_attn_heads=2,
                 self_attn_heads=4, in_dim=32, hidden_dim=64, hidden_activation="silu",
