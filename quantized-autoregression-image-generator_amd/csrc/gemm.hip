@@ -8,6 +8,8 @@
 // A and B may each be stored reduction-contiguous ([X][K], "kc") or
 // tile-contiguous ([K][X], "xc"); that covers forward (kc,kc), backward-data
 // (kc,xc) and backward-weight (xc,xc) without materialising a transpose.
+#include <stdlib.h>
+
 #include "qarig_common.h"
 
 namespace qarig {
@@ -22,6 +24,60 @@ struct GemmEpilogue {
     int gact;
     float* rowsum;                        // [splitk][M]: sum_k A(m,k) per K split, or null
 };
+
+// Wide epilogue (interior tiles): the wave's 64x64 tile goes through its private 8 KB of
+// LDS in two 32-row halves, so that every global access of the epilogue (C, preact,
+// residual, gradz, slabs) is a 16-B-per-lane, 256-B-per-row dwordx4 instead of 4x as many
+// 4-B accesses (the epilogue is store-issue bound otherwise).  `lds`: >= 32 KB, free.
+__device__ __forceinline__ void gemm_epilogue_wide(const Acc& acc, const GemmEpilogue& ep, float* lds,
+                                                   int m0, int n0, int M, int N, int splitk,
+                                                   float* slabs) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cl = lane & 31;
+    // 4 waves x 32 x 64 floats = 32 KB; unpadded rows are conflict-free for both the b32
+    // writes (half-waves hit different rows) and the b128 reads
+    constexpr int EL = 64;
+    float* stage = lds + wave * (32 * EL);
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+    const int gc = n0 + wn * 64 + ec;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ep.bias && splitk == 1) bv = *reinterpret_cast<const float4*>(ep.bias + gc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stage[acc_row(r, lane) * EL + j * 32 + cl] = acc.t[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int lr = it * 4 + er;
+            const int64_t row = m0 + wm * 64 + i * 32 + lr;
+            float4 t = *reinterpret_cast<const float4*>(stage + lr * EL + ec);
+            if (splitk > 1) {
+                *reinterpret_cast<float4*>(slabs + ((int64_t)blockIdx.z * M + row) * N + gc) = t;
+                continue;
+            }
+            t.x += bv.x; t.y += bv.y; t.z += bv.z; t.w += bv.w;
+            if (ep.residual) {
+                const float4 rv = *reinterpret_cast<const float4*>(ep.residual + row * ep.ldr + gc);
+                t.x += rv.x; t.y += rv.y; t.z += rv.z; t.w += rv.w;
+            }
+            if (ep.preact) *reinterpret_cast<float4*>(ep.preact + row * ep.ldp + gc) = t;
+            float4 y = make_float4(act_fwd(t.x, ep.act), act_fwd(t.y, ep.act),
+                                   act_fwd(t.z, ep.act), act_fwd(t.w, ep.act));
+            if (ep.gradz) {
+                const float4 z = *reinterpret_cast<const float4*>(ep.gradz + row * ep.ldz + gc);
+                y.x *= act_grad(z.x, ep.gact); y.y *= act_grad(z.y, ep.gact);
+                y.z *= act_grad(z.z, ep.gact); y.w *= act_grad(z.w, ep.gact);
+            }
+            *reinterpret_cast<float4*>(ep.C + row * ep.ldc + gc) = y;
+        }
+        __syncthreads();
+    }
+}
 
 // sum_k A(m0 + tid, k) from the staged A tiles (bias gradient riding on the dW GEMM).
 struct RowSumHook {
@@ -67,52 +123,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpi
     const int cl = lane & 31;
 
     if (FAST && vec_epi) {
-        // Wide epilogue: the wave's 64x64 tile goes through its private 8 KB of LDS in two
-        // 32-row halves, so that every global access of the epilogue (C, preact, residual,
-        // gradz, slabs) is a 16-B-per-lane, 256-B-per-row dwordx4 instead of 4x as many
-        // 4-B accesses (the epilogue is store-issue bound otherwise).
-        // 4 waves x 32 x 64 floats = 32 KB <= GEMM_LDS_FLOATS; unpadded rows are conflict-free
-        // for both the b32 writes (half-waves hit different rows) and the b128 reads
-        constexpr int EL = 64;
-        float* stage = lds + wave * (32 * EL);
-        const int er = lane >> 4, ec = (lane & 15) * 4;
-        const int gc = n0 + wn * 64 + ec;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ep.bias && splitk == 1) bv = *reinterpret_cast<const float4*>(ep.bias + gc);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stage[acc_row(r, lane) * EL + j * 32 + cl] = acc.t[i][j][r];
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int lr = it * 4 + er;
-                const int64_t row = m0 + wm * 64 + i * 32 + lr;
-                float4 t = *reinterpret_cast<const float4*>(stage + lr * EL + ec);
-                if (splitk > 1) {
-                    *reinterpret_cast<float4*>(slabs + ((int64_t)blockIdx.z * M + row) * N + gc) = t;
-                    continue;
-                }
-                t.x += bv.x; t.y += bv.y; t.z += bv.z; t.w += bv.w;
-                if (ep.residual) {
-                    const float4 rv = *reinterpret_cast<const float4*>(ep.residual + row * ep.ldr + gc);
-                    t.x += rv.x; t.y += rv.y; t.z += rv.z; t.w += rv.w;
-                }
-                if (ep.preact) *reinterpret_cast<float4*>(ep.preact + row * ep.ldp + gc) = t;
-                float4 y = make_float4(act_fwd(t.x, ep.act), act_fwd(t.y, ep.act),
-                                       act_fwd(t.z, ep.act), act_fwd(t.w, ep.act));
-                if (ep.gradz) {
-                    const float4 z = *reinterpret_cast<const float4*>(ep.gradz + row * ep.ldz + gc);
-                    y.x *= act_grad(z.x, ep.gact); y.y *= act_grad(z.y, ep.gact);
-                    y.z *= act_grad(z.z, ep.gact); y.w *= act_grad(z.w, ep.gact);
-                }
-                *reinterpret_cast<float4*>(ep.C + row * ep.ldc + gc) = y;
-            }
-            __syncthreads();
-        }
+        gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, slabs);
         return;
     }
 #pragma unroll
@@ -140,6 +151,157 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpi
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------
+// Interior GEMM, LDS-DMA staging.  Ablations (profiles/README.md) show the register-staged
+// loop above loses ~8 % to its ds_write traffic and ~7 % to ds_read2_b32 fragment reads: LDS
+// instruction issue competes with MFMA issue.  Here the tiles never touch VGPRs on the way
+// in: global_load_lds_dwordx4 writes them straight into a 2-stage LDS ring (32 KB: 4 blocks
+// per CU; ONE barrier per k-tile both publishes tile t and retires the reads of tile t-1,
+// whose stage the DMA of tile t+1 then refills under tile t's MFMAs), and reduction-contiguous
+// operands are kept k-contiguous in LDS ([x][16] floats, 16-B chunks XOR-swizzled by
+// (x>>2)&3 on the SOURCE address so the lane-linear DMA image needs no padding) and read
+// back as two conflict-free ds_read_b128 per fragment.  A lane-half h then owns k = 8h..8h+7
+// of a tile, so MFMA step s contracts k = {s, 8+s}: a fixed permutation of the summation
+// order, nothing else.  Fragment reads are inline asm: hipcc otherwise drains every
+// outstanding DMA (vmcnt(0)) in front of any LDS read.
+// ---------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* glb_ptr_t;
+
+constexpr int DMA_STAGES = 2;
+constexpr int DMA_OP_FLOATS = 128 * BK;              // 8 KB per operand per stage
+constexpr int DMA_STAGE_FLOATS = 2 * DMA_OP_FLOATS;  // A then B
+
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
+}
+
+// Issue this wave's share (2 x 1 KiB) of one operand tile.
+template <bool KC>
+__device__ __forceinline__ void dma_tile(const float* __restrict__ P, int64_t ld, int x0, int k0,
+                                         float* tile, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = wave * 2 + i;
+        const float* src;
+        if (KC) {   // [x][k]: 16 rows x 64 B per instruction, chunk-swizzled
+            const int r = 16 * q + (lane >> 2);
+            const int c = (lane & 3) ^ ((r >> 2) & 3);
+            src = P + (int64_t)(x0 + r) * ld + k0 + 4 * c;
+        } else {    // [k][x]: 2 k-rows x 512 B per instruction
+            const int k = 2 * q + (lane >> 5);
+            src = P + (int64_t)(k0 + k) * ld + x0 + (lane & 31) * 4;
+        }
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + q * 256), 16, 0, 0);
+    }
+}
+
+// The 8 k-values (k = 8h .. 8h+7) of tile row/column `x` for this lane, as two f32x4.
+template <bool KC>
+__device__ __forceinline__ void frag_read(const float* tile, int x, int h, f32x4& lo, f32x4& hi) {
+    if (KC) {
+        const int sw = (x >> 2) & 3;
+        const unsigned base = lds_addr(tile + x * 16);
+        const unsigned a0 = base + (((2 * h) ^ sw) << 4), a1 = base + (((2 * h + 1) ^ sw) << 4);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(lo) : "v"(a0));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(hi) : "v"(a1));
+    } else {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const unsigned base = lds_addr(tile + (8 * h) * 128 + x);   // rows are 512 B = 2 x 64 dwords
+        f32x2 p0, p1, p2, p3;
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:0 offset1:2" : "=v"(p0) : "v"(base));
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:4 offset1:6" : "=v"(p1) : "v"(base));
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:8 offset1:10" : "=v"(p2) : "v"(base));
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:12 offset1:14" : "=v"(p3) : "v"(base));
+        lo = f32x4{p0.x, p0.y, p1.x, p1.y};
+        hi = f32x4{p2.x, p2.y, p3.x, p3.y};
+    }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const float* __restrict__ A,
+                                                               int64_t lda,
+                                                               const float* __restrict__ B,
+                                                               int64_t ldb, GemmEpilogue ep, int M,
+                                                               int N, int K, int tiles_n, int splitk,
+                                                               float* slabs) {
+    __shared__ __attribute__((aligned(16))) float lds[DMA_STAGES * DMA_STAGE_FLOATS];   // 32 KB
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    int k_begin = 0, k_end = K;
+    if (splitk > 1) {
+        const int per = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
+        k_begin = blockIdx.z * per;
+        k_end = min(K, k_begin + per);
+    }
+    const int nk = (k_end - k_begin) / BK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int x = lane & 31, h = lane >> 5;
+    const int last = k_begin + (nk - 1) * BK;
+
+    Acc acc;
+    acc_zero(acc);
+    // bias gradient riding on the dW GEMM: sum_k A(m0 + tid, k), k ascending (A = dT^T, [k][x])
+    float rs = 0.0f;
+    const bool do_rs = !AKC && ep.rowsum != nullptr && tn == 0 && tid < 128;
+    if (nk > 0) {
+        dma_tile<AKC>(A, lda, m0, k_begin, lds, wave, lane);
+        dma_tile<BKC>(B, ldb, n0, k_begin, lds + DMA_OP_FLOATS, wave, lane);
+        int st = 0;                       // stage of tile kt
+        for (int kt = 0; kt < nk; ++kt) {
+            // this wave's DMAs of tile kt have landed, then (barrier) everybody's; the same
+            // barrier retires all reads of tile kt-1, whose stage is refilled right after it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int kn = min(k_begin + (kt + 1) * BK, last);        // tail: harmless re-load
+            dma_tile<AKC>(A, lda, m0, kn, lds + (st ^ 1) * DMA_STAGE_FLOATS, wave, lane);
+            dma_tile<BKC>(B, ldb, n0, kn, lds + (st ^ 1) * DMA_STAGE_FLOATS + DMA_OP_FLOATS, wave, lane);
+            const float* ta = lds + st * DMA_STAGE_FLOATS;
+            const float* tb = ta + DMA_OP_FLOATS;
+            f32x4 a0l, a0h, a1l, a1h, b0l, b0h, b1l, b1h;
+            frag_read<AKC>(ta, wm * 64 + x, h, a0l, a0h);
+            frag_read<BKC>(tb, wn * 64 + x, h, b0l, b0h);
+            frag_read<AKC>(ta, wm * 64 + 32 + x, h, a1l, a1h);
+            frag_read<BKC>(tb, wn * 64 + 32 + x, h, b1l, b1h);
+            f32x4 r0, r1, r2, r3;
+            if (do_rs) {
+                frag_read<false>(ta, tid, 0, r0, r1);
+                frag_read<false>(ta, tid, 1, r2, r3);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_rs) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rs += r0[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rs += r1[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rs += r2[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rs += r3[q];
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float a0 = s < 4 ? a0l[s & 3] : a0h[s & 3];
+                const float a1 = s < 4 ? a1l[s & 3] : a1h[s & 3];
+                const float b0 = s < 4 ? b0l[s & 3] : b0h[s & 3];
+                const float b1 = s < 4 ? b1l[s & 3] : b1h[s & 3];
+                acc.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc.t[0][0], 0, 0, 0);
+                acc.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc.t[0][1], 0, 0, 0);
+                acc.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc.t[1][0], 0, 0, 0);
+                acc.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc.t[1][1], 0, 0, 0);
+            }
+            st ^= 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (do_rs) ep.rowsum[(int64_t)blockIdx.z * M + m0 + tid] = rs;
+    __syncthreads();                      // ring no longer in use: the epilogue stages through it
+    gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, slabs);
 }
 
 // out[i] (+ld handling) = sum_z slabs[z][i], z ascending: deterministic.
@@ -245,6 +407,24 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
     auto ok4 = [&](const void* p, int64_t ld) { return !p || (al16(p) && ld % 4 == 0); };
     const int vec_epi = ok4(C, ldc) && ok4(bias, 4) && ok4(residual, ldr) && ok4(preact, ldp) &&
                         ok4(gradz, ldz) && ok4(slabs, 4);
+    // LDS-DMA kernel: interior shapes, 16-B epilogue, no row-sum hook; QARIG_GEMM_DMA=0 disables
+    static const bool dma_on = []() { const char* e = getenv("QARIG_GEMM_DMA"); return !(e && e[0] == '0'); }();
+    // measured (tools/gemm_bench.py): the DMA kernel wins on long reductions and narrow outputs
+    // (+5..10 %), the register-staged one on K=512 x N=2048 (its epilogue overlaps better
+    // there), so pick per shape
+    const bool dma_shape = per >= 1024 || N <= 512;
+    if (dma_on && dma_shape && fast && vec_epi && !(a_rowsum && a_kcontig) &&
+        !(!a_kcontig && b_kcontig)) {
+        if (a_kcontig && b_kcontig)
+            hipLaunchKernelGGL((gemm_dma_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
+                               N, K, tiles_n, splitk, slabs);
+        else if (a_kcontig)
+            hipLaunchKernelGGL((gemm_dma_kernel<true, false>), grid, block, 0, st, A, lda, B, ldb, ep, M,
+                               N, K, tiles_n, splitk, slabs);
+        else
+            hipLaunchKernelGGL((gemm_dma_kernel<false, false>), grid, block, 0, st, A, lda, B, ldb, ep,
+                               M, N, K, tiles_n, splitk, slabs);
+    } else {
 #define QARIG_LAUNCH_GEMM(TA, TB)                                                              \
     do {                                                                                       \
         TA sa{A, lda, M, K, 1.0f, va};                                                         \
@@ -261,6 +441,7 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
     else if (!a_kcontig && !b_kcontig) QARIG_LAUNCH_GEMM(SrcXContig, SrcXContig);
     else QARIG_LAUNCH_GEMM(SrcXContig, SrcKContig);
 #undef QARIG_LAUNCH_GEMM
+    }
     QARIG_CHECK_LAUNCH("gemm");
     if (a_rowsum) {   // a_rowsum[m] (+)= sum over splits, fixed order
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, rs_part,
