@@ -242,3 +242,43 @@ def test_transformer_readme_shape_vs_oracle():
     with torch.no_grad():
         got2 = m(x2.cuda(), x_enc.cuda(), pos.cuda())
     assert torch.equal(got[:, :-1], got2[:, :-1])
+
+
+def test_readme_block_sizes_train_step_grads_vs_oracle():
+    """README block sizes (512 / 2048 / 64 heads, window conditioning), 2 decoder layers,
+    batch 2 x 256 tokens: loss and parameter gradients of the HIP path (interior GEMM
+    kernels, LDS-broadcast attention, fused gradient accumulation) vs the CPU oracle."""
+    from models.Transformer import Transformer
+    from oracle import ref_models as rm
+    from qarig import functional as QF
+    from qarig.optim import FlatAdam
+    torch.manual_seed(5)
+    m = Transformer(use_encoder=False, use_pos_cond=True, num_enc_layers=None, num_dec_layers=2,
+                    num_enc_embedding=None, num_dec_embedding=1024, self_attn_heads=64,
+                    cross_attn_heads=None, transformer_in_dim=512, transformer_out_dim=513,
+                    transformer_hidden_dim=2048)
+    gen = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.abs().max() == 0:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.02)
+    N, S = 2, 256
+    x = torch.randint(0, 1024, (N, S), generator=gen)
+    t = torch.randint(0, 513, (N, S), generator=gen)
+    pos = torch.randint(0, 2, (N, 1), generator=gen) + torch.arange(S)[None]
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    cfg = dict(use_encoder=False, use_pos_cond=True, num_dec_layers=2, self_attn_heads=64,
+               hidden_activation="silu")
+    ref_loss = rm.cross_entropy(rm.transformer_forward(sd, cfg, x, None, pos), t)
+    ref_loss.backward()
+    m = m.cuda()
+    opt = FlatAdam(m.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    opt.zero_grad()
+    logits = m(x.cuda(), None, pos.cuda())
+    loss = QF.cross_entropy(logits.view(-1, 513), t.cuda().flatten())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-5
+    worst = 0.0
+    for n, p in m.named_parameters():
+        worst = max(worst, grad_err(p.grad, sd[n].grad, floor=1e-7))
+    assert worst < 2e-4, worst   # fp32 vs fp32 with different summation orders, K up to 2048
