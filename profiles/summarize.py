@@ -54,12 +54,13 @@ if f:
             fe = f[k][1] / n
             wr = w[k][1] / max(1, w[k][0]) if k in w else 0.0
             fh.write(f"\"{k}\",{n},{fe:.1f},{wr:.1f},{(2 * fe + wr) * 1024:.0f}\n")
-    gf = [(v[0], v[1]) for k, v in f.items() if "gemm_kernel" in k]
-    gw = [(v[0], v[1]) for k, v in w.items() if "gemm_kernel" in k]
+    is_gemm = lambda k: "gemm_kernel" in k or "gemm_dma_kernel" in k
+    gf = [(v[0], v[1]) for k, v in f.items() if is_gemm(k)]
+    gw = [(v[0], v[1]) for k, v in w.items() if is_gemm(k)]
     n = sum(a for a, _ in gf)
     fetch = sum(b for _, b in gf) / n
     write = sum(b for _, b in gw) / max(1, sum(a for a, _ in gw))
-    json.dump({"round": rnd, "kernel": "qarig::gemm_kernel<*>", "launches_profiled": n,
+    json.dump({"round": rnd, "kernel": "qarig::gemm_dma_kernel<*> + qarig::gemm_kernel<*>", "launches_profiled": n,
                "FETCH_SIZE_KiB_per_launch": round(fetch, 1),
                "WRITE_SIZE_KiB_per_launch": round(write, 1),
                "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
