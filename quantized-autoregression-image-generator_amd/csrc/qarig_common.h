@@ -331,6 +331,10 @@ __device__ __forceinline__ void contract_loop(Acc& acc, const SA& sa, const SB& 
         }
         return;
     }
+    // Guarded path (ragged extents, gathered operands): same shape of pipeline -- the next
+    // tile's (predicated, zero-filling) loads are issued above the MFMA slab and written to
+    // LDS below it; on the last tile the loads repeat that tile so the loop has no
+    // data-dependent branch for hipcc to serialise behind a vmcnt(0).
     sa.load(ra, m0, k_begin, tid);
     sb.load(rb, n0, k_begin, tid);
     sa.store(ra, TA0, tid);
@@ -338,23 +342,21 @@ __device__ __forceinline__ void contract_loop(Acc& acc, const SA& sa, const SB& 
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int kb = k_begin + kt * BK;
-        const bool more = kt + 1 < nk;
+        const int kn = kt + 1 < nk ? kb + BK : kb;
         float* ta = (kt & 1) ? TA1 : TA0;
         float* tb = (kt & 1) ? TB1 : TB0;
         float* na = (kt & 1) ? TA0 : TA1;
         float* nb = (kt & 1) ? TB0 : TB1;
-        if (more) {
-            sa.load(ra, m0, kb + BK, tid);
-            sb.load(rb, n0, kb + BK, tid);
-        }
+        sa.load(ra, m0, kn, tid);
+        sb.load(rb, n0, kn, tid);
+        __builtin_amdgcn_sched_barrier(0);
         const int rem = k_end - kb;
         if (rem >= BK) mma_tile<BK / 2>(acc, ta, tb, wm, wn, lane);
         else mma_tile_tail(acc, ta, tb, wm, wn, lane, (rem + 1) >> 1);
         hook(ta, tb);
-        if (more) {
-            sa.store(ra, na, tid);
-            sb.store(rb, nb, tid);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        sa.store(ra, na, tid);
+        sb.store(rb, nb, tid);
         __syncthreads();
     }
 }
