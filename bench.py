@@ -223,7 +223,7 @@ def main():
         dt = float(t.item())
 
     tokens = N * world * cfg["window"] * args.steps
-    out = {"metric": "image-tokens/sec (BMU quantize + base Transformer train step)",
+    out = {"metric": "image-tokens/sec at 1/2/4/8 GPUs; BMU argmin GB/s vs HBM peak",
            "value": round(tokens / dt, 1), "unit": "image-tokens/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",

@@ -24,7 +24,8 @@ struct ConvGeom {
     int Ho, Wo;            // logical output grid of this launch
     int stride;            // input step per logical output step
     int nty, ntx;          // taps
-    int offy[4], offx[4];  // input offset per tap
+    int oy0, oys, ox0, oxs;  // input offset of tap t: o0 + os*t (os = +-1).  Affine on purpose:
+                             // a per-tap table indexed at run time lives in scratch memory
     int K;                 // C * nty * ntx
     int P;                 // N * Ho * Wo logical output pixels
 };
@@ -70,7 +71,7 @@ struct SrcIm2col {
         for (int q = 0; q < 8; ++q) {
             float v = 0.0f;
             if (valid && k + q < g.K) {
-                const int iy = iy0 + g.offy[ty], ix = ix0 + g.offx[tx];
+                const int iy = iy0 + g.oy0 + g.oys * ty, ix = ix0 + g.ox0 + g.oxs * tx;
                 if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
                     v = g.x[base + ((int64_t)ci * g.H + iy) * g.W + ix];
             }
@@ -144,9 +145,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvGeom g, const floa
     const int taps = g.nty * g.ntx;
     for (int ci = 0; ci < g.C; ++ci) {
         for (int ty = 0; ty < g.nty; ++ty) {
-            const int iy = oy * g.stride + g.offy[ty];
+            const int iy = oy * g.stride + g.oy0 + g.oys * ty;
             for (int tx = 0; tx < g.ntx; ++tx) {
-                const int ix = ox * g.stride + g.offx[tx];
+                const int ix = ox * g.stride + g.ox0 + g.oxs * tx;
                 float v = 0.0f;
                 if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
                     v = xb[((int64_t)ci * g.H + iy) * g.W + ix];
@@ -384,9 +385,7 @@ extern "C" int qarig_conv2d_fwd(const float* x, int N, int Cin, int H, int W, co
     QARIG_CHECK_ARG(Ho > 0 && Wo > 0, "conv2d: empty output");
     QARIG_CHECK_ARG((int64_t)N * Ho * Wo < INT32_MAX && (int64_t)Cin * k * k < INT32_MAX,
                     "conv2d: too large");
-    ConvGeom g{x, N, Cin, H, W, Ho, Wo, stride, k, k, {0, 0, 0, 0}, {0, 0, 0, 0}, Cin * k * k,
-               N * Ho * Wo};
-    for (int t = 0; t < k; ++t) g.offy[t] = g.offx[t] = t - pad;
+    ConvGeom g{x, N, Cin, H, W, Ho, Wo, stride, k, k, -pad, 1, -pad, 1, Cin * k * k, N * Ho * Wo};
     ConvOut o{y, preact, bias, Cout, Ho, Wo, 1, 0, 0, act};
     return launch_conv(w, g, o, (hipStream_t)stream);
 }
@@ -417,10 +416,8 @@ extern "C" int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H,
     QARIG_CHECK_LAUNCH("conv_transpose2d pack");
     for (int cls = 0; cls < 4; ++cls) {
         const int py = cls >> 1, px = cls & 1;
-        ConvGeom g{x, N, Cin, H, W, H, W, 1, 2, 2, {0, 0, 0, 0}, {0, 0, 0, 0}, Cin * 4, N * H * W};
-        // oy = 2a+py: tap th uses kh = 1-py+2th and input row a + (py + 1 - kh)/2
-        g.offy[0] = py;      g.offy[1] = py - 1;
-        g.offx[0] = px;      g.offx[1] = px - 1;
+        // oy = 2a+py: tap th uses kh = 1-py+2th and input row a + (py + 1 - kh)/2 = a + py - th
+        ConvGeom g{x, N, Cin, H, W, H, W, 1, 2, 2, py, -1, px, -1, Cin * 4, N * H * W};
         ConvOut o{y, preact, bias, Cout, 2 * H, 2 * W, 2, py, px, act};
         if (int e = launch_conv(packed + (int64_t)cls * Cout * Cin * 4, g, o, st)) return e;
     }
@@ -456,10 +453,8 @@ extern "C" int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, i
             const int ky0 = (ry + pad) % s, kx0 = (rx + pad) % s;
             const int nty = ky0 < k ? (k - ky0 + s - 1) / s : 0;
             const int ntx = kx0 < k ? (k - kx0 + s - 1) / s : 0;
-            ConvGeom g{dT, N, Cout, Ho, Wo, gh, gw, 1, nty, ntx, {0, 0, 0, 0}, {0, 0, 0, 0},
-                       Cout * nty * ntx, N * gh * gw};
-            for (int t = 0; t < nty; ++t) g.offy[t] = (ry + pad - ky0) / s - t;
-            for (int t = 0; t < ntx; ++t) g.offx[t] = (rx + pad - kx0) / s - t;
+            ConvGeom g{dT, N, Cout, Ho, Wo, gh, gw, 1, nty, ntx, (ry + pad - ky0) / s, -1,
+                       (rx + pad - kx0) / s, -1, Cout * nty * ntx, N * gh * gw};
             ConvOut o{dx, nullptr, nullptr, Cin, H, W, s, ry, rx, ACT_NONE};
             if (nty == 0 || ntx == 0) return QARIG_ERR_ARG;  // cannot happen for pad < k
             const int64_t total = (int64_t)Cin * Cout * nty * ntx;
@@ -479,8 +474,7 @@ extern "C" int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, i
 extern "C" int qarig_conv_transpose2d_bwd_data(const float* dT, int N, int Cout, int H, int W,
                                                const float* w, int Cin, float* dx, void* stream) {
     QARIG_CHECK_ARG(dT && w && dx, "conv_transpose2d_bwd_data: null pointer");
-    ConvGeom g{dT, N, Cout, 2 * H, 2 * W, H, W, 2, 4, 4, {-1, 0, 1, 2}, {-1, 0, 1, 2}, Cout * 16,
-               N * H * W};
+    ConvGeom g{dT, N, Cout, 2 * H, 2 * W, H, W, 2, 4, 4, -1, 1, -1, 1, Cout * 16, N * H * W};
     ConvOut o{dx, nullptr, nullptr, Cin, H, W, 1, 0, 0, ACT_NONE};
     return launch_conv(w, g, o, (hipStream_t)stream);
 }

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Throughput of the conv autoencoder kernels on the README shapes (256/512 channels,
+128x128 images <-> 32x32x4 latents): encoder / decoder images/s and per-layer TFLOP/s.
+Run on the GPU box: python tools/conv_bench.py"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "quantized-autoregression-image-generator_amd"))
+import torch  # noqa: E402
+from models.FC_Decoder import FC_Decoder  # noqa: E402
+from models.FC_Encoder import FC_Encoder  # noqa: E402
+from qarig import ops  # noqa: E402
+
+
+def timeit(fn, reps=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    dec = FC_Decoder(num_layers=2, image_channel=3, min_channel=256, max_channel=512,
+                     latent_channel=4).to(dev).eval()
+    enc = FC_Encoder(num_layers=2, image_channel=3, min_channel=256, max_channel=512,
+                     latent_channel=4).to(dev).eval()
+    with torch.no_grad():
+        for N in (4, 32):
+            z = torch.randn(N, 4, 32, 32, device=dev)
+            x = torch.randn(N, 3, 128, 128, device=dev)
+            for name, m, inp, gf in (("decoder", dec, z, 27.64), ("encoder", enc, x, 53.41)):
+                dt = timeit(lambda: m(inp))
+                print(f"{name} N={N}: {N / dt:8.1f} img/s  {gf * N / dt / 1e3:6.1f} TF")
+        N = 16
+        for cin, cout, hw, s in ((512, 512, 32, 1), (256, 256, 128, 1), (256, 512, 128, 2),
+                                 (3, 256, 128, 1), (256, 3, 128, 1)):
+            x = torch.randn(N, cin, hw, hw, device=dev)
+            w = torch.randn(cout, cin, 3, 3, device=dev) * 0.02
+            b = torch.zeros(cout, device=dev)
+            dt = timeit(lambda: ops.conv2d_fwd(x, w, b, s, 1, 1))
+            ho = hw // s
+            print(f"conv {cin}->{cout} @{hw} s{s}: {dt * 1e3:7.2f} ms "
+                  f"{2.0 * N * cout * cin * 9 * ho * ho / dt / 1e12:6.1f} TF")
+        x = torch.randn(N, 512, 32, 32, device=dev)
+        w = torch.randn(512, 256, 4, 4, device=dev) * 0.02
+        b = torch.zeros(256, device=dev)
+        dt = timeit(lambda: ops.conv_transpose2d_fwd(x, w, b, 1))
+        print(f"convT 512->256 @32: {dt * 1e3:7.2f} ms {2.0 * N * 256 * 512 * 16 * 32 * 32 / dt / 1e12:6.1f} TF")
+
+
+if __name__ == "__main__":
+    main()
