@@ -40,10 +40,12 @@ struct ConvOut {
 };
 
 // B-side loader: x index = logical output pixel, k index = (ci, ty, tx).
+// 32-bit offsets inside one image (host checks C*H*W < 2^31); the per-thread image base is a
+// pointer computed once.
 struct SrcIm2col {
     ConvGeom g;
-    int64_t base;   // n * C*H*W
-    int iy0, ix0;   // oy*stride, ox*stride
+    const float* xb;   // x + n * C*H*W
+    int iy0, ix0;      // oy*stride + oy0, ox*stride + ox0
     bool valid;
 
     __device__ __forceinline__ void init(int x0, int tid) {
@@ -53,29 +55,27 @@ struct SrcIm2col {
         const int n = valid ? p / per : 0;
         const int rem = valid ? p - n * per : 0;
         const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
-        base = (int64_t)n * g.C * g.H * g.W;
-        iy0 = oy * g.stride;
-        ix0 = ox * g.stride;
+        xb = g.x + (int64_t)n * g.C * g.H * g.W;
+        iy0 = oy * g.stride + g.oy0;
+        ix0 = ox * g.stride + g.ox0;
     }
     __device__ __forceinline__ bool interior(int, int, int) const { return false; }
     __device__ __forceinline__ void load_fast(float (&r)[STAGE], int x0, int k0, int tid) const {
         load(r, x0, k0, tid);
     }
     __device__ __forceinline__ void load(float (&r)[STAGE], int, int k0, int tid) const {
-        int k = k0 + (tid >> 7) * 8;
+        const int k = k0 + (tid >> 7) * 8;
         int tx = k % g.ntx;
-        int t = k / g.ntx;
+        const int t = k / g.ntx;
         int ty = t % g.nty;
         int ci = t / g.nty;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            float v = 0.0f;
-            if (valid && k + q < g.K) {
-                const int iy = iy0 + g.oy0 + g.oys * ty, ix = ix0 + g.ox0 + g.oxs * tx;
-                if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
-                    v = g.x[base + ((int64_t)ci * g.H + iy) * g.W + ix];
-            }
-            r[q] = v;
+            const int iy = iy0 + g.oys * ty, ix = ix0 + g.oxs * tx;
+            const bool ok = valid && k + q < g.K && (unsigned)iy < (unsigned)g.H &&
+                            (unsigned)ix < (unsigned)g.W;
+            const int off = (ci * g.H + iy) * g.W + ix;
+            r[q] = ok ? xb[ok ? off : 0] : 0.0f;
             if (++tx == g.ntx) {
                 tx = 0;
                 if (++ty == g.nty) { ty = 0; ++ci; }
@@ -383,7 +383,8 @@ extern "C" int qarig_conv2d_fwd(const float* x, int N, int Cin, int H, int W, co
     QARIG_CHECK_ARG(act >= 0 && act <= 3, "conv2d: bad activation id");
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     QARIG_CHECK_ARG(Ho > 0 && Wo > 0, "conv2d: empty output");
-    QARIG_CHECK_ARG((int64_t)N * Ho * Wo < INT32_MAX && (int64_t)Cin * k * k < INT32_MAX,
+    QARIG_CHECK_ARG((int64_t)N * Ho * Wo < INT32_MAX && (int64_t)Cin * k * k < INT32_MAX &&
+                        (int64_t)Cin * H * W < INT32_MAX,
                     "conv2d: too large");
     ConvGeom g{x, N, Cin, H, W, Ho, Wo, stride, k, k, -pad, 1, -pad, 1, Cin * k * k, N * Ho * Wo};
     ConvOut o{y, preact, bias, Cout, Ho, Wo, 1, 0, 0, act};
