@@ -141,6 +141,18 @@ int qarig_attention_bwd(const float* q, const float* k, const float* v, const fl
                         int causal, float sqrt_d, float* dq, float* dk, float* dv, float* delta,
                         void* stream);
 
+/* Single-token decode step against a KV cache.  The reference has no cache: it re-runs the
+ * whole window for every sampled token (generate_images.py:283-307,
+ * train_quantized_transformer.py:600-640); this computes the same attention row
+ * (models/layers.py:433-474 for the last query) from cached keys/values.  q,k_new,v_new,o
+ * (B,H*d); cache row j of sequence n at n*batch_stride + j*H*d.  k_new/v_new non-NULL:
+ * stored at row len and attended as the last key; NULL: read-only cache (cross-attention).
+ * len_dev (device int, optional) overrides len for graph replay. */
+int qarig_attention_decode(const float* q, const float* k_new, const float* v_new, float* kcache,
+                           float* vcache, int B, int H, int d, int len, const int* len_dev,
+                           int max_len, int64_t batch_stride, float sqrt_d, float* o,
+                           void* stream);
+
 /* nn.CrossEntropyLoss() mean over rows + d/dlogits --
  * train_quantized_transformer.py:337,496-502.  row_ws: M floats. */
 int qarig_cross_entropy_fwd(const float* logits, const int64_t* target, int M, int C, float* loss,

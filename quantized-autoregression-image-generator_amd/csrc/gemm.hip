@@ -357,6 +357,74 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         part[(int64_t)blockIdx.y * N + col] = ((red[0][cx] + red[1][cx]) + red[2][cx]) + red[3][cx];
 }
 
+
+// Skinny GEMM for M <= 64 rows (single-token decode steps: 4..64 sequences x one token).
+// The 128x128 tile kernel leaves 7/8 of its MFMA rows empty there and needs a split-K
+// round trip to find any parallelism (measured 16 us + 6 us reduce per call); this one
+// is a weight-streaming kernel: a block owns 16 output columns, its 16 waves each own
+// 1/16 of K and feed v_mfma_f32_16x16x4_f32 straight from global memory (A rows m on
+// MFMA rows, W rows n on MFMA columns; each lane loads 16 B of a row, so lane groups
+// cover 64 contiguous bytes), partial tiles meet in LDS and are summed in wave order
+// (deterministic), then the usual epilogue runs on 256 threads per 16-row tile.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int MT>
+__global__ __launch_bounds__(1024) void gemm_skinny_kernel(const float* __restrict__ A, int64_t lda,
+                                                           const float* __restrict__ B, int64_t ldb,
+                                                           GemmEpilogue ep, int M, int N, int K) {
+    __shared__ float part[16][MT * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int kslice = K >> 4;
+    const int col = lane & 15, kg = lane >> 4;
+    const int64_t koff = (int64_t)wave * kslice + kg * 4;
+    const float* bp = B + (int64_t)min(n0 + col, N - 1) * ldb + koff;
+    const float* ap[MT];
+    bool aok[MT];
+    floatx4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = t * 16 + col;
+        aok[t] = m < M;
+        ap[t] = A + (int64_t)(aok[t] ? m : 0) * lda + koff;
+        acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int k = 0; k < kslice; k += 16) {
+        const float4 b = *reinterpret_cast<const float4*>(bp + k);
+        float4 a[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            a[t] = *reinterpret_cast<const float4*>(ap[t] + k);
+            if (!aok[t]) a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, b.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, b.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b.w, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][t * 256 + (4 * kg + r) * 16 + col] = acc[t][r];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < MT * 256; idx += 1024) {
+        const int m = (idx >> 8) * 16 + ((idx & 255) >> 4);
+        const int n = n0 + (idx & 15);
+        if (m >= M || n >= N) continue;
+        float v = part[0][idx];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) v += part[w][idx];
+        if (ep.bias) v += ep.bias[n];
+        if (ep.residual) v += ep.residual[(int64_t)m * ep.ldr + n];
+        if (ep.preact) ep.preact[(int64_t)m * ep.ldp + n] = v;
+        float y = act_fwd(v, ep.act);
+        if (ep.gradz) y *= act_grad(ep.gradz[(int64_t)m * ep.ldz + n], ep.gact);
+        ep.C[(int64_t)m * ep.ldc + n] = y;
+    }
+}
 }  // namespace qarig
 
 using namespace qarig;
@@ -391,14 +459,27 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
             return QARIG_ERR_WORKSPACE;
         }
     }
+    hipStream_t st = (hipStream_t)stream;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (M <= 64 && a_kcontig && b_kcontig && K % 256 == 0 && !accumulate && !a_rowsum &&
+        al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0) {
+        GemmEpilogue eps{C, ldc, bias, residual, ldr, preact, ldp, act, gradz, ldz, gact, nullptr};
+        dim3 sgrid((N + 15) / 16), sblock(1024);
+        switch ((M + 15) / 16) {
+            case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K); break;
+            case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K); break;
+            case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K); break;
+            default: hipLaunchKernelGGL((gemm_skinny_kernel<4>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K); break;
+        }
+        QARIG_CHECK_LAUNCH("gemm skinny");
+        return QARIG_OK;
+    }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     dim3 grid(tiles_m * tiles_n, 1, splitk), block(NTHREADS);
-    hipStream_t st = (hipStream_t)stream;
     float* slabs = (float*)workspace;
     // per-split A row sums live behind the slabs
     float* rs_part = a_rowsum ? slabs + (splitk > 1 ? (size_t)splitk * M * N : 0) : nullptr;
     GemmEpilogue ep{C, ldc, bias, residual, ldr, preact, ldp, act, gradz, ldz, gact, rs_part};
-    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     const bool va = al16(A) && lda % 4 == 0, vb = al16(B) && ldb % 4 == 0;
     int per = K;
     if (splitk > 1) per = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;

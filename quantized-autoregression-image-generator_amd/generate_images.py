@@ -29,6 +29,9 @@ def parse_args():
     p.add_argument("--batch-beams", action="store_true",
                    help="(additive) evaluate the num_beam candidate chunks as one batch per model "
                         "call; different RNG consumption order than the sequential reference loop.")
+    p.add_argument("--no-kv-cache", action="store_true",
+                   help="re-run the whole window for every token like the reference instead of "
+                        "decoding one token per step from a key/value cache")
     return vars(p.parse_args())
 
 
@@ -90,7 +93,8 @@ def main():
                 model, hr_input, lr_input, total_Seq, data["temperature"], md["use_sliding_window"],
                 md["sliding_window"], end_token=k_hr, shift=shift, num_beam=data["num_beam"],
                 beam_width=data["beam_width"], mode="generate",
-                progress=lambda i, t: print(f"{i:,} / {t:,}"), batch_beams=args["batch_beams"])
+                progress=lambda i, t: print(f"{i:,} / {t:,}"), batch_beams=args["batch_beams"],
+                use_kv_cache=not args["no_kv_cache"])
             hr_input = hr_input[:, 1:] - shift
             recon = decoder_model(hr_codebook.get_quantized_image(indices=hr_input,
                                                                   unpatchify_input=True))

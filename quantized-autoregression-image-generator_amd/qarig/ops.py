@@ -314,6 +314,22 @@ def attention_fwd(q, k, v, heads, causal):
     return o, lse
 
 
+def attention_decode(q, k_new, v_new, kcache, vcache, length, heads, len_dev=None):
+    """One decode step: q (B,D) against cache rows [0,length) (+ the appended new row).
+    kcache/vcache: (B, max_len, D) views with unit row stride D (batch stride free)."""
+    B, D = q.shape
+    d = D // heads
+    assert kcache.shape == vcache.shape and kcache.shape[0] == B and kcache.shape[2] == D
+    assert kcache.stride(2) == 1 and kcache.stride(1) == D and vcache.stride() == kcache.stride()
+    o = torch.empty_like(q)
+    check(_lib.load().qarig_attention_decode(
+        ptr(q), ptr(k_new) if k_new is not None else None,
+        ptr(v_new) if v_new is not None else None, ptr(kcache), ptr(vcache), B, heads, d,
+        int(length), ptr(len_dev) if len_dev is not None else None, kcache.shape[1],
+        kcache.stride(0), float(d ** 0.5), ptr(o), stream()), "qarig_attention_decode")
+    return o
+
+
 def attention_bwd(q, k, v, o, dO, lse, heads, causal):
     N, Sq, D = q.shape
     Sk = k.shape[1]

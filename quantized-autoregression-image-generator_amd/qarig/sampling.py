@@ -14,13 +14,104 @@ Reference quirks kept on purpose (drop-in behaviour):
  - "generate" loops while len < total_seq, so beam_width must divide total_seq."""
 import torch
 
+from .kvcache import DecodeCache
+
+
+def _sample(logits, temperature, end_token, mode, rows, comb):
+    """One sampling draw as the reference makes it; returns (next ids (B,1), comb)."""
+    probs = torch.softmax(logits / temperature, dim=1)
+    if mode == "generate":
+        probs[:, end_token] = 0.0              # <end> removed from consideration
+    nxt = torch.multinomial(probs, 1)
+    comb = comb * probs[rows, nxt.squeeze(1)]
+    if mode == "train":
+        nxt[nxt == end_token] = 0              # reference HACK: <end> -> index 0
+    return nxt, comb
+
+
+def _cacheable(model, hr_input, use_sliding_window):
+    return (hr_input.shape[1] == 1 and hasattr(model, "decoder_layers")
+            and bool(model.use_pos_cond) == bool(use_sliding_window)
+            and all(l.self_attn_block.self_attn.use_masked_attn for l in model.decoder_layers))
+
+
+def _generate_cached(model, hr_input, enc, total_seq, temperature, use_sliding_window,
+                     sliding_window, end_token, shift, num_beam, beam_width, mode, progress,
+                     stop_len, pos_off, batch_beams):
+    """The same search as the loops below, evaluating one token per model call from a
+    `DecodeCache` for as long as no evaluation of the next chunk would slide the window.
+    Sampling draws are made in the reference's order (same shapes, same generator), so the
+    sequential variant reproduces the full-window loop whenever the logits round alike.
+    Returns (hr_input, pos) for the windowed loops to continue from."""
+    device = hr_input.device
+    N = hr_input.shape[0]
+    B = num_beam if batch_beams and num_beam > 1 else 1
+    limit = min(stop_len, sliding_window) if use_sliding_window else stop_len
+    pos = torch.zeros((N, 1), device=device) if use_sliding_window else None
+    cur = hr_input.shape[1]
+    if cur + beam_width > limit:
+        return hr_input, pos
+    enc_b = enc.repeat_interleave(B, dim=0) if (enc is not None and B > 1) else enc
+    cache = DecodeCache(model, enc_b, N * B, limit)
+    rows = torch.arange(N * B, device=device)
+
+    def positions(value):
+        return torch.full((N * B,), float(value), device=device) if use_sliding_window else None
+
+    last = cache.step(hr_input[:, 0].repeat_interleave(B), positions(0.0), 0)
+    while cur < stop_len and cur + beam_width <= limit:
+        best_chunk = best_p = best_rows = None
+        for _ in range(1 if B > 1 else num_beam):
+            comb = torch.ones(N * B, device=device)
+            logits, new = last, []
+            for tok in range(beam_width):
+                nxt, comb = _sample(logits, temperature, end_token, mode, rows, comb)
+                new.append(nxt + shift)
+                if tok < beam_width - 1:
+                    logits = cache.step(new[-1].squeeze(1), positions(cur + tok + pos_off),
+                                        cur + tok)
+            chunk = torch.cat(new, dim=1)
+            if B > 1 or num_beam == 1:
+                best_chunk, best_p = chunk, comb
+                continue
+            saved = cache.rows(cur, cur + beam_width - 1).clone() if beam_width > 1 else None
+            if best_p is None:
+                best_chunk, best_p, best_rows = chunk, comb, saved
+            else:   # per sample, keep the candidate chunk with the larger probability product
+                keep = best_p >= comb
+                best_p = torch.where(keep, best_p, comb)
+                best_chunk = torch.where(keep[:, None], best_chunk, chunk)
+                if saved is not None:
+                    best_rows = torch.where(keep[None, None, :, None, None], best_rows, saved)
+        if B > 1:       # first beam with the maximal product wins, as in _generate_batched
+            pick = torch.arange(N, device=device) * B + best_p.view(N, B).argmax(dim=1)
+            best_chunk = best_chunk[pick]
+            if beam_width > 1:
+                r = cache.rows(cur, cur + beam_width - 1)
+                r.copy_(r[:, :, pick].repeat_interleave(B, dim=2))
+        elif best_rows is not None:
+            cache.rows(cur, cur + beam_width - 1).copy_(best_rows)
+        hr_input = torch.cat((hr_input, best_chunk.long()), dim=1)
+        if use_sliding_window:
+            pos = torch.cat([pos] + [torch.full((N, 1), float(cur + tok + pos_off), device=device)
+                                     for tok in range(beam_width)], dim=1)
+        cur += beam_width
+        if progress is not None:
+            progress(cur - 1, total_seq)
+        if cur < stop_len and cur + beam_width <= limit:   # another cached chunk follows
+            last = cache.step(best_chunk[:, -1].repeat_interleave(B),
+                              positions(cur - 1 + pos_off), cur - 1)
+    return hr_input, pos
+
 
 @torch.no_grad()
 def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_sliding_window,
                     sliding_window, end_token, shift=0, num_beam=1, beam_width=1, mode="generate",
-                    progress=None, batch_beams=False):
+                    progress=None, batch_beams=False, use_kv_cache=True):
     """hr_input: (N, S0) int64 conditioning/start tokens.  Returns the extended (N, S) tensor
-    (first tokens included; callers strip them and undo `shift`)."""
+    (first tokens included; callers strip them and undo `shift`).  use_kv_cache: evaluate one
+    token per step from a key/value cache until the window starts to slide (same logits up
+    to fp32 summation order); False re-runs the window for every token like the reference."""
     assert mode in ("generate", "train")
     device = hr_input.device
     N = hr_input.shape[0]
@@ -30,10 +121,15 @@ def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_slidi
     rows = torch.arange(N, device=device)
     stop_len = total_seq if mode == "generate" else hr_input.shape[1] + total_seq
     pos_off = 1 if mode == "generate" else 0
+    if use_kv_cache and _cacheable(model, hr_input, use_sliding_window):
+        hr_input, pos = _generate_cached(model, hr_input, enc, total_seq, temperature,
+                                         use_sliding_window, sliding_window, end_token, shift,
+                                         num_beam, beam_width, mode, progress, stop_len, pos_off,
+                                         batch_beams)
     if batch_beams and num_beam > 1:
         return _generate_batched(model, hr_input, enc, total_seq, temperature, use_sliding_window,
                                  sliding_window, end_token, shift, num_beam, beam_width, mode,
-                                 progress, stop_len, pos_off)
+                                 progress, stop_len, pos_off, pos)
     while hr_input.shape[1] < stop_len:
         cur = hr_input.shape[1]
         best_in = best_p = None
@@ -73,7 +169,7 @@ def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_slidi
 
 def _generate_batched(model, hr_input, enc, total_seq, temperature, use_sliding_window,
                       sliding_window, end_token, shift, num_beam, beam_width, mode, progress,
-                      stop_len, pos_off):
+                      stop_len, pos_off, pos):
     """Same search, with the `num_beam` independent candidate chunks evaluated as ONE batch
     of N*num_beam sequences per model call (the reference runs them one after the other).
     Additive option: 1/num_beam of the model calls; the device generator is consumed in a
@@ -81,7 +177,6 @@ def _generate_batched(model, hr_input, enc, total_seq, temperature, use_sliding_
     device = hr_input.device
     N, B = hr_input.shape[0], num_beam
     enc_b = enc.repeat_interleave(B, dim=0) if enc is not None else None
-    pos = torch.zeros((N, 1), device=device) if use_sliding_window else None
     start = 0
     rows = torch.arange(N * B, device=device)
     while hr_input.shape[1] < stop_len:

@@ -197,7 +197,8 @@ def _oracle_generate(fwd, hr_input, lr_input, total_seq, temperature, use_sw, sw
     return hr_input
 
 
-def test_generation_loop_real_model_matches_oracle_restatement():
+@pytest.mark.parametrize("use_kv_cache", [False, True])
+def test_generation_loop_real_model_matches_oracle_restatement(use_kv_cache):
     """At a near-zero temperature the sampler is an argmax, so the GPU generation loop
     (device sampler, real HIP model) must emit exactly the tokens of the reference's loop
     restated on the CPU oracle model."""
@@ -222,7 +223,8 @@ def test_generation_loop_real_model_matches_oracle_restatement():
     want = _oracle_generate(fwd, first, None, total, T, True, sw, 32, 7, 2, 4)
     torch.manual_seed(0)
     got = sampling.generate_tokens(m, first.cuda(), None, total, T, True, sw, end_token=32, shift=7,
-                                   num_beam=2, beam_width=4, mode="generate")
+                                   num_beam=2, beam_width=4, mode="generate",
+                                   use_kv_cache=use_kv_cache)
     assert got.shape == want.shape == (N, 25)
     assert torch.equal(got.cpu(), want)
 

@@ -69,6 +69,34 @@ def test_gemm_splitk_and_colsum():
     assert rel_err(ops.colsum(X), X.double().sum(0)) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 16, 256), (4, 2048, 512), (16, 512, 2048), (17, 513, 512),
+                                   (33, 100, 768), (64, 2048, 512), (48, 7, 256)])
+def test_gemm_skinny_decode_shapes(M, N, K):
+    """M <= 64, K % 256 == 0, both operands reduction-contiguous: the weight-streaming
+    16x16x4-MFMA kernel (decode steps), every epilogue option, strided A, ragged N."""
+    from qarig import ops
+    from oracle import ref_models as rm
+    g = torch.Generator().manual_seed(M + N + K)
+    big = torch.randn((M, K + 4), generator=g).cuda()
+    A = big[:, 4:]                      # 16-B aligned rows, ld = K + 4
+    W = (torch.randn((N, K), generator=g) * 0.1).cuda()
+    b = torch.randn((N,), generator=g).cuda()
+    R = torch.randn((M, N), generator=g).cuda()
+    Z = torch.randn((M, N), generator=g).cuda()
+    t = A.double().cpu() @ W.double().cpu().t()
+    assert rel_err(ops.gemm(A, W), t) < GEMM_TOL * max(1, K / 512) ** 0.5
+    for act_name, act in (("silu", 1), (None, 0)):
+        C, pre = ops.gemm(A, W, bias=b, residual=R, want_preact=True, act=act)
+        tt = t + b.double().cpu() + R.double().cpu()
+        assert rel_err(pre, tt) < GEMM_TOL * max(1, K / 512) ** 0.5
+        assert rel_err(C, rm.activation(tt, act_name)) < 5e-6 * max(1, K / 512) ** 0.5
+    Zd = Z.double().cpu().requires_grad_(True)
+    rm.activation(Zd, "silu").sum().backward()
+    G = ops.gemm(A, W, gradz=Z, gact=1)
+    assert rel_err(G, t * Zd.grad) < 5e-6 * max(1, K / 512) ** 0.5
+    assert torch.equal(ops.gemm(A, W), ops.gemm(A, W, splitk=4))    # own K split, deterministic
+
+
 def test_gemm_strided_views():
     from qarig import ops
     g = torch.Generator().manual_seed(2)

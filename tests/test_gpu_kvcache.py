@@ -1,0 +1,120 @@
+"""KV-cache decoding: the single-token step must reproduce the last row of the full-window
+decoder (reference generate_images.py:283-290 evaluates the whole window per token), and
+the cached generation loop must emit the tokens of the full-window loop."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(use_encoder, adaln0=False, heads=8, dim=64, hidden=128, layers=2, vocab=41):
+    from models.Transformer import Transformer
+    torch.manual_seed(3)
+    kw = dict(use_encoder=use_encoder, use_pos_cond=True, num_enc_layers=2 if use_encoder else None,
+              num_dec_layers=layers, num_enc_embedding=vocab if use_encoder else None,
+              num_dec_embedding=vocab, self_attn_heads=heads,
+              cross_attn_heads=heads if use_encoder else None, transformer_in_dim=dim,
+              transformer_out_dim=vocab, transformer_hidden_dim=hidden)
+    m = Transformer(**kw).cuda().eval()
+    with torch.no_grad():       # AdaLN-zero style zero inits would hide the conditioning path
+        for p in m.parameters():
+            if p.abs().max() == 0:
+                p.normal_(0, 0.05)
+    return m
+
+
+def test_attention_decode_matches_full_attention():
+    from qarig import ops
+    torch.manual_seed(0)
+    for heads, d in ((8, 8), (4, 16), (2, 64), (16, 4)):
+        B, L, D, Lmax = 5, 150, heads * d, 160
+        q = torch.randn(B, 1, D, device="cuda")
+        k = torch.randn(B, L + 1, D, device="cuda")
+        v = torch.randn(B, L + 1, D, device="cuda")
+        want = ops.attention_fwd(q, k, v, heads, False)[0][:, 0]
+        kc = torch.zeros(B, Lmax, D, device="cuda")
+        vc = torch.zeros(B, Lmax, D, device="cuda")
+        kc[:, :L] = k[:, :L]
+        vc[:, :L] = v[:, :L]
+        got = ops.attention_decode(q[:, 0].contiguous(), k[:, L].contiguous(), v[:, L].contiguous(),
+                                   kc, vc, L, heads)
+        assert rel_err(got, want) < 1e-5
+        assert torch.equal(kc[:, L], k[:, L]) and torch.equal(vc[:, L], v[:, L])   # appended
+        assert not kc[:, L + 1:].any()
+        # read-only form (cross-attention) on a strided batch view, and device-side length
+        got2 = ops.attention_decode(q[:, 0].contiguous(), None, None, kc, vc, L + 1, heads)
+        assert rel_err(got2, want) < 1e-5
+        ln = torch.tensor([L + 1], dtype=torch.int32, device="cuda")
+        got3 = ops.attention_decode(q[::2, 0].contiguous(), None, None, kc[::2], vc[::2], 0, heads,
+                                    len_dev=ln)
+        assert rel_err(got3, want[::2]) < 1e-5
+
+
+def test_attention_decode_rejects_bad_length():
+    from qarig import ops
+    q = torch.randn(2, 32, device="cuda")
+    kc = torch.zeros(2, 8, 32, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.attention_decode(q, q, q, kc, kc.clone(), 8, 4)      # append past the end
+    with pytest.raises(RuntimeError):
+        ops.attention_decode(q, None, None, kc, kc.clone(), 0, 4)   # nothing to attend
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("use_encoder", [False, True])
+def test_decode_cache_step_matches_full_window(use_encoder, graph):
+    from qarig.kvcache import DecodeCache
+    m = _model(use_encoder)
+    B, S = 3, 12
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, 41, (B, S), generator=g).cuda()
+    pos = torch.rand(B, S, generator=g).cuda() * 20
+    with torch.no_grad():
+        enc = m.encode(torch.randint(0, 41, (B, 7), generator=g).cuda()) if use_encoder else None
+        cache = DecodeCache(m, enc, B, S, graph=graph)
+        for t in range(S):
+            got = cache.step(ids[:, t], pos[:, t], t)
+            want = m.decode(ids[:, :t + 1].contiguous(), enc, pos[:, :t + 1].contiguous())[:, -1]
+            assert rel_err(got, want) < 1e-5, t
+        with pytest.raises(IndexError):
+            cache.step(ids[:, 0], pos[:, 0], S)
+
+
+@pytest.mark.parametrize("use_encoder,num_beam,bw,batch_beams", [
+    (False, 1, 1, False), (False, 3, 4, False), (True, 2, 4, False), (True, 3, 2, True),
+    (False, 2, 4, True)])
+def test_cached_generation_matches_full_window_loop(use_encoder, num_beam, bw, batch_beams):
+    """Same seed, same draw order: the cached loop (then its windowed continuation once the
+    window slides) must emit the tokens of the reference-style full-window loop."""
+    from qarig import sampling
+    m = _model(use_encoder)
+    with torch.no_grad():
+        m.classifier[1].linear_layer[0].bias[40] -= 20.0     # <end> out of the way
+    N, total, sw = 3, 24, 16
+    g = torch.Generator().manual_seed(4)
+    lr_in = torch.randint(0, 40, (N, 6), generator=g).cuda() if use_encoder else None
+    first = torch.randint(0, 40, (N, 1), generator=g).cuda()
+    outs = []
+    for cached in (False, True):
+        torch.manual_seed(11)
+        outs.append(sampling.generate_tokens(m, first, lr_in, total, 0.05, True, sw, end_token=40,
+                                             num_beam=num_beam, beam_width=bw, mode="generate",
+                                             batch_beams=batch_beams, use_kv_cache=cached))
+    assert outs[0].shape[1] >= total       # the loop overshoots to 1 + k*beam_width
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_cached_train_mode_sampling_matches():
+    from qarig import sampling
+    m = _model(False)
+    N, total, sw = 2, 20, 32
+    first = torch.randint(0, 40, (N, 1), generator=torch.Generator().manual_seed(9)).cuda()
+    outs = []
+    for cached in (False, True):
+        torch.manual_seed(5)
+        outs.append(sampling.generate_tokens(m, first, None, total, 0.05, True, sw, end_token=40,
+                                             mode="train", use_kv_cache=cached))
+    assert outs[0].shape == (N, total + 1)
+    assert torch.equal(outs[0], outs[1])
