@@ -297,29 +297,41 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(
         ov[c] = 0.0f;
     }
     float m = -INFINITY, l = 0.0f;
-    for (int j = lane; j < Sk; j += 64) {
-        const bool fresh = app && j == L;   // read the new row from its source, not the cache
-        const float* kr = fresh ? k_new + row : kb + (int64_t)j * D;
-        const float* vr = fresh ? v_new + row : vb + (int64_t)j * D;
-        float kk[HD], vv[HD];
+    // U rows per lane are fetched back to back (the step is latency bound), then folded
+    // into the running softmax in key order
+    constexpr int U = HD <= 16 ? 4 : 2;
+    for (int j0 = lane; j0 < Sk; j0 += 64 * U) {
+        float kk[U][HD], vv[U][HD];
 #pragma unroll
-        for (int c = 0; c < HD; c += 4) {
-            const float4 a = *reinterpret_cast<const float4*>(kr + c);
-            const float4 b = *reinterpret_cast<const float4*>(vr + c);
-            kk[c] = a.x; kk[c + 1] = a.y; kk[c + 2] = a.z; kk[c + 3] = a.w;
-            vv[c] = b.x; vv[c + 1] = b.y; vv[c + 2] = b.z; vv[c + 3] = b.w;
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + 64 * u;
+            const bool in = j < Sk;
+            const bool fresh = app && j == L;   // the new row comes from its source, not the cache
+            const float* kr = fresh ? k_new + row : kb + (int64_t)(in ? j : 0) * D;
+            const float* vr = fresh ? v_new + row : vb + (int64_t)(in ? j : 0) * D;
+#pragma unroll
+            for (int c = 0; c < HD; c += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(kr + c);
+                const float4 b = *reinterpret_cast<const float4*>(vr + c);
+                kk[u][c] = a.x; kk[u][c + 1] = a.y; kk[u][c + 2] = a.z; kk[u][c + 3] = a.w;
+                vv[u][c] = b.x; vv[u][c + 1] = b.y; vv[u][c + 2] = b.z; vv[u][c + 3] = b.w;
+            }
         }
-        float dot = 0.0f;
 #pragma unroll
-        for (int c = 0; c < HD; ++c) dot = fmaf(qv[c], kk[c], dot);
-        const float t = dot * c2;
-        const float mn = fmaxf(m, t);
-        const float alpha = exp2_fast(m - mn);
-        const float p = exp2_fast(t - mn);
-        l = l * alpha + p;
+        for (int u = 0; u < U; ++u) {
+            if (j0 + 64 * u >= Sk) break;
+            float dot = 0.0f;
 #pragma unroll
-        for (int c = 0; c < HD; ++c) ov[c] = fmaf(p, vv[c], ov[c] * alpha);
-        m = mn;
+            for (int c = 0; c < HD; ++c) dot = fmaf(qv[c], kk[u][c], dot);
+            const float t = dot * c2;
+            const float mn = fmaxf(m, t);
+            const float alpha = exp2_fast(m - mn);
+            const float p = exp2_fast(t - mn);
+            l = l * alpha + p;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) ov[c] = fmaf(p, vv[u][c], ov[c] * alpha);
+            m = mn;
+        }
     }
     const float M = wave_max(m);
     const float sc = m == -INFINITY ? 0.0f : exp2_fast(m - M);

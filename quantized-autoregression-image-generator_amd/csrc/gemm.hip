@@ -389,21 +389,30 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(const float* __restri
         ap[t] = A + (int64_t)(aok[t] ? m : 0) * lda + koff;
         acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int k = 0; k < kslice; k += 16) {
-        const float4 b = *reinterpret_cast<const float4*>(bp + k);
-        float4 a[MT];
+    // U k-steps of loads are issued back to back before their MFMAs: the kernel is pure
+    // memory latency (a wave's whole K slice is 2..8 such steps), so the loads must overlap
+    constexpr int U = MT == 1 ? 8 : (MT == 2 ? 4 : 2);
+    for (int k0 = 0; k0 < kslice; k0 += 16 * U) {
+        float4 b[U], a[MT][U];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            a[t] = *reinterpret_cast<const float4*>(ap[t] + k);
-            if (!aok[t]) a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 16 * u;
+            const bool in = k < kslice;          // wave-uniform
+            b[u] = in ? *reinterpret_cast<const float4*>(bp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                a[t][u] = (in && aok[t]) ? *reinterpret_cast<const float4*>(ap[t] + k)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, b.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, b.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b.w, acc[t], 0, 0, 0);
-        }
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][u].x, b[u].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][u].y, b[u].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][u].z, b[u].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][u].w, b[u].w, acc[t], 0, 0, 0);
+            }
     }
 #pragma unroll
     for (int t = 0; t < MT; ++t)

@@ -10,6 +10,9 @@ namespace qarig {
 
 constexpr int LN_WAVES = 4;
 
+// NV > 0: D == NV * 256 and every pointer 16-B aligned (the Transformer widths); NV == 0:
+// any D, scalar three-pass form.
+template <int NV>
 __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_fwd_kernel(
     const float* __restrict__ x, int M, int D, float eps, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ scale,
@@ -19,6 +22,46 @@ __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_fwd_kernel(
     const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     if (row >= M) return;
     const float* xr = x + (int64_t)row * D;
+    if (NV > 0) {
+        // the row lives in registers: one 16-B load per 256 columns per lane, no re-reads
+        float4 r[NV > 0 ? NV : 1];
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            r[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+            s += (r[i].x + r[i].y) + (r[i].z + r[i].w);
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            r[i].x -= mean; r[i].y -= mean; r[i].z -= mean; r[i].w -= mean;
+            v = fmaf(r[i].x, r[i].x, v); v = fmaf(r[i].y, r[i].y, v);
+            v = fmaf(r[i].z, r[i].z, v); v = fmaf(r[i].w, r[i].w, v);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)D + eps);
+        if (lane == 0) {
+            mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
+        float* yr = y + (int64_t)row * D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            float4 h = make_float4(r[i].x * rstd, r[i].y * rstd, r[i].z * rstd, r[i].w * rstd);
+            if (gamma) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+                const float4 b = *reinterpret_cast<const float4*>(beta + c);
+                h = make_float4(h.x * g.x + b.x, h.y * g.y + b.y, h.z * g.z + b.z, h.w * g.w + b.w);
+            } else if (scale) {
+                const float4 g = *reinterpret_cast<const float4*>(scale + (int64_t)row * D + c);
+                const float4 b = *reinterpret_cast<const float4*>(shift + (int64_t)row * D + c);
+                h = make_float4(g.x * h.x + b.x, g.y * h.y + b.y, g.z * h.z + b.z, g.w * h.w + b.w);
+            }
+            *reinterpret_cast<float4*>(yr + c) = h;
+        }
+        return;
+    }
     float s = 0.0f;
     for (int c = lane; c < D; c += 64) s += xr[c];
     const float mean = wave_sum(s) / (float)D;
@@ -84,9 +127,21 @@ extern "C" int qarig_layernorm_fwd(const float* x, int M, int D, float eps, cons
     QARIG_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "layernorm_fwd: gamma/beta pair");
     QARIG_CHECK_ARG((scale == nullptr) == (shift == nullptr), "layernorm_fwd: scale/shift pair");
     QARIG_CHECK_ARG(!(gamma && scale), "layernorm_fwd: affine and AdaLN forms are exclusive");
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((M + LN_WAVES - 1) / LN_WAVES),
-                       dim3(LN_WAVES * 64), 0, (hipStream_t)stream, x, M, D, eps, gamma, beta, scale,
-                       shift, y, mean, rstd);
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    const bool vec = D % 256 == 0 && al16(x) && al16(y) && al16(gamma) && al16(beta) &&
+                     al16(scale) && al16(shift);
+    const dim3 grid((M + LN_WAVES - 1) / LN_WAVES), block(LN_WAVES * 64);
+#define QARIG_LN_LAUNCH(NV)                                                                      \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<NV>), grid, block, 0, (hipStream_t)stream, x, M, D, \
+                       eps, gamma, beta, scale, shift, y, mean, rstd)
+    switch (vec ? D / 256 : 0) {
+        case 1: QARIG_LN_LAUNCH(1); break;
+        case 2: QARIG_LN_LAUNCH(2); break;
+        case 4: QARIG_LN_LAUNCH(4); break;
+        case 8: QARIG_LN_LAUNCH(8); break;
+        default: QARIG_LN_LAUNCH(0); break;
+    }
+#undef QARIG_LN_LAUNCH
     QARIG_CHECK_LAUNCH("layernorm_fwd");
     return QARIG_OK;
 }

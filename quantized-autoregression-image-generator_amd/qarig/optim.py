@@ -52,7 +52,7 @@ class FlatAdam:
                 p.grad = self.flat_grad[o:o + s].view(p.shape)
 
     # -- data-parallel overlap ----------------------------------------------------------
-    def enable_allreduce_overlap(self):
+    def enable_allreduce_overlap(self, force=False):
         """Launch the RCCL sum all-reduce of each gradient bucket as soon as the backward
         pass has written every gradient in it (buckets are contiguous runs of the flat
         buffer in parameter order, i.e. whole layers; backward completes them last layer
@@ -62,7 +62,7 @@ class FlatAdam:
         Assumes each parameter receives its gradient once per step (true for the models
         of this repository)."""
         if self._overlap or not (dist.is_available() and dist.is_initialized()) \
-                or dist.get_world_size() == 1:
+                or (dist.get_world_size() == 1 and not force):
             return
         self._overlap = True
         self._bucket_of, self._bucket_range, self._pending0 = {}, [], []

@@ -18,10 +18,11 @@ def env_world():
         int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend=None):
-    """Initialises torch.distributed from the torchrun environment (no-op at world 1)."""
+def init(backend=None, force=False):
+    """Initialises torch.distributed from the torchrun environment (no-op at world 1 unless
+    `force`, which tests use to drive the RCCL code path with a single rank)."""
     world, rank, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

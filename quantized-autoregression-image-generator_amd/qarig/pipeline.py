@@ -49,7 +49,7 @@ def train_step(model, optim, hr_input, lr_input, hr_target, pos_idx, dp=True):
     loss = QF.cross_entropy(logits.view(-1, logits.shape[-1]), hr_target.flatten())
     loss.backward()
     w = parallel.world_size() if dp else 1
-    if w > 1 and not optim.finish_allreduce():      # overlapped buckets, else one exchange
+    if dp and not optim.finish_allreduce() and w > 1:   # overlapped buckets, else one exchange
         parallel.allreduce_flat(optim.flat_grad)
     optim.step(grad_scale=1.0 / w)
     return loss

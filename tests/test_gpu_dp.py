@@ -45,7 +45,7 @@ def _data():
             torch.randint(0, 50, (N, 1), generator=g) + torch.arange(S)[None])
 
 
-def _worker(rank, world, port, overlap, q):
+def _worker(rank, world, port, overlap, q, backend="gloo"):
     from conftest import PKG, ROOT
     for p in (ROOT, PKG):
         if p not in sys.path:
@@ -54,14 +54,14 @@ def _worker(rank, world, port, overlap, q):
                       WORLD_SIZE=str(world), LOCAL_RANK="0")
     from qarig import optim as qoptim
     from qarig import parallel, pipeline
-    parallel.init(backend="gloo")
+    parallel.init(backend=backend, force=True)
     torch.cuda.set_device(0)
     m = _build().cuda()
     qoptim.BUCKET_ELEMS = 20_000                 # several buckets on this tiny model
     opt = qoptim.FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
     parallel.broadcast_params(opt.flat_param)
     if overlap:
-        opt.enable_allreduce_overlap()
+        opt.enable_allreduce_overlap(force=True)
         assert len(opt._bucket_range) > 2
     x, e, t, pos = (parallel.shard(v).cuda() for v in _data())
     for _ in range(2):
@@ -105,3 +105,37 @@ def test_dp2_step_equals_single_process(overlap):
     assert got is not None and all(p.exitcode == 0 for p in procs)
     # two Adam steps: the second one sees weights that already differ by summation-order noise
     assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+
+
+def test_rccl_single_rank_overlapped_allreduce_path():
+    """The production transport: backend "nccl" (= RCCL).  The test box has one GPU, so the
+    group has one rank; the step still goes through RCCL init, the bucketed asynchronous
+    all-reduces issued from the backward thread and their stream ordering against the
+    fused gradient kernels and the Adam launch.  A sum over one rank is the identity, so the
+    weights must equal a step without any exchange bit for bit."""
+    from qarig import pipeline
+    from qarig.optim import FlatAdam
+    m = _build().cuda()
+    opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    x, e, t, pos = (v.cuda() for v in _data())
+    for _ in range(2):
+        pipeline.train_step(m, opt, x, e, t, pos, dp=False)
+    want = opt.flat_param.detach().cpu()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), True, q, "nccl"))
+    p.start()
+    import queue
+    got = None
+    for _ in range(180):
+        try:
+            got, _ = q.get(timeout=1)
+            break
+        except queue.Empty:
+            if p.exitcode not in (None, 0):
+                break
+    p.join(timeout=30)
+    if p.is_alive():
+        p.kill()
+    assert got is not None and p.exitcode == 0
+    assert torch.equal(got, want)
