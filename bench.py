@@ -33,6 +33,7 @@ for p in (ROOT, PKG):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBPS = 8000.0
 
@@ -163,6 +164,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                    help="f32 = the parity mode and the headline number; bf16 = opt-in reduced "
+                         "precision (Linear GEMMs on the bf16 MFMA, fp32 accumulate/storage), "
+                         "reported under its own workload name, never as the headline")
     ap.add_argument("--config", choices=["c2", "c4"], default="c2",
                     help="c2 (default, the headline workload) or the config-4 per-GPU shard")
     args = ap.parse_args()
@@ -170,6 +175,7 @@ def main():
     from qarig import ops, parallel, pipeline
     from qarig.optim import FlatAdam
 
+    ops.PRECISION = args.precision
     world, rank, local = parallel.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
@@ -226,9 +232,10 @@ def main():
     out = {"metric": "image-tokens/sec at 1/2/4/8 GPUs; BMU argmin GB/s vs HBM peak",
            "value": round(tokens / dt, 1), "unit": "image-tokens/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if args.precision == "f32" else "bf16 products / f32 accumulate+storage",
            "data": "synthetic",
-           "config": {"workload": cfg["name"],
+           "config": {"workload": cfg["name"] + ("" if args.precision == "f32" else " [opt-in bf16-MFMA Linear mode, NOT the parity/headline configuration]"),
                       "batch_per_gpu": N, "global_batch": N * world, "seq_len": cfg["window"],
                       "in_dim": cfg["in_dim"], "hidden_dim": cfg["hidden"], "heads": cfg["heads"],
                       "dec_layers": cfg["dec_layers"], "params": int(optim.total),
@@ -242,9 +249,12 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "gemm_traffic.json")
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            out["roofline"] = {"bound": "mfma", "kernel": "qarig::gemm_dma_kernel<*> / gemm_kernel<*> (fp32 MFMA 32x32x2)",
-                               "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
+            kname = ("qarig::gemm_dma_kernel<*> / gemm_kernel<*> (fp32 MFMA 32x32x2)" if args.precision == "f32"
+                     else "qarig::gemm_bf16_kernel<*> (bf16 MFMA 32x32x16; HBM-bound on its fp32 operands)")
+            out["roofline"] = {"bound": "mfma", "kernel": kname,
+                               "achieved": round(ach, 2), "peak": peak,
+                               "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "launches": len(events),
                                "avg_launch_us": round(ms / len(events) * 1e3, 2),
                                "avg_launch_gflop": round(fl / len(events) / 1e9, 3),

@@ -73,6 +73,18 @@ int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const float* B, i
                    const float* gradz, int64_t ldz, int gact, int splitk, int accumulate,
                    float* a_rowsum, void* workspace, size_t ws_bytes, void* stream);
 
+/* Opt-in reduced precision (BASELINE config 5 direction; not the fp32 parity mode): the same
+ * contract as qarig_gemm_f32 -- nn.Linear forward/backward, models/layers.py:234-304,
+ * 389-418 -- with the operand products taken by v_mfma_f32_32x32x16_bf16 (inputs rounded
+ * fp32 -> bf16 round-to-nearest-even in flight, fp32 accumulation, fp32 tensors in HBM).
+ * Interior shapes only (M, N % 128 == 0, every K split % 32 == 0, 16-B aligned, no
+ * a_rowsum); any other call runs the fp32 kernels. */
+int qarig_gemm_bf16(const float* A, int64_t lda, int a_kcontig, const float* B, int64_t ldb,
+                   int b_kcontig, float* C, int64_t ldc, int M, int N, int K, const float* bias,
+                   const float* residual, int64_t ldr, float* preact, int64_t ldp, int act,
+                   const float* gradz, int64_t ldz, int gact, int splitk, int accumulate,
+                   float* a_rowsum, void* workspace, size_t ws_bytes, void* stream);
+
 /* out[N] = column sums of X[M][N] in a fixed order (bias / LayerNorm-affine grads). */
 size_t qarig_colsum_workspace_bytes(int M, int N);
 int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,

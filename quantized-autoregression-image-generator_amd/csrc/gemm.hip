@@ -434,6 +434,131 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(const float* __restri
         ep.C[(int64_t)m * ep.ldc + n] = y;
     }
 }
+
+// ---------------------------------------------------------------------------------
+// Opt-in reduced-precision contraction (BASELINE config 5 direction; NOT the parity mode):
+// operands are rounded fp32 -> bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on their
+// way into LDS and multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation; tensors
+// in HBM, the epilogue and everything around the GEMM stay fp32.  At 16x the fp32 MFMA
+// rate the kernel is bound by its fp32 HBM traffic instead of the matrix pipe.
+// Interior shapes only (M,N % 128, every K split % 32, 16-B aligned operands).
+//
+// LDS image per operand tile: [128 rows][32 k] bf16, row stride 40 (80 B: the 16-B
+// fragment reads of 32 consecutive rows fall on distinct bank groups).  Lane l of a wave
+// reads row (l & 31), k = 8 (l >> 5) + 0..7 of each 16-wide k-step with one ds_read_b128.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HK = 32;
+constexpr int HLD = 40;
+constexpr int HTILE = 128 * HLD;   // bf16 elements per operand tile
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    const f32x2 f = {a, b};
+    const bf16x2 r = __builtin_convertvector(f, bf16x2);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// One thread's share (4 x 16 B) of a 128 x 32 fp32 operand tile, register-staged.
+template <bool KC>
+struct HalfLoader {
+    const float* p;   // tile origin: row x0 (KC: [x][K]) / column x0 (XC: [K][X]), k = 0
+    int64_t ld;
+    float4 r[4];
+    __device__ __forceinline__ void load(int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (KC) {
+                const int idx = threadIdx.x + 256 * i;
+                r[i] = *reinterpret_cast<const float4*>(p + (int64_t)(idx >> 3) * ld + k0 + (idx & 7) * 4);
+            } else {   // 32 lanes cover 512 contiguous bytes of one k row
+                r[i] = *reinterpret_cast<const float4*>(p + (int64_t)(k0 + (threadIdx.x >> 5) * 4 + i) * ld +
+                                                        (threadIdx.x & 31) * 4);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short* tile) const {
+        if (KC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = threadIdx.x + 256 * i;
+                const uint2 v = make_uint2(pack_bf16(r[i].x, r[i].y), pack_bf16(r[i].z, r[i].w));
+                *reinterpret_cast<uint2*>(tile + (idx >> 3) * HLD + (idx & 7) * 4) = v;
+            }
+        } else {   // the thread holds a 4(k) x 4(x) block: transposed in registers
+            const int x = (threadIdx.x & 31) * 4, kq = (threadIdx.x >> 5) * 4;
+            *reinterpret_cast<uint2*>(tile + (x + 0) * HLD + kq) =
+                make_uint2(pack_bf16(r[0].x, r[1].x), pack_bf16(r[2].x, r[3].x));
+            *reinterpret_cast<uint2*>(tile + (x + 1) * HLD + kq) =
+                make_uint2(pack_bf16(r[0].y, r[1].y), pack_bf16(r[2].y, r[3].y));
+            *reinterpret_cast<uint2*>(tile + (x + 2) * HLD + kq) =
+                make_uint2(pack_bf16(r[0].z, r[1].z), pack_bf16(r[2].z, r[3].z));
+            *reinterpret_cast<uint2*>(tile + (x + 3) * HLD + kq) =
+                make_uint2(pack_bf16(r[0].w, r[1].w), pack_bf16(r[2].w, r[3].w));
+        }
+    }
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const float* __restrict__ A, int64_t lda,
+                                                                const float* __restrict__ B, int64_t ldb,
+                                                                GemmEpilogue ep, int M, int N, int K,
+                                                                int tiles_n, int splitk, float* slabs) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[4 * HTILE];   // 2 stages x (A,B): 40 KB
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    int k_begin = 0, k_end = K;
+    if (splitk > 1) {
+        const int per = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
+        k_begin = blockIdx.z * per;
+        k_end = min(K, k_begin + per);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    HalfLoader<AKC> la{AKC ? A + (int64_t)m0 * lda : A + m0, lda, {}};
+    HalfLoader<BKC> lb{BKC ? B + (int64_t)n0 * ldb : B + n0, ldb, {}};
+    Acc acc;
+    acc_zero(acc);
+    la.load(k_begin);
+    lb.load(k_begin);
+    la.store(lds);
+    lb.store(lds + HTILE);
+    __syncthreads();
+    const int frag = (lane & 31) * HLD + (lane >> 5) * 8;
+    int cur = 0;
+    for (int k = k_begin; k < k_end; k += HK) {
+        const bool more = k + HK < k_end;
+        if (more) {
+            la.load(k + HK);
+            lb.load(k + HK);
+        }
+        const unsigned short* ta = lds + cur * 2 * HTILE + wm * 64 * HLD + frag;
+        const unsigned short* tb = lds + cur * 2 * HTILE + HTILE + wn * 64 * HLD + frag;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * HLD + s * 16);
+                fb[i] = *reinterpret_cast<const bf16x8*>(tb + i * 32 * HLD + s * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc.t[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc.t[i][j], 0, 0, 0);
+        }
+        if (more) {
+            la.store(lds + (cur ^ 1) * 2 * HTILE);
+            lb.store(lds + (cur ^ 1) * 2 * HTILE + HTILE);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    gemm_epilogue_wide(acc, ep, reinterpret_cast<float*>(lds), m0, n0, M, N, splitk, slabs);
+}
 }  // namespace qarig
 
 using namespace qarig;
@@ -444,12 +569,12 @@ extern "C" size_t qarig_gemm_workspace_bytes(int M, int N, int splitk) {
     return (splitk > 1 ? sk * M * N * sizeof(float) : 0) + sk * M * sizeof(float);
 }
 
-extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const float* B,
-                              int64_t ldb, int b_kcontig, float* C, int64_t ldc, int M, int N,
-                              int K, const float* bias, const float* residual, int64_t ldr,
-                              float* preact, int64_t ldp, int act, const float* gradz,
-                              int64_t ldz, int gact, int splitk, int accumulate, float* a_rowsum,
-                              void* workspace, size_t ws_bytes, void* stream) {
+static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float* B,
+                         int64_t ldb, int b_kcontig, float* C, int64_t ldc, int M, int N,
+                         int K, const float* bias, const float* residual, int64_t ldr,
+                         float* preact, int64_t ldp, int act, const float* gradz,
+                         int64_t ldz, int gact, int splitk, int accumulate, float* a_rowsum,
+                         void* workspace, size_t ws_bytes, void* stream, bool bf16) {
     QARIG_CHECK_ARG(A && B && C, "gemm: null operand");
     QARIG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad extents M=%d N=%d K=%d", M, N, K);
     QARIG_CHECK_ARG(act >= 0 && act <= 3 && gact >= 0 && gact <= 3, "gemm: bad activation id");
@@ -503,7 +628,20 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
     // (+5..10 %), the register-staged one on K=512 x N=2048 (its epilogue overlaps better
     // there), so pick per shape
     const bool dma_shape = per >= 1024 || N <= 512;
-    if (dma_on && dma_shape && fast && vec_epi && !(a_rowsum && a_kcontig) &&
+    if (bf16 && fast && vec_epi && !a_rowsum && K % HK == 0 && per % HK == 0) {
+        if (a_kcontig && b_kcontig)
+            hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
+                               N, K, tiles_n, splitk, slabs);
+        else if (a_kcontig)
+            hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, st, A, lda, B, ldb, ep, M,
+                               N, K, tiles_n, splitk, slabs);
+        else if (b_kcontig)
+            hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
+                               N, K, tiles_n, splitk, slabs);
+        else
+            hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, st, A, lda, B, ldb, ep,
+                               M, N, K, tiles_n, splitk, slabs);
+    } else if (dma_on && dma_shape && fast && vec_epi && !(a_rowsum && a_kcontig) &&
         !(!a_kcontig && b_kcontig)) {
         if (a_kcontig && b_kcontig)
             hipLaunchKernelGGL((gemm_dma_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
@@ -589,4 +727,29 @@ extern "C" int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float
                        N, chunks, accumulate);
     QARIG_CHECK_LAUNCH("colsum reduce");
     return QARIG_OK;
+}
+
+extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const float* B,
+                              int64_t ldb, int b_kcontig, float* C, int64_t ldc, int M, int N,
+                              int K, const float* bias, const float* residual, int64_t ldr,
+                              float* preact, int64_t ldp, int act, const float* gradz,
+                              int64_t ldz, int gact, int splitk, int accumulate, float* a_rowsum,
+                              void* workspace, size_t ws_bytes, void* stream) {
+    return gemm_dispatch(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, residual, ldr,
+                         preact, ldp, act, gradz, ldz, gact, splitk, accumulate, a_rowsum, workspace,
+                         ws_bytes, stream, false);
+}
+
+// Same contract as qarig_gemm_f32 with the products taken in bf16 (fp32 accumulate) on
+// interior shapes; every other shape, and any call with a_rowsum, runs the fp32 kernels.
+// Opt-in reduced precision (BASELINE config 5 direction): not covered by the fp32 parity bar.
+extern "C" int qarig_gemm_bf16(const float* A, int64_t lda, int a_kcontig, const float* B,
+                               int64_t ldb, int b_kcontig, float* C, int64_t ldc, int M, int N,
+                               int K, const float* bias, const float* residual, int64_t ldr,
+                               float* preact, int64_t ldp, int act, const float* gradz,
+                               int64_t ldz, int gact, int splitk, int accumulate, float* a_rowsum,
+                               void* workspace, size_t ws_bytes, void* stream) {
+    return gemm_dispatch(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, residual, ldr,
+                         preact, ldp, act, gradz, ldz, gact, splitk, accumulate, a_rowsum, workspace,
+                         ws_bytes, stream, true);
 }

@@ -3,6 +3,8 @@
 Shapes/dtypes/contiguity are validated here, before the call, so the C side only
 sees well-formed arguments (SURVEY.md 8b "Errors").
 """
+import os
+
 import torch
 
 from . import _lib
@@ -44,6 +46,12 @@ def bmu(x, codebook, patch_dim):
 # launch stream: entries are (flops, start_event, end_event).
 GEMM_EVENTS = None
 
+# "f32" (default; the parity mode: exact fp32 fma chains on the fp32 MFMA) or "bf16"
+# (opt-in: Linear-layer contractions on the bf16 MFMA with fp32 accumulation and fp32
+# tensors; BASELINE config 5 direction, tolerance stated in tests/test_gpu_bf16.py).
+# QARIG_PRECISION in the environment sets the default.
+PRECISION = os.environ.get("QARIG_PRECISION", "f32")
+
 
 def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_preact=False,
          act=0, gradz=None, gact=0, splitk=None, out=None, accumulate=False, a_rowsum=None):
@@ -76,16 +84,25 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
         nws = lib.qarig_gemm_workspace_bytes(M, N, splitk)
         ws = workspace(nws, A.device, "gemm")
         nws = ws.numel()
+    fn, fn_name = lib.qarig_gemm_f32, "qarig_gemm_f32"
+    if PRECISION == "bf16":
+        fn, fn_name = lib.qarig_gemm_bf16, "qarig_gemm_bf16"
+        if a_rowsum is not None and not a_kcontig:
+            # the bf16 kernel has no row-sum hook: the bias gradient is its own (fp32) pass
+            colsum(A, out=a_rowsum, accumulate=accumulate)
+            a_rowsum = None
+    elif PRECISION != "f32":
+        raise ValueError(f"qarig.ops.PRECISION must be 'f32' or 'bf16', not {PRECISION!r}")
     if GEMM_EVENTS is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib.qarig_gemm_f32(
+    check(fn(
         ptr(A), A.stride(0), int(a_kcontig), ptr(B), B.stride(0), int(b_kcontig),
         ptr(C), C.stride(0), M, N, K, ptr(bias),
         ptr(residual), residual.stride(0) if residual is not None else 0,
         ptr(pre), pre.stride(0) if pre is not None else 0, act,
         ptr(gradz), gradz.stride(0) if gradz is not None else 0, gact,
-        splitk, int(accumulate), ptr(a_rowsum), ptr(ws), nws, stream()), "qarig_gemm_f32")
+        splitk, int(accumulate), ptr(a_rowsum), ptr(ws), nws, stream()), fn_name)
     if GEMM_EVENTS is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()

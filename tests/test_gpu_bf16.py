@@ -1,0 +1,129 @@
+"""Opt-in reduced-precision mode (qarig.ops.PRECISION = "bf16"; BASELINE config 5 direction).
+NOT the parity mode: the fp32 tests elsewhere hold the reference bar.  Here the bf16-MFMA
+GEMM is pinned against its own definition - operands rounded to bf16 (round-to-nearest-even),
+exact products, fp32 accumulation - for which an fp64 contraction of the rounded operands
+is the reference (tolerance 3e-6 * sqrt(K/512), accumulation order only), and a training
+step is checked to track the fp32 step within the bf16 rounding budget (tolerances below)."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def bf16_mode():
+    from qarig import ops
+    old = ops.PRECISION
+    ops.PRECISION = "bf16"
+    yield ops
+    ops.PRECISION = old
+
+
+def _rounded(t):
+    return t.bfloat16().double()
+
+
+@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("M,N,K,splitk", [(128, 128, 32, 1), (256, 384, 512, 1), (128, 256, 2048, 4),
+                                          (384, 128, 4096, 8)])
+def test_bf16_gemm_is_exact_on_rounded_operands(bf16_mode, M, N, K, splitk, ak, bk):
+    ops = bf16_mode
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((M, K) if ak else (K, M), generator=g).cuda()
+    B = torch.randn((N, K) if bk else (K, N), generator=g).cuda()
+    C = ops.gemm(A, B, ak, bk, splitk=splitk)
+    Ar, Br = _rounded(A.cpu()), _rounded(B.cpu())
+    ref = (Ar if ak else Ar.t()) @ (Br.t() if bk else Br)
+    tol = 3e-6 * max(1.0, K / 512) ** 0.5
+    assert rel_err(C, ref) < tol
+    exact = (A.double().cpu() if ak else A.double().cpu().t()) @ \
+            (B.double().cpu().t() if bk else B.double().cpu())
+    e = rel_err(C, exact)
+    assert 1e-5 < e < 2e-2, e            # the rounding is really there, and is bf16-sized
+    assert torch.equal(C, ops.gemm(A, B, ak, bk, splitk=splitk))      # deterministic
+
+
+def test_bf16_gemm_epilogues_and_accumulate(bf16_mode):
+    ops = bf16_mode
+    from oracle import ref_models as rm
+    g = torch.Generator().manual_seed(0)
+    M, N, K = 256, 256, 512
+    A = torch.randn((M, K), generator=g).cuda()
+    W = (torch.randn((N, K), generator=g) * 0.1).cuda()
+    b = torch.randn((N,), generator=g).cuda()
+    R = torch.randn((M, N), generator=g).cuda()
+    Z = torch.randn((M, N), generator=g).cuda()
+    t = _rounded(A.cpu()) @ _rounded(W.cpu()).t()
+    C, pre = ops.gemm(A, W, bias=b, residual=R, want_preact=True, act=1)
+    tt = t + b.double().cpu() + R.double().cpu()
+    assert rel_err(pre, tt) < 3e-6
+    assert rel_err(C, rm.activation(tt, "silu")) < 5e-6
+    Zd = Z.double().cpu().requires_grad_(True)
+    rm.activation(Zd, "silu").sum().backward()
+    assert rel_err(ops.gemm(A, W, gradz=Z, gact=1), t * Zd.grad) < 5e-6
+    acc = R.clone()
+    ops.gemm(A, W, out=acc, accumulate=True)
+    assert rel_err(acc, t + R.double().cpu()) < 3e-6
+    acc = R.clone()
+    ops.gemm(A, W, out=acc, accumulate=True, splitk=4)
+    assert rel_err(acc, t + R.double().cpu()) < 3e-6
+    # bias gradient riding on a weight-gradient GEMM: separate fp32 column sum in this mode
+    dT = torch.randn((1024, 256), generator=g).cuda()
+    X = torch.randn((1024, 128), generator=g).cuda()
+    rs = torch.zeros(256, device="cuda")
+    dW = ops.gemm(dT, X, False, False, a_rowsum=rs, splitk=2)
+    assert rel_err(dW, _rounded(dT.cpu()).t() @ _rounded(X.cpu())) < 3e-6 * 2 ** 0.5
+    assert rel_err(rs, dT.double().cpu().sum(0)) < 2e-6
+
+
+def test_bf16_mode_falls_back_to_fp32_kernels_off_the_interior(bf16_mode):
+    ops = bf16_mode
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn((100, 96), generator=g).cuda()      # ragged M, K % 32 == 0
+    W = torch.randn((513, 96), generator=g).cuda()
+    got = ops.gemm(A, W)
+    ops.PRECISION = "f32"
+    assert torch.equal(got, ops.gemm(A, W))
+    ops.PRECISION = "bf16"
+    with pytest.raises(ValueError):
+        ops.PRECISION = "fp8"
+        ops.gemm(A, W)
+
+
+def test_bf16_train_step_tracks_fp32_step():
+    """One README-shaped (narrower/shallower) training step in both modes from the same
+    weights: loss within 2e-3 relative, flat gradient cosine similarity > 0.999."""
+    from models.Transformer import Transformer
+    from qarig import ops, pipeline
+    from qarig.optim import FlatAdam
+    res = {}
+    for mode in ("f32", "bf16"):
+        torch.manual_seed(2)
+        m = Transformer(use_encoder=False, use_pos_cond=True, num_enc_layers=None, num_dec_layers=2,
+                        num_enc_embedding=None, num_dec_embedding=1024, self_attn_heads=16,
+                        cross_attn_heads=None, transformer_in_dim=256, transformer_out_dim=513,
+                        transformer_hidden_dim=1024).cuda()
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.abs().max() == 0:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+        opt = FlatAdam(m.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        x = torch.randint(0, 1024, (8, 128), generator=g).cuda()
+        t = torch.randint(0, 513, (8, 128), generator=g).cuda()
+        pos = torch.arange(128)[None].repeat(8, 1).cuda()
+        old, ops.PRECISION = ops.PRECISION, mode
+        try:
+            opt.zero_grad()
+            loss = pipeline.train_step(m, opt, x, None, t, pos, dp=False)
+        finally:
+            ops.PRECISION = old
+        res[mode] = (float(loss), opt.flat_grad.detach().clone())
+    lf, gf = res["f32"]
+    lb, gb = res["bf16"]
+    assert abs(lb - lf) < 2e-3 * abs(lf)
+    cos = float((gf * gb).sum() / (gf.norm() * gb.norm()))
+    assert cos > 0.999, cos
+    assert not torch.equal(gf, gb)
