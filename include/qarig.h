@@ -85,6 +85,16 @@ int qarig_gemm_bf16(const float* A, int64_t lda, int a_kcontig, const float* B, 
                    const float* gradz, int64_t ldz, int gact, int splitk, int accumulate,
                    float* a_rowsum, void* workspace, size_t ws_bytes, void* stream);
 
+/* `groups` independent skinny products in one launch, C_g = act(A_g W_g^T + bias_g) with
+ * X_g = X + g * x_gs (a_gs == 0 shares the activations).  Decode steps use it for the q/k/v
+ * MLPs (models/layers.py:389-418) and for every projection of the conditioning vector
+ * (ScaleLayer/ShiftLayer, models/layers.py:100-153, 258-304) of all layers at once.
+ * Requires M <= 64, K % 256 == 0, reduction-contiguous 16-B aligned operands. */
+int qarig_gemm_grouped_skinny_f32(const float* A, int64_t lda, int64_t a_gs, const float* W,
+                                  int64_t ldw, int64_t w_gs, float* C, int64_t ldc, int64_t c_gs,
+                                  const float* bias, int64_t bias_gs, int groups, int M, int N,
+                                  int K, int act, void* stream);
+
 /* out[N] = column sums of X[M][N] in a fixed order (bias / LayerNorm-affine grads). */
 size_t qarig_colsum_workspace_bytes(int M, int N);
 int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,
@@ -159,11 +169,12 @@ int qarig_attention_bwd(const float* q, const float* k, const float* v, const fl
  * (models/layers.py:433-474 for the last query) from cached keys/values.  q,k_new,v_new,o
  * (B,H*d); cache row j of sequence n at n*batch_stride + j*H*d.  k_new/v_new non-NULL:
  * stored at row len and attended as the last key; NULL: read-only cache (cross-attention).
- * len_dev (device int, optional) overrides len for graph replay. */
+ * len_dev (device int, optional) overrides len for graph replay.  o_mul (B,H*d), optional:
+ * multiplies the output (ResidualLinearLayer's x * scale(cond), models/layers.py:293-295). */
 int qarig_attention_decode(const float* q, const float* k_new, const float* v_new, float* kcache,
                            float* vcache, int B, int H, int d, int len, const int* len_dev,
-                           int max_len, int64_t batch_stride, float sqrt_d, float* o,
-                           void* stream);
+                           int max_len, int64_t batch_stride, float sqrt_d, const float* o_mul,
+                           float* o, void* stream);
 
 /* nn.CrossEntropyLoss() mean over rows + d/dlogits --
  * train_quantized_transformer.py:337,496-502.  row_ws: M floats. */

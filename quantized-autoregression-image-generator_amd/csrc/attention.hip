@@ -275,7 +275,8 @@ template <int HD>
 __global__ __launch_bounds__(64) void attn_decode_kernel(
     const float* __restrict__ q, const float* __restrict__ k_new, const float* __restrict__ v_new,
     float* __restrict__ kc, float* __restrict__ vc, int64_t bstride, int H, int len_arg,
-    const int* __restrict__ len_dev, int max_len, float c2, float* __restrict__ o) {
+    const int* __restrict__ len_dev, int max_len, float c2, const float* __restrict__ o_mul,
+    float* __restrict__ o) {
     const int h = blockIdx.x % H, n = blockIdx.x / H;
     const int D = H * HD;
     const int lane = threadIdx.x;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(
 #pragma unroll
     for (int c = 0; c < HD; ++c) {
         const float t = wave_sum(ov[c] * sc);
-        if (lane == 0) o[row + c] = t * inv;
+        if (lane == 0) o[row + c] = o_mul ? (t * inv) * o_mul[row + c] : t * inv;
     }
 }
 }  // namespace qarig
@@ -409,11 +410,12 @@ extern "C" int qarig_attention_bwd(const float* q, const float* k, const float* 
 // rows.  Attends keys 0..len-1 from the cache plus, when k_new/v_new are non-NULL, the new
 // key, which is also stored at row len.  With k_new == NULL (cross-attention against
 // precomputed encoder K/V) the cache is read-only.  len_dev (device int, optional)
-// overrides len so the call can sit inside a captured graph.
+// overrides len so the call can sit inside a captured graph.  o_mul (B, H*d), optional: the
+// output is multiplied elementwise by it (the residual layer's scale(cond), layers.py:293-295).
 extern "C" int qarig_attention_decode(const float* q, const float* k_new, const float* v_new,
                                       float* kcache, float* vcache, int B, int H, int d, int len,
                                       const int* len_dev, int max_len, int64_t batch_stride,
-                                      float sqrt_d, float* o, void* stream) {
+                                      float sqrt_d, const float* o_mul, float* o, void* stream) {
     QARIG_CHECK_ARG(q && kcache && vcache && o, "attention_decode: null pointer");
     QARIG_CHECK_ARG((k_new == nullptr) == (v_new == nullptr),
                     "attention_decode: k_new and v_new go together");
@@ -427,7 +429,7 @@ extern "C" int qarig_attention_decode(const float* q, const float* k_new, const 
     const float c2 = 1.4426950408889634f / sqrt_d;
     QARIG_HD_DISPATCH(d, hipLaunchKernelGGL((attn_decode_kernel<HD>), dim3(B * H), dim3(64), 0,
                                             (hipStream_t)stream, q, k_new, v_new, kcache, vcache,
-                                            batch_stride, H, len, len_dev, max_len, c2, o));
+                                            batch_stride, H, len, len_dev, max_len, c2, o_mul, o));
     QARIG_CHECK_LAUNCH("attention_decode");
     return QARIG_OK;
 }

@@ -371,8 +371,15 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 template <int MT>
 __global__ __launch_bounds__(1024) void gemm_skinny_kernel(const float* __restrict__ A, int64_t lda,
                                                            const float* __restrict__ B, int64_t ldb,
-                                                           GemmEpilogue ep, int M, int N, int K) {
+                                                           GemmEpilogue ep, int M, int N, int K,
+                                                           int64_t a_gs, int64_t b_gs, int64_t c_gs,
+                                                           int64_t bias_gs) {
     __shared__ float part[16][MT * 256];
+    // grouped form: blockIdx.y selects an independent problem at fixed operand strides
+    A += blockIdx.y * a_gs;
+    B += blockIdx.y * b_gs;
+    ep.C += blockIdx.y * c_gs;
+    if (ep.bias) ep.bias += blockIdx.y * bias_gs;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 16;
     const int kslice = K >> 4;
@@ -569,6 +576,19 @@ extern "C" size_t qarig_gemm_workspace_bytes(int M, int N, int splitk) {
     return (splitk > 1 ? sk * M * N * sizeof(float) : 0) + sk * M * sizeof(float);
 }
 
+
+static void launch_skinny(const float* A, int64_t lda, const float* B, int64_t ldb, const GemmEpilogue& eps,
+                          int M, int N, int K, int64_t a_gs, int64_t b_gs, int64_t c_gs,
+                          int64_t bias_gs, int groups, hipStream_t st) {
+    dim3 sgrid((N + 15) / 16, groups), sblock(1024);
+    switch ((M + 15) / 16) {
+        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K, a_gs, b_gs, c_gs, bias_gs); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K, a_gs, b_gs, c_gs, bias_gs); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K, a_gs, b_gs, c_gs, bias_gs); break;
+        default: hipLaunchKernelGGL((gemm_skinny_kernel<4>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K, a_gs, b_gs, c_gs, bias_gs); break;
+    }
+}
+
 static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float* B,
                          int64_t ldb, int b_kcontig, float* C, int64_t ldc, int M, int N,
                          int K, const float* bias, const float* residual, int64_t ldr,
@@ -598,13 +618,7 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     if (M <= 64 && a_kcontig && b_kcontig && K % 256 == 0 && !accumulate && !a_rowsum &&
         al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0) {
         GemmEpilogue eps{C, ldc, bias, residual, ldr, preact, ldp, act, gradz, ldz, gact, nullptr};
-        dim3 sgrid((N + 15) / 16), sblock(1024);
-        switch ((M + 15) / 16) {
-            case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K); break;
-            case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K); break;
-            case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K); break;
-            default: hipLaunchKernelGGL((gemm_skinny_kernel<4>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K); break;
-        }
+        launch_skinny(A, lda, B, ldb, eps, M, N, K, 0, 0, 0, 0, 1, st);
         QARIG_CHECK_LAUNCH("gemm skinny");
         return QARIG_OK;
     }
@@ -752,4 +766,27 @@ extern "C" int qarig_gemm_bf16(const float* A, int64_t lda, int a_kcontig, const
     return gemm_dispatch(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, residual, ldr,
                          preact, ldp, act, gradz, ldz, gact, splitk, accumulate, a_rowsum, workspace,
                          ws_bytes, stream, true);
+}
+
+// `groups` independent skinny products in one launch (decode step: the q/k/v MLPs of an
+// attention layer, and every projection of the conditioning vector, models/layers.py:100-153,
+// 258-304, 389-418):  C_g = act(A_g W_g^T + bias_g),  X_g = X + g * x_gs.  a_gs == 0 shares
+// the activations.  M <= 64 rows, K % 256 == 0, reduction-contiguous 16-B aligned operands.
+extern "C" int qarig_gemm_grouped_skinny_f32(const float* A, int64_t lda, int64_t a_gs,
+                                             const float* W, int64_t ldw, int64_t w_gs, float* C,
+                                             int64_t ldc, int64_t c_gs, const float* bias,
+                                             int64_t bias_gs, int groups, int M, int N, int K,
+                                             int act, void* stream) {
+    QARIG_CHECK_ARG(A && W && C, "gemm_grouped_skinny: null operand");
+    QARIG_CHECK_ARG(groups > 0 && groups <= 65535 && M > 0 && M <= 64 && N > 0 && K > 0 && K % 256 == 0,
+                    "gemm_grouped_skinny: needs 0 < M <= 64, K %% 256 == 0 (M=%d N=%d K=%d groups=%d)",
+                    M, N, K, groups);
+    QARIG_CHECK_ARG(act >= 0 && act <= 3, "gemm_grouped_skinny: bad activation id");
+    QARIG_CHECK_ARG((((uintptr_t)A | (uintptr_t)W) & 15) == 0 && lda % 4 == 0 && ldw % 4 == 0 &&
+                        a_gs % 4 == 0 && w_gs % 4 == 0,
+                    "gemm_grouped_skinny: operands must be 16-B aligned");
+    GemmEpilogue eps{C, ldc, bias, nullptr, 0, nullptr, 0, act, nullptr, 0, 0, nullptr};
+    launch_skinny(A, lda, W, ldw, eps, M, N, K, a_gs, w_gs, c_gs, bias_gs, groups, (hipStream_t)stream);
+    QARIG_CHECK_LAUNCH("gemm_grouped_skinny");
+    return QARIG_OK;
 }

@@ -46,7 +46,8 @@ SIGNATURES = {
     "qarig_layernorm_fwd": (I, [P, I, I, F, P, P, P, P, P, P, P, P]),
     "qarig_layernorm_bwd": (I, [P, P, P, P, P, P, I, I, P, P, P]),
     "qarig_attention_fwd": (I, [P, P, P, I, I, I, I, I, I, F, P, P, P]),
-    "qarig_attention_decode": (I, [P, P, P, P, P, I, I, I, I, P, I, L, F, P, P]),
+    "qarig_attention_decode": (I, [P, P, P, P, P, I, I, I, I, P, I, L, F, P, P, P]),
+    "qarig_gemm_grouped_skinny_f32": (I, [P, L, L, P, L, L, P, L, L, P, L, I, I, I, I, I, P]),
     "qarig_attention_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P, P, P, P, P]),
     "qarig_cross_entropy_fwd": (I, [P, P, I, I, P, P, P, P, P]),
     "qarig_mse_workspace_bytes": (Z, []),

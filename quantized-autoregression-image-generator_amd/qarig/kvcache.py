@@ -10,7 +10,7 @@ appends k/v to the cache and attends with `qarig_attention_decode`; cross-attent
 values of the (constant) encoder output are computed once.  The logits equal the last row
 of `Transformer.decode` on the full window up to fp32 summation order.
 
-The step issues ~200 small launches (skinny GEMMs, norms, one attention wave per head), so
+The step issues 100-200 small launches (skinny GEMMs, norms, one attention wave per head), so
 it is launch-bound from Python; with `graph=True` the step is captured once into a HIP graph
 (torch.cuda.CUDAGraph over the library's stream launches) and replayed per token.  What
 changes between tokens - ids, pos_cond value, the window-index sinusoid row and the cache
@@ -24,7 +24,7 @@ import os
 
 import torch
 
-from models.layers import _mlp2_forward, _norm_forward
+from models.layers import _lin_params, _mlp2_forward
 from . import functional as QF
 from . import ops
 
@@ -54,6 +54,7 @@ class DecodeCache:
                                        _mlp2_forward(at.v_block, enc).contiguous()))
                 else:
                     self.cross.append(None)
+        self._stack_weights()
         self._graph = None
         if graph is None:
             graph = os.environ.get("QARIG_DECODE_GRAPH", "1") != "0"
@@ -94,6 +95,106 @@ class DecodeCache:
         self._graph.replay()
         return self._out.clone()
 
+    # -- launch-count reduction ----------------------------------------------------------------
+    # A dependent kernel costs ~5 us in graph replay however small it is, so the step time
+    # is the NUMBER of launches on the chain.  Two groups of small GEMMs are therefore
+    # issued as one grouped launch each (qarig_gemm_grouped_skinny_f32) from weights stacked
+    # once at construction: every projection of `cond` (AdaLN scale/shift and residual scale
+    # layers of ALL decoder layers: 9 per enc-dec layer) and the q/k/v MLPs of a
+    # self-attention layer (2 launches instead of 6); the residual layer's x * scale(cond)
+    # rides in the attention kernel's output.  30 -> 15 launches per enc-dec layer.
+    # (Issuing the independent work on side streams as parallel graph branches was measured
+    # slower than the serial chain: cross-branch dependencies cost more than they hide.)
+    def _stack_weights(self):
+        model, D = self.model, self.dim
+        ws, bs, self._proj_idx = [], [], []
+
+        def add(lin):
+            ws.append(lin.weight)
+            bs.append(lin.bias)
+            return len(ws) - 1
+
+        ok = True
+        for layer in model.decoder_layers:
+            idx = {}
+            blocks = [("self", layer.self_attn_block, "self_attn_norm", "self_attn_res")]
+            if layer.use_cross_attn:
+                blocks.append(("cross", layer.cross_attn_block, "cross_attn_norm", "cross_attn_res"))
+            blocks.append(("ffn", layer.feedforward_block, "feedforward_norm", "feedforward_res"))
+            for name, blk, norm_attr, res_attr in blocks:
+                norm, res = getattr(blk, norm_attr), getattr(blk, res_attr)
+                if blk.use_adaln0:
+                    idx[name + "_norm"] = (add(norm.scale_layer.scale), add(norm.shift_layer.shift))
+                if res.use_scale_layer:
+                    idx[name + "_scale"] = add(res.scale_layer.scale)
+            self._proj_idx.append(idx)
+        ok = ok and all(w.shape == (D, D) for w in ws) and D % 256 == 0 and self.batch <= 64
+        self._qkv = []
+        for layer in model.decoder_layers:
+            at = layer.self_attn_block.self_attn
+            blocks = (at.q_block, at.k_block, at.v_block)
+            w1 = [_lin_params(b[0])[0] for b in blocks]
+            ok = ok and all(w.shape == w1[0].shape for w in w1) and w1[0].shape[0] % 256 == 0 \
+                and len({b[0]._act for b in blocks}) == 1 and len({b[1]._act for b in blocks}) == 1
+            self._qkv.append(blocks)
+        self._stacked = bool(ok)
+        if not self._stacked:
+            return
+        with torch.no_grad():
+            if ws:
+                self._proj_w = torch.stack([w.detach() for w in ws]).contiguous()
+                self._proj_b = torch.stack([b.detach() for b in bs]).contiguous()
+            packed = []
+            for blocks in self._qkv:
+                packed.append((
+                    torch.stack([_lin_params(b[0])[0].detach() for b in blocks]).contiguous(),
+                    torch.stack([_lin_params(b[0])[1].detach() for b in blocks]).contiguous(),
+                    torch.stack([_lin_params(b[1])[0].detach() for b in blocks]).contiguous(),
+                    torch.stack([_lin_params(b[1])[1].detach() for b in blocks]).contiguous(),
+                    blocks[0][0]._act, blocks[0][1]._act))
+            self._qkv = packed
+
+    def _cond_projections(self, cond):
+        """Per decoder layer: dict key -> tensor(s) (B,1,D) that depend on `cond` alone."""
+        layers = self.model.decoder_layers
+        if cond is None:
+            return [{} for _ in layers]
+        B, D = self.batch, self.dim
+        if self._stacked and self._proj_idx and any(self._proj_idx):
+            allp = ops.gemm_grouped_skinny(cond.reshape(B, D), self._proj_w, self._proj_b,
+                                           shared_a=True)                       # (P, B, D)
+            pick = lambda v: (allp[v[0]], allp[v[1]]) if isinstance(v, tuple) else allp[v]
+            return [{k: pick(v) for k, v in idx.items()} for idx in self._proj_idx]
+        out = []
+        for layer in layers:
+            proj = {}
+            blocks = [("self", layer.self_attn_block, "self_attn_norm", "self_attn_res")]
+            if layer.use_cross_attn:
+                blocks.append(("cross", layer.cross_attn_block, "cross_attn_norm", "cross_attn_res"))
+            blocks.append(("ffn", layer.feedforward_block, "feedforward_norm", "feedforward_res"))
+            for name, blk, norm_attr, res_attr in blocks:
+                norm, res = getattr(blk, norm_attr), getattr(blk, res_attr)
+                if blk.use_adaln0:
+                    proj[name + "_norm"] = (norm.scale_layer(cond), norm.shift_layer(cond))
+                if res.use_scale_layer:
+                    proj[name + "_scale"] = res.scale_layer(cond)
+            out.append(proj)
+        return out
+
+    def _norm(self, norm, x, proj, key, use_adaln0):
+        if use_adaln0:
+            scale, shift = proj[key]
+            return QF.layernorm_mod(x, scale.reshape(x.shape), shift.reshape(x.shape), norm.norm.eps)
+        return QF.layernorm_affine(x, norm.weight, norm.bias, norm.eps)
+
+    def _residual(self, res, x, x_skip, proj, key, scaled=False):
+        """ResidualLinearLayer.forward with the scale projection supplied (`scaled`: the
+        producer of x already applied it)."""
+        if res.use_scale_layer and not scaled:
+            x = QF.mul(x, proj[key].reshape(x.shape))
+        w, b = _lin_params(res.linear)
+        return QF.linear_act(x, w, b, residual=res.skip_linear(x_skip), act=res._act)
+
     def _forward(self, ids, pos, pe_row, length, len_dev):
         model, B, D = self.model, self.batch, self.dim
         x = QF.embedding_pos(ids.reshape(B, 1), model.dec_embedding.weight, pe_row)
@@ -101,25 +202,38 @@ class DecodeCache:
         if model.use_pos_cond:
             cond = ops.posemb(pos.reshape(B), D).reshape(B, 1, D)
             cond = _mlp2_forward(model.pos_cond_layer, cond)
+        projections = self._cond_projections(cond)
         for li, layer in enumerate(model.decoder_layers):
+            proj = projections[li]
             sab = layer.self_attn_block
             at = sab.self_attn
-            h = _norm_forward(sab.self_attn_norm, x, cond, sab.use_adaln0)
-            q = _mlp2_forward(at.q_block, h).reshape(B, D)
-            k = _mlp2_forward(at.k_block, h).reshape(B, D)
-            v = _mlp2_forward(at.v_block, h).reshape(B, D)
+            h = self._norm(sab.self_attn_norm, x, proj, "self_norm", sab.use_adaln0)
+            if self._stacked:
+                w1, b1, w2, b2, act1, act2 = self._qkv[li]
+                hid = ops.gemm_grouped_skinny(h.reshape(B, D), w1, b1, act=act1, shared_a=True)
+                q, k, v = ops.gemm_grouped_skinny(hid, w2, b2, act=act2)
+            else:
+                q = _mlp2_forward(at.q_block, h).reshape(B, D)
+                k = _mlp2_forward(at.k_block, h).reshape(B, D)
+                v = _mlp2_forward(at.v_block, h).reshape(B, D)
+            o_mul = proj["self_scale"].reshape(B, D) if "self_scale" in proj else None
             o = ops.attention_decode(q, k, v, self.kv[li, 0], self.kv[li, 1], length, at.heads,
-                                     len_dev=len_dev)
-            x = sab.self_attn_res(x=o.reshape(B, 1, D), x_skip=x, cond=cond)
+                                     len_dev=len_dev, o_mul=o_mul)
+            x = self._residual(sab.self_attn_res, o.reshape(B, 1, D), x, proj, "self_scale", scaled=True)
             if layer.use_cross_attn:
                 cab = layer.cross_attn_block
                 at = cab.cross_attn
                 ck, cv = self.cross[li]
-                h = _norm_forward(cab.cross_attn_norm, x, cond, cab.use_adaln0)
+                h = self._norm(cab.cross_attn_norm, x, proj, "cross_norm", cab.use_adaln0)
                 q = _mlp2_forward(at.q_block, h).reshape(B, D)
-                o = ops.attention_decode(q, None, None, ck, cv, ck.shape[1], at.heads)
-                x = cab.cross_attn_res(x=o.reshape(B, 1, D), cond=cond, x_skip=x)
-            x = layer.feedforward_block(x, cond=cond)
+                o_mul = proj["cross_scale"].reshape(B, D) if "cross_scale" in proj else None
+                o = ops.attention_decode(q, None, None, ck, cv, ck.shape[1], at.heads, o_mul=o_mul)
+                x = self._residual(cab.cross_attn_res, o.reshape(B, 1, D), x, proj, "cross_scale",
+                                   scaled=True)
+            fb = layer.feedforward_block
+            h = self._norm(fb.feedforward_norm, x, proj, "ffn_norm", fb.use_adaln0)
+            h = _mlp2_forward(fb.feedforward, h)
+            x = self._residual(fb.feedforward_res, h, x, proj, "ffn_scale")
         return _mlp2_forward(model.classifier, x).reshape(B, -1)
 
     def rows(self, lo, hi):

@@ -110,6 +110,29 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
     return (C, pre) if want_preact else C
 
 
+def gemm_grouped_skinny(A, W, bias=None, act=0, shared_a=False):
+    """out[g] = act(A[g] @ W[g].T + bias[g]).  A: (G, M, K) or (M, K) with shared_a;
+    W: (G, N, K); bias: (G, N) or None.  M <= 64, K % 256 == 0.  Returns (G, M, N)."""
+    require_cuda(A, W, bias)
+    G, N, K = W.shape
+    assert W.is_contiguous() and A.is_contiguous() and A.dtype == W.dtype == torch.float32
+    if shared_a:
+        M, Ka = A.shape
+        a_gs = 0
+    else:
+        Ga, M, Ka = A.shape
+        assert Ga == G
+        a_gs = M * K
+    assert Ka == K
+    if bias is not None:
+        assert bias.shape == (G, N) and bias.is_contiguous()
+    C = torch.empty((G, M, N), dtype=torch.float32, device=A.device)
+    check(_lib.load().qarig_gemm_grouped_skinny_f32(
+        ptr(A), K, a_gs, ptr(W), K, N * K, ptr(C), N, M * N, ptr(bias), N, G, M, N, K, act,
+        stream()), "qarig_gemm_grouped_skinny_f32")
+    return C
+
+
 def colsum(X, out=None, accumulate=False):
     """(N,) column sums of X (M,N) in a fixed order (optionally added into `out`)."""
     require_cuda(X)
@@ -331,7 +354,7 @@ def attention_fwd(q, k, v, heads, causal):
     return o, lse
 
 
-def attention_decode(q, k_new, v_new, kcache, vcache, length, heads, len_dev=None):
+def attention_decode(q, k_new, v_new, kcache, vcache, length, heads, len_dev=None, o_mul=None):
     """One decode step: q (B,D) against cache rows [0,length) (+ the appended new row).
     kcache/vcache: (B, max_len, D) views with unit row stride D (batch stride free)."""
     B, D = q.shape
@@ -339,11 +362,13 @@ def attention_decode(q, k_new, v_new, kcache, vcache, length, heads, len_dev=Non
     assert kcache.shape == vcache.shape and kcache.shape[0] == B and kcache.shape[2] == D
     assert kcache.stride(2) == 1 and kcache.stride(1) == D and vcache.stride() == kcache.stride()
     o = torch.empty_like(q)
+    if o_mul is not None:
+        assert o_mul.shape == q.shape and o_mul.is_contiguous() and q.is_contiguous()
     check(_lib.load().qarig_attention_decode(
         ptr(q), ptr(k_new) if k_new is not None else None,
         ptr(v_new) if v_new is not None else None, ptr(kcache), ptr(vcache), B, heads, d,
         int(length), ptr(len_dev) if len_dev is not None else None, kcache.shape[1],
-        kcache.stride(0), float(d ** 0.5), ptr(o), stream()), "qarig_attention_decode")
+        kcache.stride(0), float(d ** 0.5), ptr(o_mul), ptr(o), stream()), "qarig_attention_decode")
     return o
 
 

@@ -50,6 +50,30 @@ def test_attention_decode_matches_full_attention():
         got3 = ops.attention_decode(q[::2, 0].contiguous(), None, None, kc[::2], vc[::2], 0, heads,
                                     len_dev=ln)
         assert rel_err(got3, want[::2]) < 1e-5
+        mul = torch.randn(B, D, device="cuda")
+        got4 = ops.attention_decode(q[:, 0].contiguous(), None, None, kc, vc, L + 1, heads, o_mul=mul)
+        assert rel_err(got4, want * mul) < 1e-5
+
+
+def test_grouped_skinny_gemm():
+    from qarig import ops
+    g = torch.Generator().manual_seed(0)
+    G, M, N, K = 5, 12, 200, 512
+    A = torch.randn((G, M, K), generator=g).cuda()
+    W = (torch.randn((G, N, K), generator=g) * 0.1).cuda()
+    b = torch.randn((G, N), generator=g).cuda()
+    got = ops.gemm_grouped_skinny(A, W, b, act=1)
+    want = torch.nn.functional.silu(torch.einsum("gmk,gnk->gmn", A.double().cpu(), W.double().cpu())
+                                    + b.double().cpu()[:, None])
+    assert got.shape == (G, M, N) and rel_err(got, want) < 5e-6
+    for gi in range(G):      # same kernel, same order as the single-problem skinny path
+        assert torch.equal(got[gi], ops.gemm(A[gi], W[gi], bias=b[gi], act=1))
+    shared = ops.gemm_grouped_skinny(A[0], W, None, shared_a=True)
+    assert rel_err(shared, torch.einsum("mk,gnk->gmn", A[0].double().cpu(), W.double().cpu())) < 5e-6
+    with pytest.raises(RuntimeError):
+        ops.gemm_grouped_skinny(torch.randn(2, 65, 256).cuda(), torch.randn(2, 16, 256).cuda())
+    with pytest.raises(RuntimeError):
+        ops.gemm_grouped_skinny(torch.randn(2, 8, 96).cuda(), torch.randn(2, 16, 96).cuda())
 
 
 def test_attention_decode_rejects_bad_length():
@@ -62,11 +86,14 @@ def test_attention_decode_rejects_bad_length():
         ops.attention_decode(q, None, None, kc, kc.clone(), 0, 4)   # nothing to attend
 
 
+@pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("use_encoder", [False, True])
-def test_decode_cache_step_matches_full_window(use_encoder, graph):
+def test_decode_cache_step_matches_full_window(use_encoder, graph, wide):
+    """wide: D = 256 / hidden = 512, the shapes on which the step stacks the cond projections
+    and the q/k/v MLPs into grouped launches; narrow: the per-module launches."""
     from qarig.kvcache import DecodeCache
-    m = _model(use_encoder)
+    m = _model(use_encoder, heads=32, dim=256, hidden=512) if wide else _model(use_encoder)
     B, S = 3, 12
     g = torch.Generator().manual_seed(1)
     ids = torch.randint(0, 41, (B, S), generator=g).cuda()
@@ -74,6 +101,7 @@ def test_decode_cache_step_matches_full_window(use_encoder, graph):
     with torch.no_grad():
         enc = m.encode(torch.randint(0, 41, (B, 7), generator=g).cuda()) if use_encoder else None
         cache = DecodeCache(m, enc, B, S, graph=graph)
+        assert cache._stacked == wide
         for t in range(S):
             got = cache.step(ids[:, t], pos[:, t], t)
             want = m.decode(ids[:, :t + 1].contiguous(), enc, pos[:, :t + 1].contiguous())[:, -1]
@@ -82,14 +110,15 @@ def test_decode_cache_step_matches_full_window(use_encoder, graph):
             cache.step(ids[:, 0], pos[:, 0], S)
 
 
-@pytest.mark.parametrize("use_encoder,num_beam,bw,batch_beams", [
-    (False, 1, 1, False), (False, 3, 4, False), (True, 2, 4, False), (True, 3, 2, True),
-    (False, 2, 4, True)])
-def test_cached_generation_matches_full_window_loop(use_encoder, num_beam, bw, batch_beams):
+@pytest.mark.parametrize("use_encoder,num_beam,bw,batch_beams,wide", [
+    (False, 1, 1, False, False), (False, 3, 4, False, False), (True, 2, 4, False, False),
+    (True, 3, 2, True, False), (False, 2, 4, True, False), (True, 2, 4, False, True),
+    (True, 3, 2, True, True)])
+def test_cached_generation_matches_full_window_loop(use_encoder, num_beam, bw, batch_beams, wide):
     """Same seed, same draw order: the cached loop (then its windowed continuation once the
     window slides) must emit the tokens of the reference-style full-window loop."""
     from qarig import sampling
-    m = _model(use_encoder)
+    m = _model(use_encoder, heads=32, dim=256, hidden=512) if wide else _model(use_encoder)
     with torch.no_grad():
         m.classifier[1].linear_layer[0].bias[40] -= 20.0     # <end> out of the way
     N, total, sw = 3, 24, 16
