@@ -90,18 +90,85 @@ struct SrcIm2col {
     }
 };
 
+// Row-vector form of the gather for launches whose input walk is unit-stride along x
+// (Conv2d stride 1 and every ConvTranspose parity class) on output rows that are a multiple
+// of 4 wide: a thread owns ONE tap k and FOUR consecutive pixels, which are four consecutive
+// input floats -- one (4-B aligned) global_load_dwordx4 and one ds_write_b128 where the
+// per-pixel form issues four of each, and a quarter of the index arithmetic.  Only the first
+// and last group of an output row can touch the padding and take the per-element path.
+struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
+
+struct SrcIm2colRow {
+    ConvGeom g;
+    const float* xb;
+    int iy0, ix0;
+    uint32_t m_ntx, m_nty;   // ceil(2^32 / d): k / d == umulhi(k, m) for the k < 2^16 met here
+    bool valid;
+
+    __device__ __forceinline__ void init(int x0, int tid) {
+        const int p = x0 + (tid & 31) * 4;          // P % 4 == 0: a group is valid as a whole
+        valid = p < g.P;
+        const int per = g.Ho * g.Wo;
+        const int n = valid ? p / per : 0;
+        const int rem = valid ? p - n * per : 0;
+        const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+        xb = g.x + (int64_t)n * g.C * g.H * g.W;
+        iy0 = oy + g.oy0;
+        ix0 = ox + g.ox0;
+        m_ntx = g.ntx > 1 ? 0xFFFFFFFFu / (uint32_t)g.ntx + 1u : 0u;
+        m_nty = g.nty > 1 ? 0xFFFFFFFFu / (uint32_t)g.nty + 1u : 0u;
+    }
+    __device__ __forceinline__ bool interior(int, int, int) const { return false; }
+    __device__ __forceinline__ void load_fast(float (&r)[STAGE], int x0, int k0, int tid) const {
+        load(r, x0, k0, tid);
+    }
+    __device__ __forceinline__ void load(float (&r)[STAGE], int, int k0, int tid) const {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + (tid >> 5) + 8 * h;
+            const int t = g.ntx > 1 ? (int)__umulhi((uint32_t)k, m_ntx) : k;
+            const int tx = k - t * g.ntx;
+            const int ci = g.nty > 1 ? (int)__umulhi((uint32_t)t, m_nty) : t;
+            const int ty = t - ci * g.nty;
+            const int iy = iy0 + g.oys * ty, ix = ix0 + g.oxs * tx;
+            const bool rowok = valid && k < g.K && (unsigned)iy < (unsigned)g.H;
+            const int off = (ci * g.H + iy) * g.W + ix;
+            if (rowok && ix >= 0 && ix + 3 < g.W) {
+                const F4u v = *reinterpret_cast<const F4u*>(xb + off);
+                r[4 * h] = v.x; r[4 * h + 1] = v.y; r[4 * h + 2] = v.z; r[4 * h + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = rowok && (unsigned)(ix + j) < (unsigned)g.W;
+                    r[4 * h + j] = ok ? xb[ok ? off + j : 0] : 0.0f;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(const float (&r)[STAGE], float* T, int tid) const {
+        const int x = (tid & 31) * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            *reinterpret_cast<float4*>(T + ((tid >> 5) + 8 * h) * LDT + x) =
+                make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3]);
+    }
+};
+
+// FAST: Cout % 128 == 0, K % 16 == 0, P % 128 == 0 and vector-loadable weights: the
+// branch-free software-pipelined main loop of the GEMM (the gather keeps its own guards).
+template <class SB, bool FAST>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_mma_kernel(SrcKContig sa, ConvGeom g,
                                                                ConvOut o, int tiles_p) {
     __shared__ __attribute__((aligned(16))) float lds[GEMM_LDS_FLOATS];
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tc = tile / tiles_p, tp = tile - tc * tiles_p;   // pixel tile fastest
     const int c0 = tc * BM, p0 = tp * BN;
-    SrcIm2col sb;
+    SB sb;
     sb.g = g;
     sb.init(p0, threadIdx.x);
     Acc acc;
     acc_zero(acc);
-    contract_loop<false>(acc, sa, sb, c0, p0, 0, g.K, lds);
+    contract_loop<FAST>(acc, sa, sb, c0, p0, 0, g.K, lds);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, cl = lane & 31;
@@ -364,8 +431,17 @@ static int launch_conv(const float* wmat, const ConvGeom& g, const ConvOut& o, h
         SrcKContig sa{wmat, (int64_t)g.K, o.Cout, g.K, 1.0f,
                       (((uintptr_t)wmat & 15) == 0) && g.K % 4 == 0};
         const int tiles_c = (o.Cout + BM - 1) / BM, tiles_p = (g.P + BN - 1) / BN;
-        hipLaunchKernelGGL(conv_mma_kernel, dim3(tiles_c * tiles_p), dim3(NTHREADS), 0, st, sa, g, o,
-                           tiles_p);
+        const bool rowvec = g.stride == 1 && g.Wo % 4 == 0 && g.K < 65536;
+        const bool fast = sa.vec4 && o.Cout % BM == 0 && g.K % BK == 0 && g.P % BN == 0;
+        const dim3 grid(tiles_c * tiles_p), block(NTHREADS);
+        if (rowvec && fast)
+            hipLaunchKernelGGL((conv_mma_kernel<SrcIm2colRow, true>), grid, block, 0, st, sa, g, o, tiles_p);
+        else if (rowvec)
+            hipLaunchKernelGGL((conv_mma_kernel<SrcIm2colRow, false>), grid, block, 0, st, sa, g, o, tiles_p);
+        else if (fast)
+            hipLaunchKernelGGL((conv_mma_kernel<SrcIm2col, true>), grid, block, 0, st, sa, g, o, tiles_p);
+        else
+            hipLaunchKernelGGL((conv_mma_kernel<SrcIm2col, false>), grid, block, 0, st, sa, g, o, tiles_p);
     }
     QARIG_CHECK_LAUNCH("conv");
     return QARIG_OK;
