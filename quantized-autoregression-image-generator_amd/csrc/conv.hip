@@ -236,6 +236,62 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvGeom g, const floa
     }
 }
 
+// Register-blocked form of the direct kernel for the 3x3 / stride 1 / pad 1 output layers
+// (256->3 decoder pixels, 512->4 latents): a lane owns FOUR consecutive pixels of a row, so
+// one aligned 16-B load plus the two neighbours feeds 4 pixels x 3 taps x COUT FMAs (the
+// per-pixel form issues one 4-B load per COUT FMAs and is load-issue/latency bound at
+// ~3 % of the VALU rate).  The fma order per output (ci, ty, tx ascending) is unchanged.
+template <int COUT>
+__global__ __launch_bounds__(64) void conv_direct4_kernel(ConvGeom g, const float* __restrict__ w,
+                                                          ConvOut o) {
+    const int p = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (p >= g.P) return;
+    const int per = g.Ho * g.Wo;
+    const int n = p / per, rem = p - n * per;
+    const int oy = rem / g.Wo, ox = rem - oy * g.Wo;      // ox % 4 == 0, W == Wo
+    const float* xb = g.x + (int64_t)n * g.C * g.H * g.W;
+    float acc[COUT][4];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = 0.0f;
+    const bool left = ox > 0, right = ox + 4 < g.W;
+    for (int ci = 0; ci < g.C; ++ci) {
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const int iy = oy - 1 + ty;
+            float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)g.H) {
+                const float* row = xb + ((int64_t)ci * g.H + iy) * g.W + ox;
+                const float4 m = *reinterpret_cast<const float4*>(row);
+                v[1] = m.x; v[2] = m.y; v[3] = m.z; v[4] = m.w;
+                if (left) v[0] = row[-1];
+                if (right) v[5] = row[4];
+            }
+            const float* wk = w + (int64_t)ci * 9 + ty * 3;     // + co*K + tx
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) {
+                    const float wv = wk[(int64_t)c * g.K + tx];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[c][j] = fmaf(wv, v[j + tx], acc[c][j]);
+                }
+        }
+    }
+    const int64_t plane = (int64_t)o.HoP * o.WoP;
+    const int64_t pix = (int64_t)oy * o.WoP + ox;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+        const float b = o.bias ? o.bias[c] : 0.0f;
+        const float4 t = make_float4(acc[c][0] + b, acc[c][1] + b, acc[c][2] + b, acc[c][3] + b);
+        const int64_t idx = ((int64_t)n * o.Cout + c) * plane + pix;
+        if (o.preact) *reinterpret_cast<float4*>(o.preact + idx) = t;
+        *reinterpret_cast<float4*>(o.y + idx) =
+            make_float4(act_fwd(t.x, o.act), act_fwd(t.y, o.act), act_fwd(t.z, o.act), act_fwd(t.w, o.act));
+    }
+}
+
 // ConvTranspose2d weight (Cin, Cout, 4, 4) -> per output-parity class GEMM weights
 // packed[cls][co][(ci, th, tw)], cls = py*2+px; taps of class parity p: kh = 1-p + 2*th
 // (p=0: kh 1,3 ; p=1: kh 0,2).
@@ -420,7 +476,18 @@ extern "C" int qarig_slab_reduce_f32(const float* slabs, float* out, int64_t ldc
                                      int nslab, int accumulate, void* stream);
 
 static int launch_conv(const float* wmat, const ConvGeom& g, const ConvOut& o, hipStream_t st) {
-    if (o.Cout <= 8) {
+    const bool plain3x3 = g.stride == 1 && g.ntx == 3 && g.nty == 3 && g.oy0 == -1 && g.ox0 == -1 &&
+                          g.oys == 1 && g.oxs == 1 && g.Wo == g.W && g.Ho == g.H && g.W % 4 == 0 &&
+                          o.os == 1 && o.py == 0 && o.px == 0 && o.WoP == g.Wo && o.HoP == g.Ho &&
+                          (((uintptr_t)g.x | (uintptr_t)o.y | (uintptr_t)o.preact) & 15) == 0;
+    if (o.Cout <= 4 && plain3x3) {
+        dim3 grid((g.P / 4 + 63) / 64), block(64);
+        switch (o.Cout) {
+#define QARIG_DC4(n) case n: hipLaunchKernelGGL((conv_direct4_kernel<n>), grid, block, 0, st, g, wmat, o); break;
+            QARIG_DC4(1) QARIG_DC4(2) QARIG_DC4(3) QARIG_DC4(4)
+#undef QARIG_DC4
+        }
+    } else if (o.Cout <= 8) {
         dim3 grid((g.P + 255) / 256), block(256);
         switch (o.Cout) {
 #define QARIG_DC(n) case n: hipLaunchKernelGGL((conv_direct_kernel<n>), grid, block, 0, st, g, wmat, o); break;
