@@ -241,7 +241,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvGeom g, const floa
 // one aligned 16-B load plus the two neighbours feeds 4 pixels x 3 taps x COUT FMAs (the
 // per-pixel form issues one 4-B load per COUT FMAs and is load-issue/latency bound at
 // ~3 % of the VALU rate).  The fma order per output (ci, ty, tx ascending) is unchanged.
-template <int COUT>
+// FLIP: taps walk the input backwards (offset 1 - t instead of t - 1): the stride-1 data
+// gradient of the same layers, whose packed weights are already in that tap order.
+template <int COUT, bool FLIP>
 __global__ __launch_bounds__(64) void conv_direct4_kernel(ConvGeom g, const float* __restrict__ w,
                                                           ConvOut o) {
     const int p = (blockIdx.x * 64 + threadIdx.x) * 4;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(64) void conv_direct4_kernel(ConvGeom g, const floa
     for (int ci = 0; ci < g.C; ++ci) {
 #pragma unroll
         for (int ty = 0; ty < 3; ++ty) {
-            const int iy = oy - 1 + ty;
+            const int iy = FLIP ? oy + 1 - ty : oy - 1 + ty;
             float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if ((unsigned)iy < (unsigned)g.H) {
                 const float* row = xb + ((int64_t)ci * g.H + iy) * g.W + ox;
@@ -275,7 +277,8 @@ __global__ __launch_bounds__(64) void conv_direct4_kernel(ConvGeom g, const floa
                 for (int c = 0; c < COUT; ++c) {
                     const float wv = wk[(int64_t)c * g.K + tx];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[c][j] = fmaf(wv, v[j + tx], acc[c][j]);
+                    for (int j = 0; j < 4; ++j)
+                        acc[c][j] = fmaf(wv, v[j + (FLIP ? 2 - tx : tx)], acc[c][j]);
                 }
         }
     }
@@ -399,6 +402,105 @@ struct SrcIm2colPix {
     }
 };
 
+// Row forms of the two loaders for gradient rows that are a multiple of 8 wide: the 8
+// pixels a thread stages per k-tile are 8 consecutive floats of ONE row of one image, so the
+// pixel -> (image, row, column) decomposition happens once per tile (two multiply-high
+// divisions) instead of twice per element, and the loads are two 16-B accesses.
+// v / d for 0 <= v < 2^31, d > 0 without the ~40-instruction integer divide: float quotient
+// (relative error 2^-23, i.e. off by at most one for quotients below 2^22) plus one
+// correction step each way.
+__device__ __forceinline__ int div_fix(int v, int d, float inv) {
+    int q = (int)((float)v * inv);
+    q -= (int64_t)q * d > v;
+    q += (int64_t)(q + 1) * d <= v;
+    return q;
+}
+
+struct SrcGradPixRow {
+    WgradGeom g;
+    float inv_per;
+    __device__ __forceinline__ void init() { inv_per = 1.0f / (float)(g.Gh * g.Gw); }
+    __device__ __forceinline__ bool interior(int, int, int) const { return false; }
+    __device__ __forceinline__ void load_fast(float (&r)[STAGE], int x0, int k0, int tid) const {
+        load(r, x0, k0, tid);
+    }
+    __device__ __forceinline__ void load(float (&r)[STAGE], int x0, int k0, int tid) const {
+        const int cg = x0 + (tid >> 1);
+        const int p0 = k0 + (tid & 1) * 8;
+        const int per = g.Gh * g.Gw;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (cg < g.Cg && p0 < g.P) {
+            const int n = div_fix(p0, per, inv_per), sp = p0 - n * per;
+            const float* q = g.G + ((int64_t)n * g.Cg + cg) * per + sp;
+            a = *reinterpret_cast<const float4*>(q);
+            b = *reinterpret_cast<const float4*>(q + 4);
+        }
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+        r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+    }
+    __device__ __forceinline__ void store(const float (&r)[STAGE], float* T, int tid) const {
+        const int x = tid >> 1, k = (tid & 1) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) T[(k + q) * LDT + x] = r[q];
+    }
+};
+
+struct SrcIm2colPixRow {
+    WgradGeom g;
+    int cx, kh, kw;
+    float inv_per, inv_gw;
+    bool valid;
+    __device__ __forceinline__ void init(int x0, int tid) {
+        const int kidx = x0 + (tid >> 1);
+        valid = kidx < g.K2;
+        const int kk = g.k * g.k;
+        cx = valid ? kidx / kk : 0;
+        const int rem = valid ? kidx - cx * kk : 0;
+        kh = rem / g.k;
+        kw = rem - kh * g.k;
+        inv_per = 1.0f / (float)(g.Gh * g.Gw);
+        inv_gw = 1.0f / (float)g.Gw;
+    }
+    __device__ __forceinline__ bool interior(int, int, int) const { return false; }
+    __device__ __forceinline__ void load_fast(float (&r)[STAGE], int x0, int k0, int tid) const {
+        load(r, x0, k0, tid);
+    }
+    __device__ __forceinline__ void load(float (&r)[STAGE], int, int k0, int tid) const {
+        const int p0 = k0 + (tid & 1) * 8;
+        const int per = g.Gh * g.Gw;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = 0.0f;
+        if (!valid || p0 >= g.P) return;
+        const int n = div_fix(p0, per, inv_per), sp = p0 - n * per;
+        const int gy = div_fix(sp, g.Gw, inv_gw), gx = sp - gy * g.Gw;
+        const int iy = gy * g.stride + kh - g.pad;
+        if ((unsigned)iy >= (unsigned)g.H) return;
+        const int ix0 = gx * g.stride + kw - g.pad;
+        const float* row = g.X + (((int64_t)n * g.Cx + cx) * g.H + iy) * g.W;
+        if (g.stride == 1 && ix0 >= 0 && ix0 + 7 < g.W) {
+            const F4u a = *reinterpret_cast<const F4u*>(row + ix0);
+            const F4u b = *reinterpret_cast<const F4u*>(row + ix0 + 4);
+            r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+            r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int ix = ix0 + q * g.stride;
+                const bool ok = (unsigned)ix < (unsigned)g.W;
+                r[q] = ok ? row[ok ? ix : 0] : 0.0f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(const float (&r)[STAGE], float* T, int tid) const {
+        const int x = tid >> 1, k = (tid & 1) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) T[(k + q) * LDT + x] = r[q];
+    }
+};
+
+// ROW: gradient rows a multiple of 8 wide (row loaders).  FAST: additionally Cg, K2 multiples
+// of 128 and every pixel split a multiple of 16: the branch-free pipelined main loop.
+template <bool ROW, bool FAST>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(WgradGeom g, int tiles_n,
                                                                  int per_split,
                                                                  float* __restrict__ slabs) {
@@ -407,13 +509,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(WgradGeom g, in
     const int m0 = tm * BM, n0 = tn * BN;
     const int k_begin = blockIdx.z * per_split;
     const int k_end = min(g.P, k_begin + per_split);
-    SrcGradPix sa{g};
-    SrcIm2colPix sb;
-    sb.g = g;
-    sb.init(n0, threadIdx.x);
     Acc acc;
     acc_zero(acc);
-    contract_loop<false>(acc, sa, sb, m0, n0, k_begin, k_end, lds);
+    if (ROW) {
+        SrcGradPixRow sa{g, 0.0f};
+        sa.init();
+        SrcIm2colPixRow sb;
+        sb.g = g;
+        sb.init(n0, threadIdx.x);
+        contract_loop<FAST>(acc, sa, sb, m0, n0, k_begin, k_end, lds);
+    } else {
+        SrcGradPix sa{g};
+        SrcIm2colPix sb;
+        sb.g = g;
+        sb.init(n0, threadIdx.x);
+        contract_loop<false>(acc, sa, sb, m0, n0, k_begin, k_end, lds);
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, cl = lane & 31;
     float* out = slabs + (int64_t)blockIdx.z * g.Cg * g.K2;
@@ -476,14 +587,18 @@ extern "C" int qarig_slab_reduce_f32(const float* slabs, float* out, int64_t ldc
                                      int nslab, int accumulate, void* stream);
 
 static int launch_conv(const float* wmat, const ConvGeom& g, const ConvOut& o, hipStream_t st) {
-    const bool plain3x3 = g.stride == 1 && g.ntx == 3 && g.nty == 3 && g.oy0 == -1 && g.ox0 == -1 &&
-                          g.oys == 1 && g.oxs == 1 && g.Wo == g.W && g.Ho == g.H && g.W % 4 == 0 &&
+    const bool fwd_taps = g.oy0 == -1 && g.ox0 == -1 && g.oys == 1 && g.oxs == 1;
+    const bool flip_taps = g.oy0 == 1 && g.ox0 == 1 && g.oys == -1 && g.oxs == -1;
+    const bool plain3x3 = g.stride == 1 && g.ntx == 3 && g.nty == 3 && (fwd_taps || flip_taps) &&
+                          g.Wo == g.W && g.Ho == g.H && g.W % 4 == 0 &&
                           o.os == 1 && o.py == 0 && o.px == 0 && o.WoP == g.Wo && o.HoP == g.Ho &&
                           (((uintptr_t)g.x | (uintptr_t)o.y | (uintptr_t)o.preact) & 15) == 0;
     if (o.Cout <= 4 && plain3x3) {
         dim3 grid((g.P / 4 + 63) / 64), block(64);
-        switch (o.Cout) {
-#define QARIG_DC4(n) case n: hipLaunchKernelGGL((conv_direct4_kernel<n>), grid, block, 0, st, g, wmat, o); break;
+        switch (o.Cout * 2 + (flip_taps ? 1 : 0)) {
+#define QARIG_DC4(n) \
+    case 2 * n: hipLaunchKernelGGL((conv_direct4_kernel<n, false>), grid, block, 0, st, g, wmat, o); break; \
+    case 2 * n + 1: hipLaunchKernelGGL((conv_direct4_kernel<n, true>), grid, block, 0, st, g, wmat, o); break;
             QARIG_DC4(1) QARIG_DC4(2) QARIG_DC4(3) QARIG_DC4(4)
 #undef QARIG_DC4
         }
@@ -623,6 +738,89 @@ extern "C" int qarig_conv_transpose2d_bwd_data(const float* dT, int N, int Cout,
     return launch_conv(w, g, o, (hipStream_t)stream);
 }
 
+namespace qarig {
+
+// Weight gradient of the 3x3 / stride 1 / pad 1 layers with very few gradient channels
+// (CG <= 4: the 256->3 pixel layer and the 512->4 latent layer).  On the MFMA kernel such a
+// layer pays for a 128-row tile to fill 3 rows (3.5 ms at batch 16); here a block owns one
+// input channel cx and a slice of the pixels, every lane walks groups of four consecutive
+// pixels (three 6-float input rows, CG gradient float4s -> CG*9*4 FMAs) and the CG*9 sums
+// are reduced across the block in a fixed order.  slabs[z][cg][cx*9 + kh*3 + kw].
+template <int CG>
+__global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(WgradGeom g, int groups_per_split,
+                                                                float* __restrict__ slabs) {
+    __shared__ float red[4][CG * 9];
+    const int cx = blockIdx.x;
+    const int per = g.Gh * g.Gw, gpr = g.Gw >> 2;          // groups per row
+    const int total = g.P >> 2;
+    const int gbeg = blockIdx.y * groups_per_split;
+    const int gend = min(total, gbeg + groups_per_split);
+    float acc[CG][9];
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.0f;
+    for (int grp = gbeg + threadIdx.x; grp < gend; grp += 256) {
+        const int rowid = grp / gpr;                        // n * Gh + y
+        const int x = (grp - rowid * gpr) * 4;
+        const int n = rowid / g.Gh, y = rowid - n * g.Gh;
+        float4 gv[CG];
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+            gv[c] = *reinterpret_cast<const float4*>(g.G + ((int64_t)n * g.Cg + c) * per + y * g.Gw + x);
+        const float* xp = g.X + ((int64_t)n * g.Cx + cx) * per;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = y + kh - 1;
+            float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)g.H) {
+                const float* row = xp + iy * g.W + x;
+                const float4 m = *reinterpret_cast<const float4*>(row);
+                v[1] = m.x; v[2] = m.y; v[3] = m.z; v[4] = m.w;
+                if (x > 0) v[0] = row[-1];
+                if (x + 4 < g.W) v[5] = row[4];
+            }
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int c = 0; c < CG; ++c) {
+                    float t = acc[c][kh * 3 + kw];
+                    t = fmaf(gv[c].x, v[kw], t);
+                    t = fmaf(gv[c].y, v[kw + 1], t);
+                    t = fmaf(gv[c].z, v[kw + 2], t);
+                    t = fmaf(gv[c].w, v[kw + 3], t);
+                    acc[c][kh * 3 + kw] = t;
+                }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float sum = wave_sum(acc[c][t]);
+            if (lane == 0) red[wave][c * 9 + t] = sum;
+        }
+    __syncthreads();
+    if (threadIdx.x < CG * 9) {
+        const int c = threadIdx.x / 9, t = threadIdx.x - c * 9;
+        const float sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        slabs[((int64_t)blockIdx.y * g.Cg + c) * g.K2 + cx * 9 + t] = sum;
+    }
+}
+
+}  // namespace qarig
+
+static bool wgrad_direct_ok(int Cg, int Gh, int Gw, int H, int W, int k, int stride, int pad) {
+    return Cg <= 4 && k == 3 && stride == 1 && pad == 1 && Gh == H && Gw == W && W % 4 == 0;
+}
+static int wgrad_direct_splits(int Cx, int P) {
+    int s = (1024 + Cx - 1) / Cx;                      // ~4 blocks per CU
+    const int maxs = (P / 4 + 1023) / 1024;            // at least 4 groups per thread
+    if (s > maxs) s = maxs;
+    return s < 1 ? 1 : (s > 64 ? 64 : s);
+}
+
 static int wgrad_splits(int Cg, int K2, int P) {
     const int tiles = ((Cg + BM - 1) / BM) * ((K2 + BN - 1) / BN);
     int s = (768 + tiles - 1) / tiles;
@@ -633,7 +831,8 @@ static int wgrad_splits(int Cg, int K2, int P) {
 }
 
 extern "C" size_t qarig_conv_wgrad_workspace_bytes(int Cg, int K2, int P) {
-    return (size_t)wgrad_splits(Cg, K2, P) * Cg * K2 * sizeof(float);
+    const int s = wgrad_splits(Cg, K2, P);
+    return (size_t)(Cg <= 4 && s < 64 ? 64 : s) * Cg * K2 * sizeof(float);   // direct path: <= 64 slabs
 }
 
 // Weight gradient of Conv2d (G = dT, X = input -> dw (Cout,Cin,k,k)) and of
@@ -650,13 +849,34 @@ extern "C" int qarig_conv_wgrad(const float* G, int N, int Cg, int Gh, int Gw, c
         qarig_set_error("conv_wgrad: workspace too small");
         return QARIG_ERR_WORKSPACE;
     }
+    hipStream_t st0 = (hipStream_t)stream;
+    if (wgrad_direct_ok(Cg, Gh, Gw, H, W, k, stride, pad) && ((((uintptr_t)G | (uintptr_t)X)) & 15) == 0) {
+        const int ns = wgrad_direct_splits(Cx, g.P);
+        const int gps = (g.P / 4 + ns - 1) / ns;
+        const dim3 dgrid(Cx, ns), dblock(256);
+        switch (Cg) {
+            case 1: hipLaunchKernelGGL((conv_wgrad_direct_kernel<1>), dgrid, dblock, 0, st0, g, gps, (float*)workspace); break;
+            case 2: hipLaunchKernelGGL((conv_wgrad_direct_kernel<2>), dgrid, dblock, 0, st0, g, gps, (float*)workspace); break;
+            case 3: hipLaunchKernelGGL((conv_wgrad_direct_kernel<3>), dgrid, dblock, 0, st0, g, gps, (float*)workspace); break;
+            default: hipLaunchKernelGGL((conv_wgrad_direct_kernel<4>), dgrid, dblock, 0, st0, g, gps, (float*)workspace); break;
+        }
+        QARIG_CHECK_LAUNCH("conv_wgrad direct");
+        return qarig_slab_reduce_f32((const float*)workspace, dw, g.K2, Cg, g.K2, ns, 0, stream);
+    }
     const int splits = wgrad_splits(Cg, g.K2, g.P);
     const int per = ((g.P + splits - 1) / splits + BK - 1) / BK * BK;
     const int nsp = (g.P + per - 1) / per;
     const int tiles_m = (Cg + BM - 1) / BM, tiles_n = (g.K2 + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles_m * tiles_n, 1, nsp), dim3(NTHREADS), 0, st, g,
-                       tiles_n, per, (float*)workspace);
+    const bool row = Gw % 8 == 0 && (((uintptr_t)G) & 15) == 0;
+    const bool fast = row && Cg % BM == 0 && g.K2 % BN == 0 && per % BK == 0 && g.P % BK == 0;
+    const dim3 grid(tiles_m * tiles_n, 1, nsp), block(NTHREADS);
+    if (fast)
+        hipLaunchKernelGGL((conv_wgrad_kernel<true, true>), grid, block, 0, st, g, tiles_n, per, (float*)workspace);
+    else if (row)
+        hipLaunchKernelGGL((conv_wgrad_kernel<true, false>), grid, block, 0, st, g, tiles_n, per, (float*)workspace);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<false, false>), grid, block, 0, st, g, tiles_n, per, (float*)workspace);
     QARIG_CHECK_LAUNCH("conv_wgrad");
     return qarig_slab_reduce_f32((const float*)workspace, dw, g.K2, Cg, g.K2, nsp, 0, stream);
 }

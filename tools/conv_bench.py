@@ -56,5 +56,29 @@ def main():
         print(f"convT 512->256 @32: {dt * 1e3:7.2f} ms {2.0 * N * 256 * 512 * 16 * 32 * 32 / dt / 1e12:6.1f} TF")
 
 
+def train():
+    """Autoencoder training step (train_autoencoder.py loop body: recon, MSE, backward, Adam)
+    at the README config, batch 16 of 128x128 images: images/s and TFLOP/s (3x forward)."""
+    from models.Autoencoder import Autoencoder
+    from qarig import functional as QF
+    from qarig.optim import FlatAdam
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    m = Autoencoder(num_layers=2, image_channel=3, min_channel=256, max_channel=512,
+                    latent_channel=4).to(dev)
+    opt = FlatAdam(m.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    N = int(os.environ.get("AE_BATCH", "16"))
+    x = torch.rand(N, 3, 128, 128, device=dev) * 2 - 1
+
+    def step():
+        opt.zero_grad()
+        loss = QF.mse_loss(m(x), x)
+        loss.backward()
+        opt.step()
+    dt = timeit(step, reps=5)
+    print(f"autoencoder train N={N}: {N / dt:8.1f} img/s  {3 * (27.64 + 53.41) * N / dt / 1e3:6.1f} TF "
+          f"({dt * 1e3:.1f} ms/step)")
+
+
 if __name__ == "__main__":
-    main()
+    train() if "--train" in sys.argv else main()
