@@ -8,7 +8,6 @@ nn.Parameters owned by torch; the nn.Linear / nn.Conv2d children exist to hold t
 CUDA(HIP) tensors only: a CPU tensor raises (no fallback; the CPU restatement is the
 test oracle under oracle/).
 """
-import torch
 import torch.nn as nn
 
 from qarig import functional as QF

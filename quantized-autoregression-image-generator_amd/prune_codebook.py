@@ -4,7 +4,6 @@ MI355X: same command line, log and `pruned_codebook.pt` dict as the reference's
 prune_codebook.py; the usage count is a device histogram instead of a Python dict loop."""
 import argparse
 import logging
-import os
 import pathlib
 
 import torch

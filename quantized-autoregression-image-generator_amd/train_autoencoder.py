@@ -5,8 +5,6 @@ import argparse
 import logging
 import pathlib
 
-import torch
-
 from models.Autoencoder import Autoencoder
 from qarig import cli_common as cc
 from qarig import functional as QF

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import PKG, ROOT
+from conftest import PKG
 
 pytestmark = pytest.mark.gpu
 

@@ -1,6 +1,5 @@
 """GPU parity of the Transformer building blocks and of the whole model (forward,
 backward, Adam) against the oracle and the reference's golden vectors."""
-import math
 
 import pytest
 import torch
