@@ -79,7 +79,7 @@ def build_models(device, cfg, seed=3):
     return lr_cb.to(device), hr_cb.to(device), model.to(device)
 
 
-def cpu_baseline(cfg, budget_s=15.0):
+def cpu_baseline(cfg, budget_s=float(os.environ.get("QARIG_CPU_BASELINE_SECONDS", "15"))):
     """The oracle (torch-CPU restatement, oracle/ref_models.py) running the same train
     step on the host cores: batch 2 sequences of 256 tokens, as many steps as fit the
     budget (>= 1)."""

@@ -20,6 +20,11 @@ SHAPES = [  # (name, M, N, K, a_kcontig, b_kcontig, kwargs)
     ("dW  2048x512 over M (splitk)", 2048, 512, M, False, False, dict(splitk=-1)),
     ("dW  512x2048 over M (splitk)", 512, 2048, M, False, False, dict(splitk=-1)),
     ("dW  512x512 over M (splitk)", 512, 512, M, False, False, dict(splitk=-1)),
+    # what batching the 42 cond projections of a step into one launch would run as
+    ("dX  512->512 [M,512]@[512,512]", M, 512, 512, True, False, {}),
+    ("fwd cond-all 512->21504 +bias", M, 21504, 512, True, True, dict(bias=True)),
+    ("dX  cond-all [M,21504]@[21504,512]", M, 512, 21504, True, False, {}),
+    ("dW  cond-all 21504x512 over M", 21504, 512, M, False, False, dict(splitk=-1)),
 ]
 
 
