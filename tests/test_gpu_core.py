@@ -143,6 +143,36 @@ def test_bmu_seeded_vs_oracle(N, C, H, W, p, K):
     assert (ref.numpy() != got).mean() <= 1e-4  # torch's own sgemm order: noise rows only
 
 
+def test_bmu_random_shapes_bit_exact():
+    """Seeded sweep over ragged geometries (rows and K off the 128 tile, odd patch sizes,
+    D from 1 to 768, duplicated codebook rows and duplicated patches, K straddling the
+    25-row direct-formula switch of torch.cdist): the HIP indices equal the C oracle's
+    bit for bit on every case."""
+    from qarig import ops
+    from oracle import bmu as obmu
+    rng = np.random.default_rng(1234)
+    g = torch.Generator().manual_seed(77)
+    cases = 0
+    for _ in range(40):
+        p = int(rng.choice([1, 2, 3, 4, 8]))
+        C = int(rng.choice([1, 3, 4, 12]))
+        H, W = p * int(rng.integers(1, 7)), p * int(rng.integers(1, 7))
+        N = int(rng.integers(1, 6))
+        K = int(rng.choice([1, 2, 7, 24, 25, 26, 64, 100, 129, 300, 513]))
+        x = torch.tanh(torch.randn((N, C, H, W), generator=g))
+        w = torch.tanh(torch.randn((K, C * p * p), generator=g))
+        if K > 3 and rng.random() < 0.5:
+            w[K // 2] = w[0]                      # duplicated unit: the lower index must win
+            w[K - 1] = w[1]
+        if rng.random() < 0.3:
+            x[:, :, -p:, -p:] = x[:, :, :p, :p].clone()   # duplicated patches
+        got = ops.bmu(x.cuda(), w.cuda(), (p, p)).cpu().numpy()
+        want = obmu.bmu(x.numpy(), w.numpy(), (p, p))
+        assert np.array_equal(got, want), (N, C, H, W, p, K)
+        cases += 1
+    assert cases == 40
+
+
 def test_bmu_full_size_properties():
     """BASELINE-size run (65,536 rows x K=512): properties that need no oracle pass --
     the chosen unit's exact distance is within fp32 noise of the exact minimum, and
