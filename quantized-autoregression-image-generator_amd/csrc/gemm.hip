@@ -358,7 +358,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 }
 
 
-// Skinny GEMM for M <= 64 rows (single-token decode steps: 4..64 sequences x one token).
+// Skinny GEMM for few rows (single-token decode steps: sequences x beams x one token; 64 rows
+// per workgroup pass, up to 256 rows through blockIdx.z).
 // The 128x128 tile kernel leaves 7/8 of its MFMA rows empty there and needs a split-K
 // round trip to find any parallelism (measured 16 us + 6 us reduce per call); this one
 // is a weight-streaming kernel: a block owns 16 output columns, its 16 waves each own
@@ -380,6 +381,14 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(const float* __restri
     B += blockIdx.y * b_gs;
     ep.C += blockIdx.y * c_gs;
     if (ep.bias) ep.bias += blockIdx.y * bias_gs;
+    // more than 64 rows: blockIdx.z walks 64-row slabs (the weights come back from L2)
+    const int mz = blockIdx.z * 64;
+    A += (int64_t)mz * lda;
+    ep.C += (int64_t)mz * ep.ldc;
+    if (ep.residual) ep.residual += (int64_t)mz * ep.ldr;
+    if (ep.preact) ep.preact += (int64_t)mz * ep.ldp;
+    if (ep.gradz) ep.gradz += (int64_t)mz * ep.ldz;
+    M = min(M - mz, 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 16;
     const int kslice = K >> 4;
@@ -577,11 +586,14 @@ extern "C" size_t qarig_gemm_workspace_bytes(int M, int N, int splitk) {
 }
 
 
+// decode batches (sequences x beams) up to this many rows stay on the weight-streaming kernel
+static constexpr int SKINNY_MAX_ROWS = 256;
+
 static void launch_skinny(const float* A, int64_t lda, const float* B, int64_t ldb, const GemmEpilogue& eps,
                           int M, int N, int K, int64_t a_gs, int64_t b_gs, int64_t c_gs,
                           int64_t bias_gs, int groups, hipStream_t st) {
-    dim3 sgrid((N + 15) / 16, groups), sblock(1024);
-    switch ((M + 15) / 16) {
+    dim3 sgrid((N + 15) / 16, groups, (M + 63) / 64), sblock(1024);
+    switch (M > 64 ? 4 : (M + 15) / 16) {
         case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K, a_gs, b_gs, c_gs, bias_gs); break;
         case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K, a_gs, b_gs, c_gs, bias_gs); break;
         case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K, a_gs, b_gs, c_gs, bias_gs); break;
@@ -615,7 +627,7 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     }
     hipStream_t st = (hipStream_t)stream;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    if (M <= 64 && a_kcontig && b_kcontig && K % 256 == 0 && !accumulate && !a_rowsum &&
+    if (M <= SKINNY_MAX_ROWS && a_kcontig && b_kcontig && K % 256 == 0 && !accumulate && !a_rowsum &&
         al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0) {
         GemmEpilogue eps{C, ldc, bias, residual, ldr, preact, ldp, act, gradz, ldz, gact, nullptr};
         launch_skinny(A, lda, B, ldb, eps, M, N, K, 0, 0, 0, 0, 1, st);
@@ -778,8 +790,8 @@ extern "C" int qarig_gemm_grouped_skinny_f32(const float* A, int64_t lda, int64_
                                              int64_t bias_gs, int groups, int M, int N, int K,
                                              int act, void* stream) {
     QARIG_CHECK_ARG(A && W && C, "gemm_grouped_skinny: null operand");
-    QARIG_CHECK_ARG(groups > 0 && groups <= 65535 && M > 0 && M <= 64 && N > 0 && K > 0 && K % 256 == 0,
-                    "gemm_grouped_skinny: needs 0 < M <= 64, K %% 256 == 0 (M=%d N=%d K=%d groups=%d)",
+    QARIG_CHECK_ARG(groups > 0 && groups <= 65535 && M > 0 && M <= SKINNY_MAX_ROWS && N > 0 && K > 0 && K % 256 == 0,
+                    "gemm_grouped_skinny: needs 0 < M <= 256, K %% 256 == 0 (M=%d N=%d K=%d groups=%d)",
                     M, N, K, groups);
     QARIG_CHECK_ARG(act >= 0 && act <= 3, "gemm_grouped_skinny: bad activation id");
     QARIG_CHECK_ARG((((uintptr_t)A | (uintptr_t)W) & 15) == 0 && lda % 4 == 0 && ldw % 4 == 0 &&

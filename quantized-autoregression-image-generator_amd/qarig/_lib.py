@@ -109,7 +109,13 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """Handle of torch's current HIP stream on the current device (what every launch uses)."""
+    if _raw_stream is not None:      # same value as below without building a Stream object
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -112,7 +112,7 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
 
 def gemm_grouped_skinny(A, W, bias=None, act=0, shared_a=False):
     """out[g] = act(A[g] @ W[g].T + bias[g]).  A: (G, M, K) or (M, K) with shared_a;
-    W: (G, N, K); bias: (G, N) or None.  M <= 64, K % 256 == 0.  Returns (G, M, N)."""
+    W: (G, N, K); bias: (G, N) or None.  M <= 256, K % 256 == 0.  Returns (G, M, N)."""
     require_cuda(A, W, bias)
     G, N, K = W.shape
     assert W.is_contiguous() and A.is_contiguous() and A.dtype == W.dtype == torch.float32

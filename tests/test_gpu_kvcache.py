@@ -58,7 +58,7 @@ def test_attention_decode_matches_full_attention():
 def test_grouped_skinny_gemm():
     from qarig import ops
     g = torch.Generator().manual_seed(0)
-    G, M, N, K = 5, 12, 200, 512
+    G, M, N, K = 5, 70, 200, 512
     A = torch.randn((G, M, K), generator=g).cuda()
     W = (torch.randn((G, N, K), generator=g) * 0.1).cuda()
     b = torch.randn((G, N), generator=g).cuda()
@@ -71,7 +71,7 @@ def test_grouped_skinny_gemm():
     shared = ops.gemm_grouped_skinny(A[0], W, None, shared_a=True)
     assert rel_err(shared, torch.einsum("mk,gnk->gmn", A[0].double().cpu(), W.double().cpu())) < 5e-6
     with pytest.raises(RuntimeError):
-        ops.gemm_grouped_skinny(torch.randn(2, 65, 256).cuda(), torch.randn(2, 16, 256).cuda())
+        ops.gemm_grouped_skinny(torch.randn(2, 257, 256).cuda(), torch.randn(2, 16, 256).cuda())
     with pytest.raises(RuntimeError):
         ops.gemm_grouped_skinny(torch.randn(2, 8, 96).cuda(), torch.randn(2, 16, 96).cuda())
 
