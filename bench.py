@@ -203,7 +203,7 @@ def main():
         rand = parallel.shard(torch.randint(0, nwin, (N * world,), generator=rng))
         hr_in, lr_in, hr_tg = pipeline.tokenize(z, lr_cb, hr_cb, train_base_model=cfg["base"])
         hr_in, hr_tg, pos = pipeline.slide(hr_in, hr_tg, cfg["window"], rand)
-        return pipeline.train_step(model, optim, hr_in, lr_in, hr_tg, pos)
+        return pipeline.train_step(model, optim, hr_in, lr_in, hr_tg, pos, pos_bound=seq)
 
     def fence():
         if world > 1:

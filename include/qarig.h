@@ -147,11 +147,31 @@ int qarig_embedding_bwd(const int64_t* ids, int M, int D, int V, const float* dy
 /* nn.LayerNorm(D) (gamma,beta) / AdaLNZero modulation (scale,shift per token) --
  * models/layers.py:130-153,327,499,559.  Exactly one of the pairs, or neither. */
 int qarig_layernorm_fwd(const float* x, int M, int D, float eps, const float* gamma,
-                        const float* beta, const float* scale, const float* shift, float* y,
-                        float* mean, float* rstd, void* stream);
+                        const float* beta, const float* scale, const float* shift,
+                        const int* mod_idx, float* y, float* mean, float* rstd, void* stream);
 int qarig_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
-                        const float* gamma, const float* scale, int M, int D, float* dx,
-                        float* dy_xhat, void* stream);
+                        const float* gamma, const float* scale, const int* mod_idx, int M, int D,
+                        float* dx, float* dy_xhat, void* stream);
+
+/* Position-table form of the conditioning path.  `cond` (models/Transformer.py:154-167) is a
+ * function of the token's integer position alone, so pos_cond_layer and every
+ * ScaleLayer/ShiftLayer projection (models/layers.py:100-153, 258-304) are evaluated once per
+ * distinct position into (P,D) tables and the per-token consumers index them:
+ *   - qarig_layernorm_fwd/bwd with mod_idx (int32 (M,)): scale/shift row = table[mod_idx[row]];
+ *     mod_idx == NULL keeps the per-token (M,D) scale/shift form;
+ *   - qarig_mul_rows_fwd/bwd: y[r] = a[r] * tab[idx[r]] (ResidualLinearLayer's x * scale(cond));
+ *   - qarig_rowmap_build + qarig_segment_sum: gradient of a table row = sum of its tokens'
+ *     per-token gradients in ascending token order (deterministic, no atomics).
+ * counts: P ints scratch; offsets: P+1 ints; rows: M ints; *bad_flag is set when an index is
+ * outside [0,P). */
+int qarig_rowmap_build(const int* idx, int M, int P, int* counts, int* offsets, int* rows,
+                       int* bad_flag, void* stream);
+int qarig_segment_sum(const float* src, const int* offsets, const int* rows, int P, int D,
+                      float* out, void* stream);
+int qarig_mul_rows_fwd(const float* a, const float* tab, const int* idx, float* y, int M, int D,
+                       void* stream);
+int qarig_mul_rows_bwd(const float* dy, const float* a, const float* tab, const int* idx, float* da,
+                       float* db_tok, int M, int D, void* stream);
 
 /* AttentionLayer core -- models/layers.py:433-474.  q (N,Sq,H*d); k,v (N,Sk,H*d);
  * o (N,Sq,H*d); lse (N,H,Sq); sqrt_d = float(d ** 0.5). */

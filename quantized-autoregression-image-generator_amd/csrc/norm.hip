@@ -16,12 +16,14 @@ template <int NV>
 __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_fwd_kernel(
     const float* __restrict__ x, int M, int D, float eps, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ y, float* __restrict__ mean_out,
-    float* __restrict__ rstd_out) {
+    const float* __restrict__ shift, const int* __restrict__ mod_idx, float* __restrict__ y,
+    float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     if (row >= M) return;
     const float* xr = x + (int64_t)row * D;
+    // scale/shift row: the token's own, or (position-table form) the row its index names
+    const int64_t mrow = (int64_t)(mod_idx ? mod_idx[row] : row) * D;
     if (NV > 0) {
         // the row lives in registers: one 16-B load per 256 columns per lane, no re-reads
         float4 r[NV > 0 ? NV : 1];
@@ -54,8 +56,8 @@ __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_fwd_kernel(
                 const float4 b = *reinterpret_cast<const float4*>(beta + c);
                 h = make_float4(h.x * g.x + b.x, h.y * g.y + b.y, h.z * g.z + b.z, h.w * g.w + b.w);
             } else if (scale) {
-                const float4 g = *reinterpret_cast<const float4*>(scale + (int64_t)row * D + c);
-                const float4 b = *reinterpret_cast<const float4*>(shift + (int64_t)row * D + c);
+                const float4 g = *reinterpret_cast<const float4*>(scale + mrow + c);
+                const float4 b = *reinterpret_cast<const float4*>(shift + mrow + c);
                 h = make_float4(g.x * h.x + b.x, g.y * h.y + b.y, g.z * h.z + b.z, g.w * h.w + b.w);
             }
             *reinterpret_cast<float4*>(yr + c) = h;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_fwd_kernel(
     for (int c = lane; c < D; c += 64) {
         float h = (xr[c] - mean) * rstd;
         if (gamma) h = h * gamma[c] + beta[c];
-        else if (scale) h = scale[(int64_t)row * D + c] * h + shift[(int64_t)row * D + c];
+        else if (scale) h = scale[mrow + c] * h + shift[mrow + c];
         yr[c] = h;
     }
 }
@@ -90,18 +92,19 @@ __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_fwd_kernel(
 __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_in,
     const float* __restrict__ rstd_in, const float* __restrict__ gamma,
-    const float* __restrict__ scale, int M, int D, float* __restrict__ dx,
-    float* __restrict__ dy_xhat) {
+    const float* __restrict__ scale, const int* __restrict__ mod_idx, int M, int D,
+    float* __restrict__ dx, float* __restrict__ dy_xhat) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     if (row >= M) return;
     const int64_t off = (int64_t)row * D;
+    const int64_t moff = (int64_t)(mod_idx ? mod_idx[row] : row) * D;
     const float mean = mean_in[row], rstd = rstd_in[row];
     float s1 = 0.0f, s2 = 0.0f;
     for (int c = lane; c < D; c += 64) {
         const float h = (x[off + c] - mean) * rstd;
         const float d = dy[off + c];
-        const float g = gamma ? d * gamma[c] : (scale ? d * scale[off + c] : d);
+        const float g = gamma ? d * gamma[c] : (scale ? d * scale[moff + c] : d);
         s1 += g;
         s2 = fmaf(g, h, s2);
     }
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_bwd_kernel(
     for (int c = lane; c < D; c += 64) {
         const float h = (x[off + c] - mean) * rstd;
         const float d = dy[off + c];
-        const float g = gamma ? d * gamma[c] : (scale ? d * scale[off + c] : d);
+        const float g = gamma ? d * gamma[c] : (scale ? d * scale[moff + c] : d);
         dx[off + c] = rstd * ((g - s1) - h * s2);
         if (dy_xhat) dy_xhat[off + c] = d * h;
     }
@@ -122,7 +125,9 @@ using namespace qarig;
 
 extern "C" int qarig_layernorm_fwd(const float* x, int M, int D, float eps, const float* gamma,
                                    const float* beta, const float* scale, const float* shift,
-                                   float* y, float* mean, float* rstd, void* stream) {
+                                   const int* mod_idx, float* y, float* mean, float* rstd,
+                                   void* stream) {
+    QARIG_CHECK_ARG(!mod_idx || scale, "layernorm_fwd: mod_idx needs scale/shift tables");
     QARIG_CHECK_ARG(x && y && mean && rstd && M > 0 && D > 0, "layernorm_fwd: bad arguments");
     QARIG_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "layernorm_fwd: gamma/beta pair");
     QARIG_CHECK_ARG((scale == nullptr) == (shift == nullptr), "layernorm_fwd: scale/shift pair");
@@ -133,7 +138,7 @@ extern "C" int qarig_layernorm_fwd(const float* x, int M, int D, float eps, cons
     const dim3 grid((M + LN_WAVES - 1) / LN_WAVES), block(LN_WAVES * 64);
 #define QARIG_LN_LAUNCH(NV)                                                                      \
     hipLaunchKernelGGL((layernorm_fwd_kernel<NV>), grid, block, 0, (hipStream_t)stream, x, M, D, \
-                       eps, gamma, beta, scale, shift, y, mean, rstd)
+                       eps, gamma, beta, scale, shift, mod_idx, y, mean, rstd)
     switch (vec ? D / 256 : 0) {
         case 1: QARIG_LN_LAUNCH(1); break;
         case 2: QARIG_LN_LAUNCH(2); break;
@@ -148,12 +153,13 @@ extern "C" int qarig_layernorm_fwd(const float* x, int M, int D, float eps, cons
 
 extern "C" int qarig_layernorm_bwd(const float* dy, const float* x, const float* mean,
                                    const float* rstd, const float* gamma, const float* scale,
-                                   int M, int D, float* dx, float* dy_xhat, void* stream) {
+                                   const int* mod_idx, int M, int D, float* dx, float* dy_xhat,
+                                   void* stream) {
     QARIG_CHECK_ARG(dy && x && mean && rstd && dx && M > 0 && D > 0, "layernorm_bwd: bad arguments");
     QARIG_CHECK_ARG(!(gamma && scale), "layernorm_bwd: affine and AdaLN forms are exclusive");
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + LN_WAVES - 1) / LN_WAVES),
                        dim3(LN_WAVES * 64), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, scale,
-                       M, D, dx, dy_xhat);
+                       mod_idx, M, D, dx, dy_xhat);
     QARIG_CHECK_LAUNCH("layernorm_bwd");
     return QARIG_OK;
 }

@@ -84,15 +84,30 @@ class Transformer(nn.Module):
                 enc = layer(enc)
         return enc
 
-    def decode(self, x_dec, enc=None, pos_cond=None):
+    def _cond(self, pos_cond, N, S, D, pos_bound):
+        """Conditioning of the decoder blocks.  Integer positions (training): a position table
+        -- the sinusoid, pos_cond_layer and (inside the blocks) every scale/shift projection
+        evaluated once per position 0..P-1 instead of once per token -- whenever that is at
+        least 4x fewer rows; P = pos_bound when the caller knows it (no host sync), else
+        max(pos)+1.  Float positions (sampling) keep the per-token form."""
+        if QF.USE_COND_TABLE and not pos_cond.dtype.is_floating_point:
+            P = int(pos_bound) if pos_bound is not None else int(pos_cond.max().item()) + 1
+            if 0 < 4 * P <= N * S:
+                dev = pos_cond.device
+                tab = ops.posemb(torch.arange(P, device=dev), D)
+                tab = _mlp2_forward(self.pos_cond_layer, tab)
+                return QF.CondTable(tab, pos_cond.reshape(-1).to(torch.int32).contiguous(), (N, S))
+        cond = ops.posemb(pos_cond.flatten(), D).reshape(N, S, D)
+        return _mlp2_forward(self.pos_cond_layer, cond)
+
+    def decode(self, x_dec, enc=None, pos_cond=None, pos_bound=None):
         table = self.dec_embedding.weight
         N, S = x_dec.shape
         D = table.shape[1]
         x = QF.embedding_pos(x_dec, table, self._sequence_pe(S, D, table.device))
         cond = None
         if self.use_pos_cond:
-            cond = ops.posemb(pos_cond.flatten(), D).reshape(N, S, D)
-            cond = _mlp2_forward(self.pos_cond_layer, cond)
+            cond = self._cond(pos_cond, N, S, D, pos_bound)
         for layer in self.decoder_layers:
             if self.use_activation_checkpoint and torch.is_grad_enabled():
                 x = checkpoint.checkpoint(layer, x, cross_cond=enc, pos_cond=cond,
@@ -101,6 +116,8 @@ class Transformer(nn.Module):
                 x = layer(x=x, cross_cond=enc, pos_cond=cond)
         return _mlp2_forward(self.classifier, x)
 
-    def forward(self, x_dec, x_enc=None, pos_cond=None):
+    def forward(self, x_dec, x_enc=None, pos_cond=None, pos_bound=None):
+        """pos_bound (optional, additive): exclusive upper bound of the integer positions in
+        pos_cond, so that the position table can be sized without reading pos_cond back."""
         enc = self.encode(x_enc) if self.use_encoder else None
-        return self.decode(x_dec, enc, pos_cond)
+        return self.decode(x_dec, enc, pos_cond, pos_bound)

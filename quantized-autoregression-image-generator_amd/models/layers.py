@@ -79,6 +79,9 @@ class AdaLNZero(nn.Module):
         self.shift_layer = ShiftLayer(in_dim=in_dim, out_dim=out_dim)
 
     def forward(self, x, cond):
+        if isinstance(cond, QF.CondTable):     # projections once per position, indexed per token
+            return QF.layernorm_mod_table(x, self.scale_layer(cond.table), self.shift_layer(cond.table),
+                                          cond, self.norm.eps)
         return QF.layernorm_mod(x, self.scale_layer(cond), self.shift_layer(cond), self.norm.eps)
 
 
@@ -183,7 +186,10 @@ class ResidualLinearLayer(nn.Module):
 
     def forward(self, x, x_skip, cond=None):
         if self.use_scale_layer:
-            x = QF.mul(x, self.scale_layer(cond))
+            if isinstance(cond, QF.CondTable):
+                x = QF.mul_table(x, self.scale_layer(cond.table), cond)
+            else:
+                x = QF.mul(x, self.scale_layer(cond))
         x_skip = self.skip_linear(x_skip)
         w, b = _lin_params(self.linear)
         return QF.linear_act(x, w, b, residual=x_skip, act=self._act)

@@ -43,8 +43,12 @@ SIGNATURES = {
     "qarig_posemb_fwd": (I, [P, I, I, P, P, P]),
     "qarig_embedding_fwd": (I, [P, I, I, I, I, P, P, P, P, P]),
     "qarig_embedding_bwd": (I, [P, I, I, I, P, P, P]),
-    "qarig_layernorm_fwd": (I, [P, I, I, F, P, P, P, P, P, P, P, P]),
-    "qarig_layernorm_bwd": (I, [P, P, P, P, P, P, I, I, P, P, P]),
+    "qarig_layernorm_fwd": (I, [P, I, I, F, P, P, P, P, P, P, P, P, P]),
+    "qarig_layernorm_bwd": (I, [P, P, P, P, P, P, P, I, I, P, P, P]),
+    "qarig_rowmap_build": (I, [P, I, I, P, P, P, P, P]),
+    "qarig_segment_sum": (I, [P, P, P, I, I, P, P]),
+    "qarig_mul_rows_fwd": (I, [P, P, P, P, I, I, P]),
+    "qarig_mul_rows_bwd": (I, [P, P, P, P, P, P, I, I, P]),
     "qarig_attention_fwd": (I, [P, P, P, I, I, I, I, I, I, F, P, P, P]),
     "qarig_attention_decode": (I, [P, P, P, P, P, I, I, I, I, P, I, L, F, P, P, P]),
     "qarig_gemm_grouped_skinny_f32": (I, [P, L, L, P, L, L, P, L, L, P, L, I, I, I, I, I, P]),

@@ -321,25 +321,70 @@ def embedding_bwd(ids, dy, V):
     return out
 
 
-def layernorm_fwd(x2d, gamma=None, beta=None, scale=None, shift=None, eps=1e-5):
+def layernorm_fwd(x2d, gamma=None, beta=None, scale=None, shift=None, eps=1e-5, mod_idx=None):
+    """mod_idx (int32 (M,)): scale/shift are (P,D) position tables read at row mod_idx[token]."""
     M, D = x2d.shape
     y = torch.empty_like(x2d)
     mean = torch.empty(M, dtype=torch.float32, device=x2d.device)
     rstd = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    if mod_idx is not None:
+        assert mod_idx.dtype == torch.int32 and mod_idx.shape == (M,) and mod_idx.is_contiguous()
     check(_lib.load().qarig_layernorm_fwd(ptr(x2d), M, D, eps, ptr(gamma), ptr(beta), ptr(scale),
-                                          ptr(shift), ptr(y), ptr(mean), ptr(rstd), stream()),
-          "qarig_layernorm_fwd")
+                                          ptr(shift), ptr(mod_idx), ptr(y), ptr(mean), ptr(rstd),
+                                          stream()), "qarig_layernorm_fwd")
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x2d, mean, rstd, gamma=None, scale=None, want_dy_xhat=False):
+def layernorm_bwd(dy, x2d, mean, rstd, gamma=None, scale=None, want_dy_xhat=False, mod_idx=None):
     M, D = x2d.shape
     dx = torch.empty_like(x2d)
     dyx = torch.empty_like(x2d) if want_dy_xhat else None
     check(_lib.load().qarig_layernorm_bwd(ptr(dy), ptr(x2d), ptr(mean), ptr(rstd), ptr(gamma),
-                                          ptr(scale), M, D, ptr(dx), ptr(dyx), stream()),
-          "qarig_layernorm_bwd")
+                                          ptr(scale), ptr(mod_idx), M, D, ptr(dx), ptr(dyx),
+                                          stream()), "qarig_layernorm_bwd")
     return dx, dyx
+
+
+def rowmap_build(idx, P):
+    """(offsets (P+1,), rows (M,)) int32: rows[offsets[p]:offsets[p+1]] = ascending tokens with
+    idx == p.  Out-of-range indices set the device index flag (see check_index_flag)."""
+    require_cuda(idx)
+    assert idx.dtype == torch.int32 and idx.dim() == 1 and idx.is_contiguous()
+    M = idx.numel()
+    counts = torch.empty(P, dtype=torch.int32, device=idx.device)
+    offsets = torch.empty(P + 1, dtype=torch.int32, device=idx.device)
+    rows = torch.empty(M, dtype=torch.int32, device=idx.device)
+    check(_lib.load().qarig_rowmap_build(ptr(idx), M, P, ptr(counts), ptr(offsets), ptr(rows),
+                                         ptr(_bad_flag(idx.device)), stream()), "qarig_rowmap_build")
+    return offsets, rows
+
+
+def segment_sum(src, offsets, rows):
+    """(P,D) sums of the rows of src (M,D) that the row map assigns to each table row."""
+    P = offsets.numel() - 1
+    M, D = src.shape
+    assert src.is_contiguous() and rows.numel() == M
+    out = torch.empty((P, D), dtype=torch.float32, device=src.device)
+    check(_lib.load().qarig_segment_sum(ptr(src), ptr(offsets), ptr(rows), P, D, ptr(out), stream()),
+          "qarig_segment_sum")
+    return out
+
+
+def mul_rows_fwd(a, tab, idx):
+    M, D = a.shape
+    y = torch.empty_like(a)
+    check(_lib.load().qarig_mul_rows_fwd(ptr(a), ptr(tab), ptr(idx), ptr(y), M, D, stream()),
+          "qarig_mul_rows_fwd")
+    return y
+
+
+def mul_rows_bwd(dy, a, tab, idx):
+    M, D = a.shape
+    da = torch.empty_like(a)
+    db = torch.empty_like(a)
+    check(_lib.load().qarig_mul_rows_bwd(ptr(dy), ptr(a), ptr(tab), ptr(idx), ptr(da), ptr(db), M, D,
+                                         stream()), "qarig_mul_rows_bwd")
+    return da, db
 
 
 def attention_fwd(q, k, v, heads, causal):

@@ -41,11 +41,13 @@ def num_windows(seq_len, window):
     return seq_len - window + 1
 
 
-def train_step(model, optim, hr_input, lr_input, hr_target, pos_idx, dp=True):
+def train_step(model, optim, hr_input, lr_input, hr_target, pos_idx, dp=True, pos_bound=None):
     """forward + CE + backward + gradient all-reduce + Adam.  Returns the loss tensor
-    (device scalar; callers decide when to .item())."""
+    (device scalar; callers decide when to .item()).  pos_bound: exclusive upper bound of
+    pos_idx (the un-windowed sequence length) -- sizes the model's position table without
+    a device read-back."""
     optim.zero_grad()
-    logits = model(x_dec=hr_input, x_enc=lr_input, pos_cond=pos_idx)
+    logits = model(x_dec=hr_input, x_enc=lr_input, pos_cond=pos_idx, pos_bound=pos_bound)
     loss = QF.cross_entropy(logits.view(-1, logits.shape[-1]), hr_target.flatten())
     loss.backward()
     w = parallel.world_size() if dp else 1

@@ -223,13 +223,15 @@ def main():
             hr_in, lr_in, hr_tg = pipeline.tokenize(feature_map, lr_codebook, hr_codebook,
                                                     train_base_model)
             pos_idx = None
+            seq_total = hr_in.shape[1]
             if use_sliding_window:
                 nwin = pipeline.num_windows(hr_in.shape[1], sliding_window)
                 rand = torch.randint(low=0, high=nwin, size=(N * world,))   # CPU global RNG
                 rand = parallel.shard(parallel.broadcast_host_tensor(rand))
                 hr_in, hr_tg, pos_idx = pipeline.slide(hr_in, hr_tg, sliding_window, rand)
             model.train()
-            loss = pipeline.train_step(model, optim, hr_in, lr_in, hr_tg, pos_idx)
+            loss = pipeline.train_step(model, optim, hr_in, lr_in, hr_tg, pos_idx,
+                                       pos_bound=seq_total)
             loss_val = loss.item()                                   # the reference's per-step sync
             ops.check_index_flag(device, "training batch")
             if loss_val != loss_val:

@@ -1,0 +1,104 @@
+"""Position-table conditioning (csrc/condtable.hip): the table path must reproduce the
+reference's per-token evaluation -- same logits, same loss, same gradient for EVERY parameter
+(1e-5 relative, summation order only) -- and its building blocks are checked on their own."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rowmap_and_segment_sum():
+    from qarig import ops
+    g = torch.Generator().manual_seed(0)
+    M, P, D = 5000, 37, 64
+    idx = torch.randint(0, P - 3, (M,), generator=g).to(torch.int32)     # rows P-3.. stay empty
+    off, rows = ops.rowmap_build(idx.cuda(), P)
+    off, rows = off.cpu(), rows.cpu()
+    assert off[0] == 0 and off[-1] == M
+    for p in range(P):
+        want = torch.nonzero(idx == p).flatten().to(torch.int32)
+        assert torch.equal(rows[off[p]:off[p + 1]], want)                  # ascending token order
+    src = torch.randn((M, D), generator=g)
+    got = ops.segment_sum(src.cuda(), off.cuda(), rows.cuda())
+    want = torch.zeros((P, D), dtype=torch.float64).index_add_(0, idx.long(), src.double())
+    assert rel_err(got, want) < 1e-6
+    assert not got[P - 3:].any()
+    assert torch.equal(got, ops.segment_sum(src.cuda(), off.cuda(), rows.cuda()))   # deterministic
+    ops.check_index_flag(torch.device("cuda"), "rowmap")
+    bad = idx.clone()
+    bad[17] = P
+    ops.rowmap_build(bad.cuda(), P)
+    with pytest.raises(IndexError):
+        ops.check_index_flag(torch.device("cuda"), "rowmap")
+
+
+def test_table_ops_match_per_token_ops():
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(1)
+    N, S, D, P = 3, 40, 256, 50
+    idx = (torch.randint(0, P - S + 1, (N, 1), generator=g) + torch.arange(S)[None]).reshape(-1)
+    x = torch.randn((N, S, D), generator=g).cuda().requires_grad_(True)
+    st = torch.randn((P, D), generator=g).cuda().requires_grad_(True)
+    sh = torch.randn((P, D), generator=g).cuda().requires_grad_(True)
+    gy = torch.randn((N, S, D), generator=g).cuda()
+    cond = QF.CondTable(st, idx.to(torch.int32).cuda(), (N, S))
+    for name in ("ln", "mul"):
+        if name == "ln":
+            y = QF.layernorm_mod_table(x, st, sh, cond)
+            y_ref = QF.layernorm_mod(x, st[idx.cuda()].reshape(N, S, D), sh[idx.cuda()].reshape(N, S, D))
+        else:
+            y = QF.mul_table(x, st, cond)
+            y_ref = QF.mul(x, st[idx.cuda()].reshape(N, S, D))
+        assert torch.equal(y, y_ref)                 # forward: the same arithmetic per element
+        got = torch.autograd.grad(y, (x, st, sh) if name == "ln" else (x, st), gy)
+        want = torch.autograd.grad(y_ref, (x, st, sh) if name == "ln" else (x, st), gy)
+        for a, b in zip(got, want):
+            assert rel_err(a, b) < 2e-6
+
+
+@pytest.mark.parametrize("use_encoder", [False, True])
+def test_table_path_equals_per_token_path_for_every_parameter(use_encoder):
+    from models.Transformer import Transformer
+    from qarig import functional as QF
+    torch.manual_seed(5)
+    m = Transformer(use_encoder=use_encoder, use_pos_cond=True, num_enc_layers=1 if use_encoder else None,
+                    num_dec_layers=2, num_enc_embedding=30 if use_encoder else None,
+                    num_dec_embedding=50, self_attn_heads=8, cross_attn_heads=8 if use_encoder else None,
+                    transformer_in_dim=64, transformer_out_dim=41, transformer_hidden_dim=128).cuda()
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.abs().max() == 0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    N, S, total = 6, 32, 40
+    x = torch.randint(0, 50, (N, S), generator=g).cuda()
+    e = torch.randint(0, 30, (N, 7), generator=g).cuda() if use_encoder else None
+    t = torch.randint(0, 41, (N, S), generator=g).cuda()
+    pos = (torch.randint(0, total - S + 1, (N, 1), generator=g) + torch.arange(S)[None]).cuda()
+    res = {}
+    for table in (False, True):
+        QF.USE_COND_TABLE = table
+        try:
+            m.zero_grad()
+            logits = m(x, e, pos, pos_bound=total if table else None)
+            loss = QF.cross_entropy(logits.view(-1, 41), t.flatten())
+            loss.backward()
+            res[table] = (logits.detach().clone(), float(loss.detach()),
+                          {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+        finally:
+            QF.USE_COND_TABLE = True
+    assert rel_err(res[True][0], res[False][0]) < 1e-5
+    assert abs(res[True][1] - res[False][1]) < 1e-6 * abs(res[False][1])
+    for n, gref in res[False][2].items():
+        if float(gref.abs().max()) == 0.0:
+            assert float(res[True][2][n].abs().max()) == 0.0, n
+        else:
+            assert rel_err(res[True][2][n], gref) < 1e-5, n
+    # without the bound the table is sized from the data (one read-back), same result
+    with torch.no_grad():
+        assert rel_err(m(x, e, pos), m(x, e, pos, pos_bound=total)) < 1e-6
+    # float positions (sampling) keep the per-token form
+    with torch.no_grad():
+        assert rel_err(m(x, e, pos.float()), res[False][0]) < 1e-5
