@@ -12,7 +12,7 @@
 //   * ResidualLinearLayer's x * scale(cond): qarig_mul_rows_fwd/bwd (here).
 // Row r of a GEMM depends on row r of its input only, so the forward values are those of the
 // per-token evaluation; in the backward pass the per-token gradients of a table row are summed
-// in ascending token order (qarig_segment_sum over the row map built by qarig_rowmap_build):
+// in a fixed order (qarig_segment_sum over the row map built by qarig_rowmap_build):
 // deterministic, no atomics.
 #include "qarig_common.h"
 
@@ -77,20 +77,46 @@ __global__ __launch_bounds__(64) void rowmap_fill_kernel(const int* __restrict__
     }
 }
 
-// out[p][c] = sum over the tokens t of table row p (ascending) of src[t][c].
-__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ src,
+// out[p][c] = sum over the tokens t of table row p of src[t][c].  The block's SG sub-groups
+// take the row's tokens round-robin (sub-group s: entries s, s+SG, ...; two loads in flight
+// each) and their partial sums are added in sub-group order: a fixed order, so the result is
+// run-to-run identical, while 2*SG row reads are in flight instead of one.
+constexpr int SEG_GROUPS = 4;
+__global__ __launch_bounds__(512) void segment_sum_kernel(const float* __restrict__ src,
                                                           const int* __restrict__ offsets,
                                                           const int* __restrict__ rows, int D,
                                                           float* __restrict__ out) {
+    __shared__ float4 part[SEG_GROUPS][128];
     const int p = blockIdx.x;
     const int beg = offsets[p], end = offsets[p + 1];
-    for (int c = (blockIdx.y * 256 + threadIdx.x) * 4; c < D; c += gridDim.y * 1024) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int e = beg; e < end; ++e) {
-            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)rows[e] * D + c);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    const int sg = threadIdx.x >> 7, t = threadIdx.x & 127;
+    for (int c0 = blockIdx.y * 512; c0 < D; c0 += gridDim.y * 512) {
+        const int c = c0 + t * 4;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        if (c < D) {
+            int e = beg + sg;
+            for (; e + SEG_GROUPS < end; e += 2 * SEG_GROUPS) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src + (int64_t)rows[e] * D + c);
+                const float4 v1 = *reinterpret_cast<const float4*>(src + (int64_t)rows[e + SEG_GROUPS] * D + c);
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+            }
+            if (e < end) {
+                const float4 v0 = *reinterpret_cast<const float4*>(src + (int64_t)rows[e] * D + c);
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            }
         }
-        *reinterpret_cast<float4*>(out + (int64_t)p * D + c) = acc;
+        __syncthreads();
+        part[sg][t] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        __syncthreads();
+        if (sg == 0 && c < D) {
+            float4 r = part[0][t];
+#pragma unroll
+            for (int g = 1; g < SEG_GROUPS; ++g) {
+                r.x += part[g][t].x; r.y += part[g][t].y; r.z += part[g][t].z; r.w += part[g][t].w;
+            }
+            *reinterpret_cast<float4*>(out + (int64_t)p * D + c) = r;
+        }
     }
 }
 
@@ -157,7 +183,7 @@ extern "C" int qarig_segment_sum(const float* src, const int* offsets, const int
     QARIG_CHECK_ARG(src && offsets && rows && out && P > 0 && D > 0 && D % 4 == 0 &&
                         ((((uintptr_t)src | (uintptr_t)out)) & 15) == 0,
                     "segment_sum: bad arguments (D %% 4 == 0, 16-B aligned)");
-    hipLaunchKernelGGL(segment_sum_kernel, dim3(P, (D + 1023) / 1024), dim3(256), 0,
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(P, (D + 511) / 512), dim3(512), 0,
                        (hipStream_t)stream, src, offsets, rows, D, out);
     QARIG_CHECK_LAUNCH("segment_sum");
     return QARIG_OK;

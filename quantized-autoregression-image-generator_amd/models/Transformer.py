@@ -92,6 +92,9 @@ class Transformer(nn.Module):
         max(pos)+1.  Float positions (sampling) keep the per-token form."""
         if QF.USE_COND_TABLE and not pos_cond.dtype.is_floating_point:
             P = int(pos_bound) if pos_bound is not None else int(pos_cond.max().item()) + 1
+            # whole 128-row tiles: every GEMM on the table (forward, d-input, d-weight with
+            # K = P) then takes the interior kernels; rows past the bound are never indexed
+            P = (P + 127) // 128 * 128
             if 0 < 4 * P <= N * S:
                 dev = pos_cond.device
                 tab = ops.posemb(torch.arange(P, device=dev), D)
