@@ -89,7 +89,7 @@ int qarig_gemm_bf16(const float* A, int64_t lda, int a_kcontig, const float* B, 
  * X_g = X + g * x_gs (a_gs == 0 shares the activations).  Decode steps use it for the q/k/v
  * MLPs (models/layers.py:389-418) and for every projection of the conditioning vector
  * (ScaleLayer/ShiftLayer, models/layers.py:100-153, 258-304) of all layers at once.
- * Requires M <= 256, K % 256 == 0, reduction-contiguous 16-B aligned operands. */
+ * Requires M <= 512, K % 256 == 0, reduction-contiguous 16-B aligned operands. */
 int qarig_gemm_grouped_skinny_f32(const float* A, int64_t lda, int64_t a_gs, const float* W,
                                   int64_t ldw, int64_t w_gs, float* C, int64_t ldc, int64_t c_gs,
                                   const float* bias, int64_t bias_gs, int groups, int M, int N,

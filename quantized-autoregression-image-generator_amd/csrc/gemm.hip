@@ -359,7 +359,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 
 // Skinny GEMM for few rows (single-token decode steps: sequences x beams x one token; 64 rows
-// per workgroup pass, up to 256 rows through blockIdx.z).
+// per workgroup pass, up to 512 rows through blockIdx.z; also the forward of the position-table
+// projections, a few hundred rows).
 // The 128x128 tile kernel leaves 7/8 of its MFMA rows empty there and needs a split-K
 // round trip to find any parallelism (measured 16 us + 6 us reduce per call); this one
 // is a weight-streaming kernel: a block owns 16 output columns, its 16 waves each own
@@ -587,7 +588,7 @@ extern "C" size_t qarig_gemm_workspace_bytes(int M, int N, int splitk) {
 
 
 // decode batches (sequences x beams) up to this many rows stay on the weight-streaming kernel
-static constexpr int SKINNY_MAX_ROWS = 256;
+static constexpr int SKINNY_MAX_ROWS = 512;
 
 static void launch_skinny(const float* A, int64_t lda, const float* B, int64_t ldb, const GemmEpilogue& eps,
                           int M, int N, int K, int64_t a_gs, int64_t b_gs, int64_t c_gs,
@@ -791,7 +792,7 @@ extern "C" int qarig_gemm_grouped_skinny_f32(const float* A, int64_t lda, int64_
                                              int act, void* stream) {
     QARIG_CHECK_ARG(A && W && C, "gemm_grouped_skinny: null operand");
     QARIG_CHECK_ARG(groups > 0 && groups <= 65535 && M > 0 && M <= SKINNY_MAX_ROWS && N > 0 && K > 0 && K % 256 == 0,
-                    "gemm_grouped_skinny: needs 0 < M <= 256, K %% 256 == 0 (M=%d N=%d K=%d groups=%d)",
+                    "gemm_grouped_skinny: needs 0 < M <= 512, K %% 256 == 0 (M=%d N=%d K=%d groups=%d)",
                     M, N, K, groups);
     QARIG_CHECK_ARG(act >= 0 && act <= 3, "gemm_grouped_skinny: bad activation id");
     QARIG_CHECK_ARG((((uintptr_t)A | (uintptr_t)W) & 15) == 0 && lda % 4 == 0 && ldw % 4 == 0 &&

@@ -128,7 +128,7 @@ class DecodeCache:
                 if res.use_scale_layer:
                     idx[name + "_scale"] = add(res.scale_layer.scale)
             self._proj_idx.append(idx)
-        ok = ok and all(w.shape == (D, D) for w in ws) and D % 256 == 0 and self.batch <= 256
+        ok = ok and all(w.shape == (D, D) for w in ws) and D % 256 == 0 and self.batch <= 512
         self._qkv = []
         for layer in model.decoder_layers:
             at = layer.self_attn_block.self_attn

@@ -112,7 +112,7 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
 
 def gemm_grouped_skinny(A, W, bias=None, act=0, shared_a=False):
     """out[g] = act(A[g] @ W[g].T + bias[g]).  A: (G, M, K) or (M, K) with shared_a;
-    W: (G, N, K); bias: (G, N) or None.  M <= 256, K % 256 == 0.  Returns (G, M, N)."""
+    W: (G, N, K); bias: (G, N) or None.  M <= 512, K % 256 == 0.  Returns (G, M, N)."""
     require_cuda(A, W, bias)
     G, N, K = W.shape
     assert W.is_contiguous() and A.is_contiguous() and A.dtype == W.dtype == torch.float32
@@ -164,8 +164,18 @@ def auto_splitk(M, N, K):
 def pick_splitk(M, N, K):
     """Reduction split for weight-gradient shaped GEMMs (small M x N, long K)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 256 or K < 2048:
+    if tiles >= 256:
         return 1
+    if K < 2048:
+        # short reductions over few tiles (weight gradients of the position-table layers,
+        # K = a few hundred positions): a handful of workgroups would each walk the whole
+        # reduction at DMA latency; spread it in 64-deep slices that divide K exactly
+        if tiles > 64 or K % 64:
+            return 1
+        s = K // 64
+        while s > 1 and (K % s or (K // s) % 16 or s * tiles > 512):
+            s -= 1
+        return max(1, s)
     s = min(max(1, 512 // tiles), K // 512)
     return max(1, min(s, 32))
 

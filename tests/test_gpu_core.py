@@ -71,9 +71,9 @@ def test_gemm_splitk_and_colsum():
 
 @pytest.mark.parametrize("M,N,K", [(1, 16, 256), (4, 2048, 512), (16, 512, 2048), (17, 513, 512),
                                    (33, 100, 768), (64, 2048, 512), (48, 7, 256), (65, 300, 512),
-                                   (100, 513, 2048), (256, 64, 256)])
+                                   (100, 513, 2048), (256, 64, 256), (384, 512, 512)])
 def test_gemm_skinny_decode_shapes(M, N, K):
-    """M <= 256, K % 256 == 0, both operands reduction-contiguous: the weight-streaming
+    """M <= 512, K % 256 == 0, both operands reduction-contiguous: the weight-streaming
     16x16x4-MFMA kernel (decode steps), every epilogue option, strided A, ragged N."""
     from qarig import ops
     from oracle import ref_models as rm

@@ -71,7 +71,7 @@ def test_grouped_skinny_gemm():
     shared = ops.gemm_grouped_skinny(A[0], W, None, shared_a=True)
     assert rel_err(shared, torch.einsum("mk,gnk->gmn", A[0].double().cpu(), W.double().cpu())) < 5e-6
     with pytest.raises(RuntimeError):
-        ops.gemm_grouped_skinny(torch.randn(2, 257, 256).cuda(), torch.randn(2, 16, 256).cuda())
+        ops.gemm_grouped_skinny(torch.randn(2, 513, 256).cuda(), torch.randn(2, 16, 256).cuda())
     with pytest.raises(RuntimeError):
         ops.gemm_grouped_skinny(torch.randn(2, 8, 96).cuda(), torch.randn(2, 16, 96).cuda())
 
