@@ -628,7 +628,8 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     }
     hipStream_t st = (hipStream_t)stream;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    if (M <= SKINNY_MAX_ROWS && a_kcontig && b_kcontig && K % 256 == 0 && !accumulate && !a_rowsum &&
+    // (the reduced-precision mode keeps its interior shapes on the bf16 kernel)
+    if (M <= (bf16 ? 64 : SKINNY_MAX_ROWS) && a_kcontig && b_kcontig && K % 256 == 0 && !accumulate && !a_rowsum &&
         al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0) {
         GemmEpilogue eps{C, ldc, bias, residual, ldr, preact, ldp, act, gradz, ldz, gact, nullptr};
         launch_skinny(A, lda, B, ldb, eps, M, N, K, 0, 0, 0, 0, 1, st);

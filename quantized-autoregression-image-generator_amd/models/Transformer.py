@@ -88,18 +88,20 @@ class Transformer(nn.Module):
         """Conditioning of the decoder blocks.  Integer positions (training): a position table
         -- the sinusoid, pos_cond_layer and (inside the blocks) every scale/shift projection
         evaluated once per position 0..P-1 instead of once per token -- whenever that is at
-        least 4x fewer rows; P = pos_bound when the caller knows it (no host sync), else
+        least QF.COND_TABLE_MIN_RATIO (4) times fewer rows; P = pos_bound when the caller knows it (no host sync), else
         max(pos)+1.  Float positions (sampling) keep the per-token form."""
         if QF.USE_COND_TABLE and not pos_cond.dtype.is_floating_point:
             P = int(pos_bound) if pos_bound is not None else int(pos_cond.max().item()) + 1
             # whole 128-row tiles: every GEMM on the table (forward, d-input, d-weight with
             # K = P) then takes the interior kernels; rows past the bound are never indexed
             P = (P + 127) // 128 * 128
-            if 0 < 4 * P <= N * S:
+            if P > 0 and QF.COND_TABLE_MIN_RATIO * P <= N * S:
                 dev = pos_cond.device
                 tab = ops.posemb(torch.arange(P, device=dev), D)
                 tab = _mlp2_forward(self.pos_cond_layer, tab)
+                self._last_cond_form = "table"
                 return QF.CondTable(tab, pos_cond.reshape(-1).to(torch.int32).contiguous(), (N, S))
+        self._last_cond_form = "per_token"
         cond = ops.posemb(pos_cond.flatten(), D).reshape(N, S, D)
         return _mlp2_forward(self.pos_cond_layer, cond)
 

@@ -423,6 +423,9 @@ def mse_loss(pred, target):
 # table) and the per-token consumers index the tables; see csrc/condtable.hip.  False
 # re-enables the reference's per-token evaluation (tests compare the two).
 USE_COND_TABLE = True
+# the table form is taken when it has at least this many times fewer rows than there are
+# tokens (the table is padded to whole 128-row tiles); tests set 0 to force it on tiny shapes
+COND_TABLE_MIN_RATIO = 4
 
 
 class CondTable:

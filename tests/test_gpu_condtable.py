@@ -1,10 +1,10 @@
 """Position-table conditioning (csrc/condtable.hip): the table path must reproduce the
-reference's per-token evaluation -- same logits, same loss, same gradient for EVERY parameter
-(1e-5 relative, summation order only) -- and its building blocks are checked on their own."""
+reference's per-token evaluation -- same logits and loss (1e-5), same gradient for EVERY
+parameter (5e-5 relative: summation order only) -- and its building blocks are checked on their own."""
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import grad_err, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -78,8 +78,9 @@ def test_table_path_equals_per_token_path_for_every_parameter(use_encoder):
     t = torch.randint(0, 41, (N, S), generator=g).cuda()
     pos = (torch.randint(0, total - S + 1, (N, 1), generator=g) + torch.arange(S)[None]).cuda()
     res = {}
+    ratio = QF.COND_TABLE_MIN_RATIO
     for table in (False, True):
-        QF.USE_COND_TABLE = table
+        QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO = table, 0     # tiny shapes: force the table
         try:
             m.zero_grad()
             logits = m(x, e, pos, pos_bound=total if table else None)
@@ -89,16 +90,25 @@ def test_table_path_equals_per_token_path_for_every_parameter(use_encoder):
                           {n: p.grad.detach().clone() for n, p in m.named_parameters()})
         finally:
             QF.USE_COND_TABLE = True
+    assert m._last_cond_form == "table"
     assert rel_err(res[True][0], res[False][0]) < 1e-5
     assert abs(res[True][1] - res[False][1]) < 1e-6 * abs(res[False][1])
     for n, gref in res[False][2].items():
-        if float(gref.abs().max()) == 0.0:
-            assert float(res[True][2][n].abs().max()) == 0.0, n
-        else:
-            assert rel_err(res[True][2][n], gref) < 1e-5, n
+        # the golden tests' gradient bar; the floor covers gradients that are zero in exact
+        # arithmetic (key biases: softmax ignores a constant added to every key) and come out
+        # as 1e-14-sized rounding noise in both forms
+        assert grad_err(res[True][2][n], gref, floor=1e-7) < 5e-5, n
     # without the bound the table is sized from the data (one read-back), same result
-    with torch.no_grad():
-        assert rel_err(m(x, e, pos), m(x, e, pos, pos_bound=total)) < 1e-6
-    # float positions (sampling) keep the per-token form
-    with torch.no_grad():
-        assert rel_err(m(x, e, pos.float()), res[False][0]) < 1e-5
+    try:
+        with torch.no_grad():
+            assert rel_err(m(x, e, pos), m(x, e, pos, pos_bound=total)) < 1e-6
+            assert m._last_cond_form == "table"
+            # float positions (sampling) keep the per-token form
+            assert rel_err(m(x, e, pos.float()), res[False][0]) < 1e-5
+            assert m._last_cond_form == "per_token"
+            # default heuristic: 192 tokens do not pay for a 128-row table
+            QF.COND_TABLE_MIN_RATIO = ratio
+            m(x, e, pos, pos_bound=total)
+            assert m._last_cond_form == "per_token"
+    finally:
+        QF.COND_TABLE_MIN_RATIO = ratio

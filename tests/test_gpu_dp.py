@@ -15,6 +15,17 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _position_table_on():
+    """The workers force the position-table conditioning (production shapes take it by
+    themselves); the in-process reference step must run the same form."""
+    from qarig import functional as QF
+    old = QF.COND_TABLE_MIN_RATIO
+    QF.COND_TABLE_MIN_RATIO = 0
+    yield
+    QF.COND_TABLE_MIN_RATIO = old
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -52,8 +63,10 @@ def _worker(rank, world, port, overlap, q, backend="gloo"):
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from qarig import functional as QF
     from qarig import optim as qoptim
     from qarig import parallel, pipeline
+    QF.COND_TABLE_MIN_RATIO = 0        # position-table conditioning on, as in production shapes
     parallel.init(backend=backend, force=True)
     torch.cuda.set_device(0)
     m = _build().cuda()

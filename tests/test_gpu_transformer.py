@@ -175,8 +175,19 @@ def _build(tag, g):
     return m.cuda()
 
 
+@pytest.fixture(params=[False, True], ids=["per_token_cond", "position_table"])
+def cond_table(request):
+    """Both forms of the conditioning path: the reference's per-token evaluation, and the
+    position table forced on (these shapes are too small for the default heuristic)."""
+    from qarig import functional as QF
+    old = (QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO)
+    QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO = request.param, 0
+    yield request.param
+    QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO = old
+
+
 @pytest.mark.parametrize("tag", TAGS)
-def test_transformer_vs_reference_golden(tag):
+def test_transformer_vs_reference_golden(tag, cond_table):
     """Reference weights + inputs -> logits, loss, every parameter gradient, and the
     weights after one Adam(0.5, 0.999) step, against what the reference produced."""
     from qarig import functional as QF
@@ -207,7 +218,7 @@ def test_transformer_vs_reference_golden(tag):
         assert rel_err(p, g["sd_after_adam"][n]) < 1e-5, n
 
 
-def test_transformer_readme_shape_vs_oracle():
+def test_transformer_readme_shape_vs_oracle(cond_table):
     """README-shaped block sizes (in 512 / hidden 2048 / 64 heads -> head dim 8), 2
     decoder layers, sliding-window conditioning, vs the CPU oracle in fp64."""
     from models.Transformer import Transformer
@@ -243,7 +254,7 @@ def test_transformer_readme_shape_vs_oracle():
     assert torch.equal(got[:, :-1], got2[:, :-1])
 
 
-def test_readme_block_sizes_train_step_grads_vs_oracle():
+def test_readme_block_sizes_train_step_grads_vs_oracle(cond_table):
     """README block sizes (512 / 2048 / 64 heads, window conditioning), 2 decoder layers,
     batch 2 x 256 tokens: loss and parameter gradients of the HIP path (interior GEMM
     kernels, LDS-broadcast attention, fused gradient accumulation) vs the CPU oracle."""
