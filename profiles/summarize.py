@@ -30,12 +30,17 @@ if st:
     shutil.copy(st, os.path.join(here, f"{rnd}_kernel_stats.csv"))
 
 
-def agg(path, counter):
+BIG_GRID = 100000   # work-items: the (N*S)-row GEMMs; the position-table GEMMs launch < 25k
+
+
+def agg(path, counter, big_only=False):
     d = collections.defaultdict(lambda: [0, 0.0])
     if not path:
         return d
     for row in csv.DictReader(open(path)):
         if row["Counter_Name"] != counter:
+            continue
+        if big_only and int(row["Grid_Size"]) < BIG_GRID:
             continue
         k = row["Kernel_Name"]
         d[k][0] += 1
@@ -55,8 +60,10 @@ if f:
             wr = w[k][1] / max(1, w[k][0]) if k in w else 0.0
             fh.write(f"\"{k}\",{n},{fe:.1f},{wr:.1f},{(2 * fe + wr) * 1024:.0f}\n")
     is_gemm = lambda k: "gemm_kernel" in k or "gemm_dma_kernel" in k
-    gf = [(v[0], v[1]) for k, v in f.items() if is_gemm(k)]
-    gw = [(v[0], v[1]) for k, v in w.items() if is_gemm(k)]
+    fb = agg(one(f"{rnd}_pmc_fetch/*/*_counter_collection.csv"), "FETCH_SIZE", big_only=True)
+    wb = agg(one(f"{rnd}_pmc_write/*/*_counter_collection.csv"), "WRITE_SIZE", big_only=True)
+    gf = [(v[0], v[1]) for k, v in fb.items() if is_gemm(k)]
+    gw = [(v[0], v[1]) for k, v in wb.items() if is_gemm(k)]
     n = sum(a for a, _ in gf)
     fetch = sum(b for _, b in gf) / n
     write = sum(b for _, b in gw) / max(1, sum(a for a, _ in gw))
@@ -65,6 +72,7 @@ if f:
                "WRITE_SIZE_KiB_per_launch": round(write, 1),
                "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
                "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE), bench.py --steps 1; "
-                       "reads doubled per the gfx950 FETCH_SIZE calibration"},
+                       "reads doubled per the gfx950 FETCH_SIZE calibration; launches of >= 100k "
+                       "work-items only (the same set bench.py's roofline object averages)"},
               open(os.path.join(here, "gemm_traffic.json"), "w"), indent=1)
 print("ok")
