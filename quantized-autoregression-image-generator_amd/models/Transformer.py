@@ -100,10 +100,27 @@ class Transformer(nn.Module):
                 tab = ops.posemb(torch.arange(P, device=dev), D)
                 tab = _mlp2_forward(self.pos_cond_layer, tab)
                 self._last_cond_form = "table"
-                return QF.CondTable(tab, pos_cond.reshape(-1).to(torch.int32).contiguous(), (N, S))
+                return QF.CondTable(tab, pos_cond.reshape(-1).to(torch.int32).contiguous(), (N, S),
+                                    linears=self._cond_linears())
         self._last_cond_form = "per_token"
         cond = ops.posemb(pos_cond.flatten(), D).reshape(N, S, D)
         return _mlp2_forward(self.pos_cond_layer, cond)
+
+    def _cond_linears(self):
+        """Every nn.Linear that projects `cond` inside the decoder blocks, in layer order."""
+        out = []
+        for layer in self.decoder_layers:
+            blocks = [(layer.self_attn_block, "self_attn_norm", "self_attn_res")]
+            if layer.use_cross_attn:
+                blocks.append((layer.cross_attn_block, "cross_attn_norm", "cross_attn_res"))
+            blocks.append((layer.feedforward_block, "feedforward_norm", "feedforward_res"))
+            for blk, norm_attr, res_attr in blocks:
+                norm, res = getattr(blk, norm_attr), getattr(blk, res_attr)
+                if blk.use_adaln0:
+                    out += [norm.scale_layer.scale, norm.shift_layer.shift]
+                if res.use_scale_layer:
+                    out.append(res.scale_layer.scale)
+        return out
 
     def decode(self, x_dec, enc=None, pos_cond=None, pos_bound=None):
         table = self.dec_embedding.weight

@@ -80,8 +80,8 @@ class AdaLNZero(nn.Module):
 
     def forward(self, x, cond):
         if isinstance(cond, QF.CondTable):     # projections once per position, indexed per token
-            return QF.layernorm_mod_table(x, self.scale_layer(cond.table), self.shift_layer(cond.table),
-                                          cond, self.norm.eps)
+            return QF.layernorm_mod_table(x, cond.projection(self.scale_layer.scale),
+                                          cond.projection(self.shift_layer.shift), cond, self.norm.eps)
         return QF.layernorm_mod(x, self.scale_layer(cond), self.shift_layer(cond), self.norm.eps)
 
 
@@ -187,7 +187,7 @@ class ResidualLinearLayer(nn.Module):
     def forward(self, x, x_skip, cond=None):
         if self.use_scale_layer:
             if isinstance(cond, QF.CondTable):
-                x = QF.mul_table(x, self.scale_layer(cond.table), cond)
+                x = QF.mul_table(x, cond.projection(self.scale_layer.scale), cond)
             else:
                 x = QF.mul(x, self.scale_layer(cond))
         x_skip = self.skip_linear(x_skip)

@@ -431,13 +431,76 @@ COND_TABLE_MIN_RATIO = 4
 class CondTable:
     """What the decoder blocks receive as `cond` in table form: `table` (P,D) = cond of
     position p (differentiable), `idx` int32 (M,) = position of token m, and the row map used
-    to sum per-token gradients back into table rows."""
+    to sum per-token gradients back into table rows.  `linears`: the nn.Linear modules whose
+    projection of the table the blocks are going to ask for (every ScaleLayer/ShiftLayer of the
+    decoder); when the shapes allow they are evaluated up front as ONE grouped launch."""
 
-    def __init__(self, table, idx, shape):
+    def __init__(self, table, idx, shape, linears=()):
         self.table = table
         self.idx = idx
         self.shape = shape                      # (N, S) of the token grid
         self.offsets, self.rows = ops.rowmap_build(idx, table.shape[0])
+        self._proj = {}
+        P, D = table.shape
+        linears = list(linears)
+        if (linears and P <= 512 and D % 256 == 0
+                and all(l.weight.shape == (D, D) and l.bias is not None for l in linears)):
+            params = [t for l in linears for t in (l.weight, l.bias)]
+            outs = _TableProjections.apply(table, *params)
+            self._proj = {id(l): o for l, o in zip(linears, outs)}
+
+    def projection(self, linear):
+        """linear(table) (P, out): from the grouped evaluation when it covered this module."""
+        got = self._proj.get(id(linear))
+        if got is not None:
+            return got
+        return linear_act(self.table, linear.weight, linear.bias)
+
+
+class _TableProjections(torch.autograd.Function):
+    """G projections of the same (P,D) table, out_g = table W_g^T + b_g, as one grouped
+    skinny launch; backward as two GEMMs over the concatenated gradients (d-table with
+    K = G*D, d-weights as one (G*D, D) product) instead of 2G small ones."""
+
+    @staticmethod
+    def forward(ctx, table, *params):
+        require_cuda(table)
+        weights, biases = params[0::2], params[1::2]
+        tab = f32c(table)
+        W = torch.stack([w.detach() for w in weights])             # (G, D, D)
+        b = torch.stack([v.detach() for v in biases])               # (G, D)
+        out = ops.gemm_grouped_skinny(tab, W, b, shared_a=True)     # (G, P, D)
+        ctx.save_for_backward(tab, W)
+        ctx.params = params
+        return tuple(out.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *douts):
+        tab, W = ctx.saved_tensors
+        G, D, _ = W.shape
+        P = tab.shape[0]
+        cols = [f32c(d) if d is not None else torch.zeros((P, D), dtype=torch.float32, device=tab.device)
+                for d in douts]
+        dcat = torch.cat(cols, dim=1)                               # (P, G*D)
+        W2 = W.reshape(G * D, D)
+        dtab = ops.gemm(dcat, W2, a_kcontig=True, b_kcontig=False) if ctx.needs_input_grad[0] else None
+        dW = ops.gemm(dcat, tab, a_kcontig=False, b_kcontig=False,
+                      splitk=ops.pick_splitk(G * D, D, P)).reshape(G, D, D)
+        db = ops.colsum(dcat).reshape(G, D)
+        grads = [dtab]
+        wparams, bparams = ctx.params[0::2], ctx.params[1::2]
+        wslots = [_grad_slot(p) for p in wparams]
+        bslots = [_grad_slot(p) for p in bparams]
+        if all(s is not None for s in wslots) and all(s is not None for s in bslots):
+            torch._foreach_add_(wslots, list(dW.unbind(0)))
+            torch._foreach_add_(bslots, list(db.unbind(0)))
+            for p in ctx.params:
+                _report_done(p)
+            grads += [None] * len(ctx.params)
+        else:
+            for g in range(G):
+                grads += [dW[g], db[g]]
+        return tuple(grads)
 
 
 class _LayerNormModTable(torch.autograd.Function):
