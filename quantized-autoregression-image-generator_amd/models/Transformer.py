@@ -101,15 +101,19 @@ class Transformer(nn.Module):
                 tab = _mlp2_forward(self.pos_cond_layer, tab)
                 self._last_cond_form = "table"
                 return QF.CondTable(tab, pos_cond.reshape(-1).to(torch.int32).contiguous(), (N, S),
-                                    linears=self._cond_linears())
+                                    groups=self._cond_linear_groups())
         self._last_cond_form = "per_token"
         cond = ops.posemb(pos_cond.flatten(), D).reshape(N, S, D)
         return _mlp2_forward(self.pos_cond_layer, cond)
 
-    def _cond_linears(self):
-        """Every nn.Linear that projects `cond` inside the decoder blocks, in layer order."""
-        out = []
+    def _cond_linear_groups(self):
+        """The nn.Linear modules that project `cond` inside the decoder blocks, grouped for the
+        grouped launches of the position table: ONE group (all layers) on a single GPU; one group
+        per decoder layer under data parallelism, so that each layer's projection gradients
+        are final when that layer's backward is and its all-reduce bucket can leave early."""
+        per_layer = []
         for layer in self.decoder_layers:
+            out = []
             blocks = [(layer.self_attn_block, "self_attn_norm", "self_attn_res")]
             if layer.use_cross_attn:
                 blocks.append((layer.cross_attn_block, "cross_attn_norm", "cross_attn_res"))
@@ -120,7 +124,15 @@ class Transformer(nn.Module):
                     out += [norm.scale_layer.scale, norm.shift_layer.shift]
                 if res.use_scale_layer:
                     out.append(res.scale_layer.scale)
-        return out
+            per_layer.append(out)
+        mode = QF.COND_TABLE_GROUPING
+        if mode is None:
+            import torch.distributed as dist
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            mode = "layer" if multi else "all"
+        if mode == "layer":
+            return per_layer
+        return [[l for group in per_layer for l in group]]
 
     def decode(self, x_dec, enc=None, pos_cond=None, pos_bound=None):
         table = self.dec_embedding.weight

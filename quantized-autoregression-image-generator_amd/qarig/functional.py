@@ -426,35 +426,51 @@ USE_COND_TABLE = True
 # the table form is taken when it has at least this many times fewer rows than there are
 # tokens (the table is padded to whole 128-row tiles); tests set 0 to force it on tiny shapes
 COND_TABLE_MIN_RATIO = 4
+# grouped evaluation of the table projections: "all" (one launch for every decoder layer),
+# "layer" (one per layer: gradients final in layer order, for the overlapped data-parallel
+# all-reduce) or None = "layer" under torch.distributed with more than one rank, else "all"
+COND_TABLE_GROUPING = None
 
 
 class CondTable:
     """What the decoder blocks receive as `cond` in table form: `table` (P,D) = cond of
     position p (differentiable), `idx` int32 (M,) = position of token m, and the row map used
-    to sum per-token gradients back into table rows.  `linears`: the nn.Linear modules whose
-    projection of the table the blocks are going to ask for (every ScaleLayer/ShiftLayer of the
-    decoder); when the shapes allow they are evaluated up front as ONE grouped launch."""
+    to sum per-token gradients back into table rows.  `groups`: lists of nn.Linear modules
+    (ScaleLayer/ShiftLayer of the decoder blocks) whose projections of the table are evaluated
+    together as one grouped launch per list when the shapes allow."""
 
-    def __init__(self, table, idx, shape, linears=()):
+    def __init__(self, table, idx, shape, groups=()):
         self.table = table
         self.idx = idx
         self.shape = shape                      # (N, S) of the token grid
         self.offsets, self.rows = ops.rowmap_build(idx, table.shape[0])
         self._proj = {}
+        self._group_of = {}
         P, D = table.shape
-        linears = list(linears)
-        if (linears and P <= 512 and D % 256 == 0
-                and all(l.weight.shape == (D, D) and l.bias is not None for l in linears)):
-            params = [t for l in linears for t in (l.weight, l.bias)]
-            outs = _TableProjections.apply(table, *params)
-            self._proj = {id(l): o for l, o in zip(linears, outs)}
+        for group in groups:
+            group = list(group)
+            if (group and P <= 512 and D % 256 == 0
+                    and all(l.weight.shape == (D, D) and l.bias is not None for l in group)):
+                for l in group:
+                    self._group_of[id(l)] = group
 
     def projection(self, linear):
-        """linear(table) (P, out): from the grouped evaluation when it covered this module."""
+        """linear(table) (P, out).  Linears registered in a group are evaluated together, as one
+        grouped launch, the first time any of them is asked for -- i.e. inside the forward of the
+        layer that owns them, so that in backward the group's gradient node runs right after that
+        layer's and its parameters' gradients are final in layer order (what the overlapped
+        data-parallel all-reduce buckets rely on)."""
         got = self._proj.get(id(linear))
         if got is not None:
             return got
-        return linear_act(self.table, linear.weight, linear.bias)
+        group = self._group_of.get(id(linear))
+        if group is None:
+            return linear_act(self.table, linear.weight, linear.bias)
+        params = [t for l in group for t in (l.weight, l.bias)]
+        outs = _TableProjections.apply(self.table, *params)
+        for l, o in zip(group, outs):
+            self._proj[id(l)] = o
+        return self._proj[id(linear)]
 
 
 class _TableProjections(torch.autograd.Function):

@@ -112,3 +112,50 @@ def test_table_path_equals_per_token_path_for_every_parameter(use_encoder):
             assert m._last_cond_form == "per_token"
     finally:
         QF.COND_TABLE_MIN_RATIO = ratio
+
+
+@pytest.mark.parametrize("grouping", ["all", "layer"])
+def test_grouped_table_projections_match_per_token_path(grouping):
+    """D = 256: the table projections run as grouped launches (one for the whole decoder, or one
+    per layer as under data parallelism) with the two-GEMM backward; every parameter gradient
+    must still match the per-token evaluation."""
+    from models.Transformer import Transformer
+    from qarig import functional as QF
+    torch.manual_seed(7)
+    m = Transformer(use_encoder=False, use_pos_cond=True, num_enc_layers=None, num_dec_layers=3,
+                    num_enc_embedding=None, num_dec_embedding=60, self_attn_heads=32,
+                    cross_attn_heads=None, transformer_in_dim=256, transformer_out_dim=41,
+                    transformer_hidden_dim=512).cuda()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.abs().max() == 0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    N, S, total = 8, 64, 100
+    x = torch.randint(0, 60, (N, S), generator=g).cuda()
+    t = torch.randint(0, 41, (N, S), generator=g).cuda()
+    pos = (torch.randint(0, total - S + 1, (N, 1), generator=g) + torch.arange(S)[None]).cuda()
+    old = (QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO, QF.COND_TABLE_GROUPING)
+    res = {}
+    try:
+        for table in (False, True):
+            QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO, QF.COND_TABLE_GROUPING = table, 0, grouping
+            m.zero_grad()
+            calls = []
+            orig = QF._TableProjections.apply
+            if table:
+                QF._TableProjections.apply = staticmethod(lambda *a: (calls.append(len(a)), orig(*a))[1])
+            try:
+                logits = m(x, None, pos, pos_bound=total)
+                loss = QF.cross_entropy(logits.view(-1, 41), t.flatten())
+                loss.backward()
+            finally:
+                QF._TableProjections.apply = orig
+            if table:     # 6 projections (12 parameters + the table) per base decoder layer
+                assert calls == ([1 + 12 * 3] if grouping == "all" else [13, 13, 13]), calls
+            res[table] = (logits.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+    finally:
+        QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO, QF.COND_TABLE_GROUPING = old
+    assert rel_err(res[True][0], res[False][0]) < 1e-5
+    for n, gref in res[False][1].items():
+        assert grad_err(res[True][1][n], gref, floor=1e-7) < 5e-5, n
