@@ -89,6 +89,8 @@ __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_fwd_kernel(
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * (gamma | scale | 1)
 // dy_xhat (optional) = dy * xhat: AdaLN's d(scale), or the column-summed d(gamma).
+// NV as in the forward kernel: D == NV * 256, 16-B aligned: x and dy are read once into registers.
+template <int NV>
 __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_in,
     const float* __restrict__ rstd_in, const float* __restrict__ gamma,
@@ -100,6 +102,39 @@ __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_bwd_kernel(
     const int64_t off = (int64_t)row * D;
     const int64_t moff = (int64_t)(mod_idx ? mod_idx[row] : row) * D;
     const float mean = mean_in[row], rstd = rstd_in[row];
+    if (NV > 0) {
+        float4 h[NV > 0 ? NV : 1], d[NV > 0 ? NV : 1], g[NV > 0 ? NV : 1];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const float4 xv = *reinterpret_cast<const float4*>(x + off + c);
+            d[i] = *reinterpret_cast<const float4*>(dy + off + c);
+            h[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd,
+                               (xv.w - mean) * rstd);
+            float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (gamma) m = *reinterpret_cast<const float4*>(gamma + c);
+            else if (scale) m = *reinterpret_cast<const float4*>(scale + moff + c);
+            g[i] = (gamma || scale) ? make_float4(d[i].x * m.x, d[i].y * m.y, d[i].z * m.z, d[i].w * m.w)
+                                    : d[i];
+            s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+            s2 = fmaf(g[i].x, h[i].x, s2); s2 = fmaf(g[i].y, h[i].y, s2);
+            s2 = fmaf(g[i].z, h[i].z, s2); s2 = fmaf(g[i].w, h[i].w, s2);
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            *reinterpret_cast<float4*>(dx + off + c) =
+                make_float4(rstd * ((g[i].x - s1) - h[i].x * s2), rstd * ((g[i].y - s1) - h[i].y * s2),
+                            rstd * ((g[i].z - s1) - h[i].z * s2), rstd * ((g[i].w - s1) - h[i].w * s2));
+            if (dy_xhat)
+                *reinterpret_cast<float4*>(dy_xhat + off + c) =
+                    make_float4(d[i].x * h[i].x, d[i].y * h[i].y, d[i].z * h[i].z, d[i].w * h[i].w);
+        }
+        return;
+    }
     float s1 = 0.0f, s2 = 0.0f;
     for (int c = lane; c < D; c += 64) {
         const float h = (x[off + c] - mean) * rstd;
@@ -157,9 +192,20 @@ extern "C" int qarig_layernorm_bwd(const float* dy, const float* x, const float*
                                    void* stream) {
     QARIG_CHECK_ARG(dy && x && mean && rstd && dx && M > 0 && D > 0, "layernorm_bwd: bad arguments");
     QARIG_CHECK_ARG(!(gamma && scale), "layernorm_bwd: affine and AdaLN forms are exclusive");
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + LN_WAVES - 1) / LN_WAVES),
-                       dim3(LN_WAVES * 64), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, scale,
-                       mod_idx, M, D, dx, dy_xhat);
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    const bool vec = D % 256 == 0 && al16(dy) && al16(x) && al16(gamma) && al16(scale) && al16(dx) &&
+                     al16(dy_xhat);
+    const dim3 grid((M + LN_WAVES - 1) / LN_WAVES), block(LN_WAVES * 64);
+#define QARIG_LNB_LAUNCH(NV)                                                                       \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), grid, block, 0, (hipStream_t)stream, dy, x, mean, \
+                       rstd, gamma, scale, mod_idx, M, D, dx, dy_xhat)
+    switch (vec ? D / 256 : 0) {
+        case 1: QARIG_LNB_LAUNCH(1); break;
+        case 2: QARIG_LNB_LAUNCH(2); break;
+        case 4: QARIG_LNB_LAUNCH(4); break;
+        default: QARIG_LNB_LAUNCH(0); break;
+    }
+#undef QARIG_LNB_LAUNCH
     QARIG_CHECK_LAUNCH("layernorm_bwd");
     return QARIG_OK;
 }
