@@ -34,12 +34,21 @@ def _free_port():
     return p
 
 
+WIDE = False     # True: D = 256 -> the position-table projections run as grouped launches
+
+
 def _build():
     from models.Transformer import Transformer
     torch.manual_seed(11)
-    m = Transformer(use_encoder=True, use_pos_cond=True, num_enc_layers=1, num_dec_layers=2,
-                    num_enc_embedding=24, num_dec_embedding=40, self_attn_heads=4, cross_attn_heads=2,
-                    transformer_in_dim=32, transformer_out_dim=33, transformer_hidden_dim=64)
+    if WIDE:
+        m = Transformer(use_encoder=True, use_pos_cond=True, num_enc_layers=1, num_dec_layers=2,
+                        num_enc_embedding=24, num_dec_embedding=40, self_attn_heads=32,
+                        cross_attn_heads=32, transformer_in_dim=256, transformer_out_dim=33,
+                        transformer_hidden_dim=512)
+    else:
+        m = Transformer(use_encoder=True, use_pos_cond=True, num_enc_layers=1, num_dec_layers=2,
+                        num_enc_embedding=24, num_dec_embedding=40, self_attn_heads=4, cross_attn_heads=2,
+                        transformer_in_dim=32, transformer_out_dim=33, transformer_hidden_dim=64)
     g = torch.Generator().manual_seed(3)
     with torch.no_grad():
         for p in m.parameters():
@@ -56,7 +65,9 @@ def _data():
             torch.randint(0, 50, (N, 1), generator=g) + torch.arange(S)[None])
 
 
-def _worker(rank, world, port, overlap, q, backend="gloo"):
+def _worker(rank, world, port, overlap, q, backend="gloo", wide=False):
+    global WIDE
+    WIDE = wide
     from conftest import PKG, ROOT
     for p in (ROOT, PKG):
         if p not in sys.path:
@@ -70,7 +81,7 @@ def _worker(rank, world, port, overlap, q, backend="gloo"):
     parallel.init(backend=backend, force=True)
     torch.cuda.set_device(0)
     m = _build().cuda()
-    qoptim.BUCKET_ELEMS = 20_000                 # several buckets on this tiny model
+    qoptim.BUCKET_ELEMS = 400_000 if wide else 20_000    # several buckets on these small models
     opt = qoptim.FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
     parallel.broadcast_params(opt.flat_param)
     if overlap:
@@ -85,10 +96,15 @@ def _worker(rank, world, port, overlap, q, backend="gloo"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_dp2_step_equals_single_process(overlap):
+@pytest.mark.parametrize("overlap,wide", [(False, False), (True, False), (True, True)])
+def test_dp2_step_equals_single_process(overlap, wide):
+    """wide: the workers' position-table projections are grouped per decoder layer (what
+    torch.distributed with 2 ranks selects) and report their parameters to the overlapped
+    all-reduce from the grouped backward; the reference step groups them in one launch."""
+    global WIDE
     from qarig import pipeline
     from qarig.optim import FlatAdam
+    WIDE = wide
     m = _build().cuda()
     opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
     x, e, t, pos = (v.cuda() for v in _data())
@@ -99,7 +115,7 @@ def test_dp2_step_equals_single_process(overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q, "gloo", wide)) for r in range(2)]
     for p in procs:
         p.start()
     import queue
@@ -126,8 +142,10 @@ def test_rccl_single_rank_overlapped_allreduce_path():
     all-reduces issued from the backward thread and their stream ordering against the
     fused gradient kernels and the Adam launch.  A sum over one rank is the identity, so the
     weights must equal a step without any exchange bit for bit."""
+    global WIDE
     from qarig import pipeline
     from qarig.optim import FlatAdam
+    WIDE = False
     m = _build().cuda()
     opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
     x, e, t, pos = (v.cuda() for v in _data())
