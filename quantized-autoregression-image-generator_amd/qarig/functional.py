@@ -6,6 +6,8 @@ Saved-tensor policy: HBM is 288 GB per GPU, so every pre-activation that a backw
 needs is kept (no recompute); compatible with torch.utils.checkpoint(use_reentrant=
 False) for the reference's --use-activation-checkpoint flag.
 """
+import os
+
 import torch
 
 from . import ops
@@ -429,7 +431,7 @@ COND_TABLE_MIN_RATIO = 4
 # grouped evaluation of the table projections: "all" (one launch for every decoder layer),
 # "layer" (one per layer: gradients final in layer order, for the overlapped data-parallel
 # all-reduce) or None = "layer" under torch.distributed with more than one rank, else "all"
-COND_TABLE_GROUPING = None
+COND_TABLE_GROUPING = os.environ.get("QARIG_COND_GROUPING") or None
 
 
 class CondTable:
@@ -441,9 +443,12 @@ class CondTable:
 
     def __init__(self, table, idx, shape, groups=()):
         self.table = table
-        self.idx = idx
         self.shape = shape                      # (N, S) of the token grid
+        # positions outside [0, P) raise the device index flag here (the host turns it into an
+        # IndexError at its next check, as for embedding ids); the consumers read through a
+        # clamped copy so that such a batch cannot address memory outside the tables
         self.offsets, self.rows = ops.rowmap_build(idx, table.shape[0])
+        self.idx = idx.clamp(0, table.shape[0] - 1)
         self._proj = {}
         self._group_of = {}
         P, D = table.shape

@@ -159,3 +159,16 @@ def test_grouped_table_projections_match_per_token_path(grouping):
     assert rel_err(res[True][0], res[False][0]) < 1e-5
     for n, gref in res[False][1].items():
         assert grad_err(res[True][1][n], gref, floor=1e-7) < 5e-5, n
+
+
+def test_out_of_range_positions_are_flagged_not_dereferenced():
+    from qarig import functional as QF
+    from qarig import ops
+    tab = torch.randn((128, 256)).cuda()
+    idx = torch.arange(200, dtype=torch.int32).cuda() - 20          # -20 .. 179, P = 128
+    cond = QF.CondTable(tab, idx, (1, 200))
+    assert int(cond.idx.min()) == 0 and int(cond.idx.max()) == 127
+    y = QF.mul_table(torch.ones((1, 200, 256)).cuda(), tab, cond)
+    assert torch.equal(y[0, 50], tab[30])
+    with pytest.raises(IndexError):
+        ops.check_index_flag(torch.device("cuda"), "positions")
