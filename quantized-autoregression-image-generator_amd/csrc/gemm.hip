@@ -655,7 +655,8 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     // measured (tools/gemm_bench.py): the DMA kernel wins on long reductions and narrow outputs
     // (+5..10 %), the register-staged one on K=512 x N=2048 (its epilogue overlaps better
     // there), so pick per shape
-    const bool dma_shape = per >= 1024 || N <= 512;
+    static const bool dma_all = []() { const char* e = getenv("QARIG_GEMM_DMA_ALL"); return e && e[0] == '1'; }();
+    const bool dma_shape = dma_all || per >= 1024 || N <= 512;
     if (bf16 && fast && vec_epi && !a_rowsum && K % HK == 0 && per % HK == 0) {
         if (a_kcontig && b_kcontig)
             hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
