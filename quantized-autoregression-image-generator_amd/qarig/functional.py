@@ -292,6 +292,12 @@ class _EmbeddingPos(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (ids,) = ctx.saved_tensors
+        D = dy.shape[-1]
+        if ids.numel() >= 4096 and D % 4 == 0:
+            # many tokens per vocabulary row: row map once, then each table row sums its own
+            # tokens (reads dy once) instead of every row scanning the whole id stream
+            off, rows = ops.rowmap_build(ids.reshape(-1).to(torch.int32), ctx.V)
+            return None, ops.segment_sum(_2d(f32c(dy)), off, rows), None
         return None, ops.embedding_bwd(ids, dy, ctx.V), None
 
 

@@ -172,3 +172,18 @@ def test_out_of_range_positions_are_flagged_not_dereferenced():
     assert torch.equal(y[0, 50], tab[30])
     with pytest.raises(IndexError):
         ops.check_index_flag(torch.device("cuda"), "positions")
+
+
+def test_embedding_gradient_by_row_map_matches_index_add():
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(3)
+    N, S, V, D = 32, 256, 100, 64                      # 8192 tokens: the row-map path
+    ids = torch.randint(0, V, (N, S), generator=g).cuda()
+    table = torch.randn((V, D), generator=g).cuda().requires_grad_(True)
+    pe = torch.randn((S, D), generator=g).cuda()
+    gy = torch.randn((N, S, D), generator=g).cuda()
+    y = QF.embedding_pos(ids, table, pe)
+    (got,) = torch.autograd.grad(y, table, gy)
+    want = torch.zeros((V, D), dtype=torch.float64).index_add_(0, ids.cpu().reshape(-1),
+                                                                 gy.double().cpu().reshape(-1, D))
+    assert rel_err(got, want) < 2e-6
