@@ -462,15 +462,135 @@ __global__ void bmu_direct_kernel(PatchGeom g, const float* __restrict__ w, int 
     out[row] = idx;
 }
 
+
+// ---------------------------------------------------------------------------------
+// Few patch rows, long patches (the conditional codebook: one 4096-element patch per latent,
+// 64 rows per batch).  The 128x128 MFMA tiling finds 4 workgroups there, each walking a
+// 4096-deep reduction alone (0.59 ms).  The work is tiny (rows*K*D = 134 M fma), so it runs
+// on the vector ALU instead, one (row, code) pair per lane with the SAME k-ordered chains as
+// the MFMA form (an MFMA accumulates in k order with one rounding per fma, so
+// fmaf(-2 w_e, x_e, acc) over ascending e is bit-identical): 8 x 8 pairs per 64-lane workgroup,
+// operands through LDS in 128-element chunks, every lane carrying its own |w|^2 and |x|^2
+// chains (the first pair row / column publishes them).  acc (rows x K), w2 (K) and x2 (rows) go to the workspace; the
+// second kernel takes sqrt(max((acc + w2) + x2, 0)) and the first minimum per row.
+constexpr int FR_CH = 128;    // elements per staged chunk
+constexpr int FR_T = 8;       // 8 rows x 8 codes per 64-lane workgroup: 512 workgroups at 64 x 512
+constexpr int FR_LD = FR_CH + 4;   // 16-B aligned rows, lanes of different codes on different banks
+__global__ __launch_bounds__(64) void bmu_fewrows_dot_kernel(PatchGeom g, const float* __restrict__ w,
+                                                             int K, float* __restrict__ acc_out,
+                                                             float* __restrict__ w2_out,
+                                                             float* __restrict__ x2_out) {
+    __shared__ __attribute__((aligned(16))) float xs[FR_T][FR_LD];
+    __shared__ __attribute__((aligned(16))) float ws[FR_T][FR_LD];
+    const int tid = threadIdx.x;
+    const int c = tid & 7, r = tid >> 3;
+    const int code0 = blockIdx.x * FR_T, row0 = blockIdx.y * FR_T;
+    // staging: lane -> (tile row tid >> 3, 16 consecutive elements at (tid & 7) * 16)
+    const int sr = tid >> 3, se = (tid & 7) * 16;
+    const int srow = row0 + sr, scode = code0 + sr;
+    const int64_t rbase = srow < g.R ? patch_row_base(g, srow) : 0;
+    const bool xvec = (g.pW & 3) == 0 && (g.W & 3) == 0 && (((uintptr_t)g.x) & 15) == 0;
+    const bool wvec = (g.D & 3) == 0 && (((uintptr_t)w) & 15) == 0;
+    float acc = 0.0f, w2 = 0.0f, x2 = 0.0f;
+    for (int e0 = 0; e0 < g.D; e0 += FR_CH) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {
+            const int e = e0 + se + q;
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), wv = xv;
+            if (srow < g.R) {
+                if (xvec && e + 3 < g.D) {
+                    const int j = e % g.pW, t = e / g.pW;
+                    const int i = t % g.pH, ch = t / g.pH;
+                    xv = *reinterpret_cast<const float4*>(g.x + rbase + ((int64_t)ch * g.H + i) * g.W + j);
+                } else {
+                    float t4[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int u = 0; u < 4; ++u)
+                        if (e + u < g.D) {
+                            const int j = (e + u) % g.pW, t = (e + u) / g.pW;
+                            const int i = t % g.pH, ch = t / g.pH;
+                            t4[u] = g.x[rbase + ((int64_t)ch * g.H + i) * g.W + j];
+                        }
+                    xv = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                }
+            }
+            if (scode < K) {
+                const float* wp = w + (int64_t)scode * g.D + e;
+                if (wvec && e + 3 < g.D) wv = *reinterpret_cast<const float4*>(wp);
+                else
+                    wv = make_float4(e < g.D ? wp[0] : 0.f, e + 1 < g.D ? wp[1] : 0.f,
+                                     e + 2 < g.D ? wp[2] : 0.f, e + 3 < g.D ? wp[3] : 0.f);
+            }
+            *reinterpret_cast<float4*>(&xs[sr][se + q]) = xv;
+            *reinterpret_cast<float4*>(&ws[sr][se + q]) = wv;
+        }
+        __syncthreads();
+        // zero padding past D contributes fmaf(-0, 0, acc) = acc and fmaf(0, 0, n2) = n2: exact
+#pragma unroll 8
+        for (int e = 0; e < FR_CH; e += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(&xs[r][e]);
+            const float4 wv = *reinterpret_cast<const float4*>(&ws[c][e]);
+            acc = fmaf(-2.0f * wv.x, xv.x, acc);
+            acc = fmaf(-2.0f * wv.y, xv.y, acc);
+            acc = fmaf(-2.0f * wv.z, xv.z, acc);
+            acc = fmaf(-2.0f * wv.w, xv.w, acc);
+            w2 = fmaf(wv.x, wv.x, w2); w2 = fmaf(wv.y, wv.y, w2);
+            w2 = fmaf(wv.z, wv.z, w2); w2 = fmaf(wv.w, wv.w, w2);
+            x2 = fmaf(xv.x, xv.x, x2); x2 = fmaf(xv.y, xv.y, x2);
+            x2 = fmaf(xv.z, xv.z, x2); x2 = fmaf(xv.w, xv.w, x2);
+        }
+    }
+    const int row = row0 + r, code = code0 + c;
+    if (row < g.R && code < K) acc_out[(int64_t)row * K + code] = acc;
+    if (r == 0 && blockIdx.y == 0 && code < K) w2_out[code] = w2;
+    if (c == 0 && blockIdx.x == 0 && row < g.R) x2_out[row] = x2;
+}
+
+__global__ __launch_bounds__(256) void bmu_fewrows_argmin_kernel(const float* __restrict__ acc, int K,
+                                                                 const float* __restrict__ w2,
+                                                                 const float* __restrict__ x2,
+                                                                 int64_t* __restrict__ out) {
+    __shared__ float bd[256];
+    __shared__ int bi[256];
+    const int row = blockIdx.x;
+    const float xx = x2[row];
+    float best = INFINITY;
+    int idx = INT_MAX;
+    for (int k = threadIdx.x; k < K; k += 256) {          // ascending k per lane: strict < keeps the first
+        const float d = sqrtf(fmaxf((acc[(int64_t)row * K + k] + w2[k]) + xx, 0.0f));
+        if (d < best) { best = d; idx = k; }
+    }
+    bd[threadIdx.x] = best;
+    bi[threadIdx.x] = idx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const float od = bd[threadIdx.x + o];
+            const int oi = bi[threadIdx.x + o];
+            if (od < bd[threadIdx.x] || (od == bd[threadIdx.x] && oi < bi[threadIdx.x])) {
+                bd[threadIdx.x] = od;
+                bi[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[row] = bi[0] == INT_MAX ? 0 : (int64_t)bi[0];
+}
+
 }  // namespace qarig
 
 using namespace qarig;
 
 static int bmu_code_tiles(int K) { return (K + BM - 1) / BM; }
 
+static constexpr int FEWROWS_MAX = 128, FEWROWS_MIN_D = 512;
+
 extern "C" size_t qarig_bmu_workspace_bytes(int64_t rows, int K) {
     // per-split (min, idx, second) partials for up to code_tiles splits + |x|^2 per row
-    return (size_t)bmu_code_tiles(K) * (size_t)rows * 12 + (size_t)rows * 4 + 64;
+    size_t need = (size_t)bmu_code_tiles(K) * (size_t)rows * 12 + (size_t)rows * 4 + 64;
+    // few-rows form: rows x K dot products + |w|^2 + |x|^2
+    if (rows <= FEWROWS_MAX) need = need > ((size_t)rows * K + K + rows) * 4 ? need : ((size_t)rows * K + K + rows) * 4;
+    return need;
 }
 
 extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH, int pW,
@@ -497,6 +617,17 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
         qarig_set_error("bmu: workspace too small (%zu < %zu)", ws_bytes,
                         qarig_bmu_workspace_bytes(rows, K));
         return QARIG_ERR_WORKSPACE;
+    }
+    if (g.R <= FEWROWS_MAX && D >= FEWROWS_MIN_D) {
+        float* acc = (float*)workspace;
+        float* w2 = acc + (size_t)g.R * K;
+        float* x2 = w2 + K;
+        hipLaunchKernelGGL(bmu_fewrows_dot_kernel, dim3((K + 7) / 8, (g.R + 7) / 8), dim3(64), 0, st, g,
+                           codebook, K, acc, w2, x2);
+        QARIG_CHECK_LAUNCH("bmu fewrows dot");
+        hipLaunchKernelGGL(bmu_fewrows_argmin_kernel, dim3(g.R), dim3(256), 0, st, acc, K, w2, x2, out_idx);
+        QARIG_CHECK_LAUNCH("bmu fewrows argmin");
+        return QARIG_OK;
     }
     float* part_d = (float*)workspace;
     int* part_i = (int*)(part_d + (size_t)bmu_code_tiles(K) * g.R);
