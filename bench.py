@@ -168,6 +168,9 @@ def main():
                     help="f32 = the parity mode and the headline number; bf16 = opt-in reduced "
                          "precision (Linear GEMMs on the bf16 MFMA, fp32 accumulate/storage), "
                          "reported under its own workload name, never as the headline")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole training step from a captured HIP graph (single GPU; "
+                         "helps launch-bound per-GPU batches such as --config c4)")
     ap.add_argument("--config", choices=["c2", "c4"], default="c2",
                     help="c2 (default, the headline workload) or the config-4 per-GPU shard")
     args = ap.parse_args()
@@ -199,8 +202,13 @@ def main():
     nwin = pipeline.num_windows(seq, cfg["window"])
     rng = torch.Generator().manual_seed(4)
 
+    graphed = pipeline.GraphedTrainStep(model, optim, lr_cb, hr_cb, cfg["base"], cfg["window"]) \
+        if args.graph else None
+
     def step():
         rand = parallel.shard(torch.randint(0, nwin, (N * world,), generator=rng))
+        if graphed is not None:
+            return graphed(z, rand)
         hr_in, lr_in, hr_tg = pipeline.tokenize(z, lr_cb, hr_cb, train_base_model=cfg["base"])
         hr_in, hr_tg, pos = pipeline.slide(hr_in, hr_tg, cfg["window"], rand)
         return pipeline.train_step(model, optim, hr_in, lr_in, hr_tg, pos, pos_bound=seq)
@@ -239,7 +247,8 @@ def main():
                       "batch_per_gpu": N, "global_batch": N * world, "seq_len": cfg["window"],
                       "in_dim": cfg["in_dim"], "hidden_dim": cfg["hidden"], "heads": cfg["heads"],
                       "dec_layers": cfg["dec_layers"], "params": int(optim.total),
-                      "parallelism": f"dp{world}", "loss": round(loss_val, 5)}}
+                      "parallelism": f"dp{world}", "loss": round(loss_val, 5),
+                      "launch": "captured HIP graph replay" if args.graph else "eager stream launches"}}
     if rank == 0:
         if events:
             times = [(e[0], e[1].elapsed_time(e[2])) for e in events]

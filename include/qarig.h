@@ -206,10 +206,12 @@ size_t qarig_mse_workspace_bytes(void);
 int qarig_mse_fwd(const float* pred, const float* target, int64_t n, float* loss, float* dpred,
                   float* part_ws, void* stream);
 
-/* torch.optim.Adam step on a flat buffer -- train_quantized_transformer.py:317-320. */
+/* torch.optim.Adam step on a flat buffer -- train_quantized_transformer.py:317-320.
+ * dev_step (optional device float[2] = {lr / (1 - beta1^t), sqrt(1 - beta2^t)}) overrides the two
+ * per-step scalars (graph replay). */
 int qarig_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
                     float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale,
-                    void* stream);
+                    const float* dev_step, void* stream);
 
 /* elementwise helpers (ResidualLinearLayer gate, models/layers.py:293-295) */
 int qarig_mul_fwd(const float* a, const float* b, float* y, int64_t n, void* stream);

@@ -10,7 +10,11 @@ namespace qarig {
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                             float* __restrict__ m, float* __restrict__ v, int64_t n, float beta1,
                             float beta2, float eps, float step_size, float bc2_sqrt,
-                            float grad_scale) {
+                            float grad_scale, const float* __restrict__ dev_step) {
+    if (dev_step) {     // captured-graph replay: the per-step scalars live in device memory
+        step_size = dev_step[0];
+        bc2_sqrt = dev_step[1];
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * grad_scale;
@@ -33,15 +37,17 @@ using namespace qarig;
 
 // step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t), both computed by the
 // host in double as torch does.  grad_scale multiplies g first (1/world after a sum
-// all-reduce; 1 otherwise).
+// all-reduce; 1 otherwise).  dev_step (optional, device, 2 floats {step_size, bc2_sqrt}) overrides
+// the two per-step scalars, so that a captured graph of the training step can be replayed while
+// the host refreshes them between replays.
 extern "C" int qarig_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
                                float beta2, float eps, float step_size, float bc2_sqrt,
-                               float grad_scale, void* stream) {
+                               float grad_scale, const float* dev_step, void* stream) {
     QARIG_CHECK_ARG(p && g && m && v && n > 0, "adam: bad arguments");
     int64_t b = (n + 255) / 256;
     if (b > 8192) b = 8192;
     hipLaunchKernelGGL(adam_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
-                       beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
+                       beta1, beta2, eps, step_size, bc2_sqrt, grad_scale, dev_step);
     QARIG_CHECK_LAUNCH("adam");
     return QARIG_OK;
 }

@@ -453,9 +453,10 @@ def cross_entropy_fwd(logits2d, target, want_grad=True):
     return loss, dl
 
 
-def adam_step(p, g, m, v, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale=1.0):
+def adam_step(p, g, m, v, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale=1.0, dev_step=None):
     check(_lib.load().qarig_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), beta1, beta2, eps,
-                                      step_size, bc2_sqrt, grad_scale, stream()), "qarig_adam_step")
+                                      step_size, bc2_sqrt, grad_scale, ptr(dev_step), stream()),
+          "qarig_adam_step")
 
 
 def mul_fwd(a, b):

@@ -118,14 +118,38 @@ class FlatAdam:
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
 
     @torch.no_grad()
+    def _step_scalars(self, step):
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        return g["lr"] / (1 - b1 ** step), math.sqrt(1 - b2 ** step)
+
     def step(self, grad_scale=1.0):
         self.step_count += 1
         g = self.param_groups[0]
         b1, b2 = g["betas"]
-        bc1 = 1 - b1 ** self.step_count
-        bc2 = 1 - b2 ** self.step_count
+        step_size, bc2_sqrt = self._step_scalars(self.step_count)
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, b1, b2,
-                      g["eps"], g["lr"] / bc1, math.sqrt(bc2), grad_scale)
+                      g["eps"], step_size, bc2_sqrt, grad_scale)
+
+    # -- graph replay (qarig.pipeline.GraphedTrainStep) -----------------------------------
+    def _dev_step_buffer(self):
+        if not hasattr(self, "_dev_step"):
+            self._dev_step = torch.zeros(2, dtype=torch.float32, device=self.flat_param.device)
+        return self._dev_step
+
+    def step_captured(self, grad_scale=1.0):
+        """The Adam launch as it is recorded into a captured training-step graph: step size and
+        bias correction are read from a device buffer that `advance_captured` refreshes on the
+        host before every replay (learning-rate changes included)."""
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, b1, b2,
+                      g["eps"], 0.0, 1.0, grad_scale, dev_step=self._dev_step_buffer())
+
+    def advance_captured(self):
+        self.step_count += 1
+        step_size, bc2_sqrt = self._step_scalars(self.step_count)
+        self._dev_step_buffer().copy_(torch.tensor([step_size, bc2_sqrt], dtype=torch.float32))
 
     def state_dict(self):
         state = {}

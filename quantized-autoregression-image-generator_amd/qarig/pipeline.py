@@ -55,3 +55,68 @@ def train_step(model, optim, hr_input, lr_input, hr_target, pos_idx, dp=True, po
         parallel.allreduce_flat(optim.flat_grad)
     optim.step(grad_scale=1.0 / w)
     return loss
+
+
+class GraphedTrainStep:
+    """The whole training step -- BMU tokenisation, window slicing, forward, cross-entropy,
+    backward, Adam -- captured ONCE into a HIP graph (torch.cuda.CUDAGraph over the library's
+    stream launches and torch's own small kernels) and replayed per batch.
+
+    For per-GPU batches of a few thousand tokens (BASELINE config 4 hands each GPU 8 sequences)
+    the step is ~1,700 launches of 20-60 us kernels and the Python issue rate, not the GPU, sets
+    the step time; replay removes the host from the loop.  At config 2's 16 k tokens the step is
+    GPU-bound already and this changes nothing.
+
+    What varies between steps lives in static device buffers refreshed before each replay: the
+    latent batch, the per-sample window offsets, and Adam's step size / bias correction
+    (FlatAdam.advance_captured).  Single process only: collectives are not captured, so data-
+    parallel runs keep the eager `train_step`.  The first `warmup` calls run eagerly (they are
+    real training steps; they also size every workspace and the allocator pools)."""
+
+    def __init__(self, model, optim, lr_codebook, hr_codebook, train_base_model, window, warmup=2):
+        if parallel.world_size() > 1:
+            raise RuntimeError("GraphedTrainStep is single-process: data-parallel all-reduces are "
+                               "not captured; use pipeline.train_step")
+        self.model, self.optim = model, optim
+        self.lr_cb, self.hr_cb = lr_codebook, hr_codebook
+        self.base, self.window = train_base_model, window
+        self.warmup = warmup
+        self.calls = 0
+        self.graph = None
+
+    def _body(self, z, rand, captured):
+        hr_in, lr_in, hr_tg = tokenize(z, self.lr_cb, self.hr_cb, self.base)
+        seq = hr_in.shape[1]
+        pos = None
+        if self.window is not None:
+            hr_in, hr_tg, pos = slide(hr_in, hr_tg, self.window, rand)
+        self.optim.zero_grad()
+        logits = self.model(x_dec=hr_in, x_enc=lr_in, pos_cond=pos, pos_bound=seq)
+        loss = QF.cross_entropy(logits.view(-1, logits.shape[-1]), hr_tg.flatten())
+        loss.backward()
+        if captured:
+            self.optim.step_captured()
+        else:
+            self.optim.step()
+        return loss.detach()
+
+    def __call__(self, z, rand):
+        """z: latent batch on the device; rand: int64 window offsets (host or device).
+        Returns the loss (device scalar; a view of the graph's static output after capture)."""
+        self.calls += 1
+        if self.calls <= self.warmup:
+            return self._body(z, rand.to(z.device), captured=False)
+        if self.graph is None:
+            self._z = z.clone()
+            self._rand = rand.to(z.device).clone()
+            self.optim._dev_step_buffer()      # must exist BEFORE capture: created inside, its
+            torch.cuda.synchronize()           # zero-fill would be replayed ahead of every Adam
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._loss = self._body(self._z, self._rand, captured=True)
+        else:
+            self._z.copy_(z)
+            self._rand.copy_(rand)
+        self.optim.advance_captured()
+        self.graph.replay()
+        return self._loss

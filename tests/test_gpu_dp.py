@@ -170,3 +170,48 @@ def test_rccl_single_rank_overlapped_allreduce_path():
         p.kill()
     assert got is not None and p.exitcode == 0
     assert torch.equal(got, want)
+
+
+def test_graphed_train_step_matches_eager_steps():
+    """pipeline.GraphedTrainStep: after its eager warm-up the step is replayed from a captured
+    HIP graph (tokenisation, forward, loss, backward, Adam with device-side step scalars);
+    five steps on changing batches must leave the weights of five eager steps."""
+    from models.Codebook import Codebook
+    from models.Transformer import Transformer
+    from qarig import pipeline
+    from qarig.optim import FlatAdam
+
+    def build():
+        torch.manual_seed(3)
+        g = torch.Generator().manual_seed(4)
+        lr_cb = Codebook(patch_dim=(8, 8), image_dim=(8, 8), image_channel=4, num_embeddings=16).cuda()
+        hr_cb = Codebook(patch_dim=(2, 2), image_dim=(8, 8), image_channel=4, num_embeddings=32).cuda()
+        with torch.no_grad():
+            lr_cb.codebook.weight.copy_(torch.tanh(torch.randn((16, 256), generator=g)))
+            hr_cb.codebook.weight.copy_(torch.tanh(torch.randn((32, 16), generator=g)))
+        m = Transformer(use_encoder=False, use_pos_cond=True, num_enc_layers=None, num_dec_layers=2,
+                        num_enc_embedding=None, num_dec_embedding=48, self_attn_heads=8,
+                        cross_attn_heads=None, transformer_in_dim=64, transformer_out_dim=33,
+                        transformer_hidden_dim=128).cuda()
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.abs().max() == 0:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        return lr_cb, hr_cb, m, FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
+
+    g = torch.Generator().manual_seed(9)
+    batches = [(torch.tanh(torch.randn((6, 4, 8, 8), generator=g)).cuda(),
+                torch.randint(0, 17 - 12 + 1, (6,), generator=g)) for _ in range(5)]
+    lr_cb, hr_cb, m, opt = build()
+    losses_e = []
+    for z, rand in batches:
+        hr_in, lr_in, hr_tg = pipeline.tokenize(z, lr_cb, hr_cb, True)
+        hr_in, hr_tg, pos = pipeline.slide(hr_in, hr_tg, 12, rand)
+        losses_e.append(float(pipeline.train_step(m, opt, hr_in, lr_in, hr_tg, pos, dp=False, pos_bound=17)))
+    want = opt.flat_param.detach().clone()
+    lr_cb, hr_cb, m, opt = build()
+    step = pipeline.GraphedTrainStep(m, opt, lr_cb, hr_cb, True, 12, warmup=2)
+    losses_g = [float(step(z, rand)) for z, rand in batches]
+    assert step.graph is not None and opt.step_count == 5
+    assert torch.equal(opt.flat_param, want)
+    assert losses_g == losses_e
