@@ -104,6 +104,8 @@ class GraphedTrainStep:
         """z: latent batch on the device; rand: int64 window offsets (host or device).
         Returns the loss (device scalar; a view of the graph's static output after capture)."""
         self.calls += 1
+        if rand is None:                       # no sliding window: nothing to slice
+            rand = torch.zeros(z.shape[0], dtype=torch.int64)
         if self.calls <= self.warmup:
             return self._body(z, rand.to(z.device), captured=False)
         if self.graph is None:
@@ -115,6 +117,9 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph):
                 self._loss = self._body(self._z, self._rand, captured=True)
         else:
+            if z.shape != self._z.shape:
+                raise ValueError(f"GraphedTrainStep was captured for batches of shape {tuple(self._z.shape)}, "
+                                 f"got {tuple(z.shape)}")
             self._z.copy_(z)
             self._rand.copy_(rand)
         self.optim.advance_captured()

@@ -60,6 +60,9 @@ def parse_args():
     p.add_argument("--config-path", required=True, type=pathlib.Path,
                    help="File path to load json config file.")
     p.add_argument("--out-dir", required=True, type=pathlib.Path, help="File path to output directory.")
+    p.add_argument("--graph-step", action="store_true",
+                   help="(additive) replay the training step from a captured HIP graph: removes the "
+                        "Python launch overhead for small per-GPU batches; single process, full batches only")
     p.add_argument("--max-steps", type=int, default=None,
                    help="(additive) stop after this many optimiser steps.")
     return vars(p.parse_args())
@@ -212,6 +215,14 @@ def main():
         model.train()
         torch.cuda.empty_cache()
 
+    graphed = None
+    batch_size = args["batch_size"]
+    lr_pH, lr_pW = lr_d["patch_dim"]
+    # tokens per sequence before windowing: the LR tokens (base model) or <start>, then the HR tokens
+    graphed_seq = total_hr_Seq + ((img_H // lr_pH) * (img_W // lr_pW) if train_base_model else 1)
+    if args["graph_step"] and world == 1:
+        graphed = pipeline.GraphedTrainStep(model, optim, lr_codebook, hr_codebook, train_base_model,
+                                            sliding_window if use_sliding_window else None)
     global_steps = 0
     done = False
     for epoch in range(0, args["max_epoch"]):
@@ -220,18 +231,25 @@ def main():
             iteration_count += 1
             feature_map = feature_map.to(device)
             N = feature_map.shape[0]
-            hr_in, lr_in, hr_tg = pipeline.tokenize(feature_map, lr_codebook, hr_codebook,
-                                                    train_base_model)
-            pos_idx = None
-            seq_total = hr_in.shape[1]
-            if use_sliding_window:
-                nwin = pipeline.num_windows(hr_in.shape[1], sliding_window)
-                rand = torch.randint(low=0, high=nwin, size=(N * world,))   # CPU global RNG
-                rand = parallel.shard(parallel.broadcast_host_tensor(rand))
-                hr_in, hr_tg, pos_idx = pipeline.slide(hr_in, hr_tg, sliding_window, rand)
             model.train()
-            loss = pipeline.train_step(model, optim, hr_in, lr_in, hr_tg, pos_idx,
-                                       pos_bound=seq_total)
+            if graphed is not None and N == batch_size:
+                rand = None
+                if use_sliding_window:
+                    rand = torch.randint(low=0, high=pipeline.num_windows(graphed_seq, sliding_window),
+                                         size=(N,))                     # CPU global RNG
+                loss = graphed(feature_map, rand)
+            else:
+                hr_in, lr_in, hr_tg = pipeline.tokenize(feature_map, lr_codebook, hr_codebook,
+                                                        train_base_model)
+                pos_idx = None
+                seq_total = hr_in.shape[1]
+                if use_sliding_window:
+                    nwin = pipeline.num_windows(hr_in.shape[1], sliding_window)
+                    rand = torch.randint(low=0, high=nwin, size=(N * world,))   # CPU global RNG
+                    rand = parallel.shard(parallel.broadcast_host_tensor(rand))
+                    hr_in, hr_tg, pos_idx = pipeline.slide(hr_in, hr_tg, sliding_window, rand)
+                loss = pipeline.train_step(model, optim, hr_in, lr_in, hr_tg, pos_idx,
+                                           pos_bound=seq_total)
             loss_val = loss.item()                                   # the reference's per-step sync
             ops.check_index_flag(device, "training batch")
             if loss_val != loss_val:

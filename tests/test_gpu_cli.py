@@ -118,6 +118,16 @@ def test_cli_pipeline(tmp_path):
         "--out-dir", f"{t}/t_base2", "--model-path", f"{t}/t_base/models_checkpoint/model_2.pt",
         "--load-optim", "--max-steps", 1, cwd=t)
 
+    # the same run replayed from a captured HIP graph (3 steps: 2 eager warm-ups + 1 replay)
+    out_g = run("train_quantized_transformer.py", *common, "--train-base-model", "--lr-codebook-path",
+                f"{t}/cb_lr/models_checkpoint/codebook_2.pt", "--hr-codebook-path",
+                f"{t}/cb_mid/models_checkpoint/codebook_2.pt", "--config-path", f"{t}/t_base.json",
+                "--out-dir", f"{t}/t_base_graph", "--graph-step", cwd=t)
+    assert "Cum. Steps: 3 | Steps: 3 / 3" in out_g
+    final = float([ln for ln in out_g.splitlines() if "Cum. Steps: 3 |" in ln][-1].split("Recon Loss:")[1])
+    assert 0.0 < final < 10.0          # (weights are drawn unseeded: only sanity here; bit-equality
+    #                                     with the eager step is tests/test_gpu_dp.py's graphed test)
+
     tcfg2 = dict(tcfg, use_sliding_window=True, sliding_window=32)
     json.dump(tcfg2, open(f"{t}/t_s1.json", "w"))
     out = run("train_quantized_transformer.py", *common, "--lr-codebook-path",
