@@ -245,6 +245,12 @@ class AttentionLayer(nn.Module):
         self.v_block = block(cross_cond_dim)
 
     def forward(self, x, cross_cond=None):
+        if not self.use_cross_attn:      # q, k, v from the same rows: one autograd node
+            blocks = (self.q_block, self.k_block, self.v_block)
+            if len({(b[0]._act, b[1]._act) for b in blocks}) == 1:
+                params = [(*_lin_params(b[0]), *_lin_params(b[1])) for b in blocks]
+                q, k, v = QF.mlp2x3(x, params, blocks[0][0]._act, blocks[0][1]._act)
+                return QF.attention(q, k, v, self.heads, self.use_masked_attn)
         src = cross_cond if self.use_cross_attn else x
         q = _mlp2_forward(self.q_block, x)
         k = _mlp2_forward(self.k_block, src)

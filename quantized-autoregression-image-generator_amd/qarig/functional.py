@@ -175,6 +175,72 @@ def mlp2(x, w1, b1, w2, b2, act1, act2=0):
     return _MLP2.apply(x, w1, b1, w2, b2, act1, act2)
 
 
+class _MLP2x3(torch.autograd.Function):
+    """The q, k and v two-layer MLPs of a SELF-attention layer (reference models/layers.py:389-418)
+    on their common input: same six GEMMs forward as three `_MLP2`s; in backward the three
+    input gradients are accumulated by the GEMM epilogues into one tensor (dx = dT1_q W1_q,
+    then += dT1_k W1_k, += dT1_v W1_v) instead of three tensors and two elementwise adds."""
+
+    @staticmethod
+    def forward(ctx, x, act1, act2, *params):
+        require_cuda(x, *params)
+        shp = x.shape
+        x2 = _2d(f32c(x))
+        outs, saved = [], [x2]
+        for i in range(3):
+            w1, b1, w2, b2 = params[4 * i:4 * i + 4]
+            h, t1 = ops.gemm(x2, w1, bias=b1, want_preact=True, act=act1)
+            if act2:
+                y, t2 = ops.gemm(h, w2, bias=b2, want_preact=True, act=act2)
+            else:
+                y, t2 = ops.gemm(h, w2, bias=b2), None
+            outs.append(y.reshape(*shp[:-1], w2.shape[0]))
+            saved += [t1, h, t2 if t2 is not None else x2.new_empty(0)]
+        ctx.save_for_backward(*saved)
+        ctx.act1, ctx.act2 = act1, act2
+        ctx.params = params
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        saved = ctx.saved_tensors
+        x2 = saved[0]
+        grads = []
+        dx = None
+        for i in range(3):
+            w1, b1, w2, b2 = ctx.params[4 * i:4 * i + 4]
+            t1, h, t2 = saved[1 + 3 * i:4 + 3 * i]
+            dy2 = _2d(f32c(dys[i]))
+            dT2 = ops.act_bwd(dy2, t2, ctx.act2) if ctx.act2 else dy2
+            dT1 = ops.gemm(dT2, w2, a_kcontig=True, b_kcontig=False, gradz=t1, gact=ctx.act1)
+            ni = 3 + 4 * i          # needs_input_grad index of w1
+            dw1 = db1 = dw2 = db2 = None
+            if ctx.needs_input_grad[ni + 2]:
+                dw2, db2 = _wgrad(dT2, h, w2, b2, ctx.needs_input_grad[ni + 3])
+            elif ctx.needs_input_grad[ni + 3]:
+                db2 = _bgrad(dT2, b2)
+            if ctx.needs_input_grad[0]:
+                if dx is None:
+                    dx = ops.gemm(dT1, w1, a_kcontig=True, b_kcontig=False)
+                else:
+                    ops.gemm(dT1, w1, a_kcontig=True, b_kcontig=False, out=dx, accumulate=True, splitk=1)
+            if ctx.needs_input_grad[ni]:
+                dw1, db1 = _wgrad(dT1, x2, w1, b1, ctx.needs_input_grad[ni + 1])
+            elif ctx.needs_input_grad[ni + 1]:
+                db1 = _bgrad(dT1, b1)
+            grads += [dw1, db1, dw2, db2]
+        if dx is not None:
+            dx = dx.reshape(*dys[0].shape[:-1], x2.shape[1])
+        return (dx, None, None, *grads)
+
+
+def mlp2x3(x, blocks_params, act1, act2=0):
+    """blocks_params: three (w1, b1, w2, b2) tuples (q, k, v).  Returns (q, k, v)."""
+    if _no_grad():
+        return tuple(mlp2(x, *p, act1, act2) for p in blocks_params)
+    return _MLP2x3.apply(x, act1, act2, *[t for p in blocks_params for t in p])
+
+
 class _Mul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
