@@ -132,31 +132,72 @@ class _MLP2(torch.autograd.Function):
     act1' into the epilogue of the dH GEMM."""
 
     @staticmethod
+    def _padded_out(M, N, K, act2, b2):
+        """A wide, ragged output layer (the classifier: 513 = K_hr + 1 columns over N*S rows) runs
+        on zero-padded copies of its weight -- whole 128-column tiles, hence the interior GEMM
+        kernels forward, d-input and d-weight -- instead of the guarded kernels (575 -> ~360 us
+        per GEMM at 16384 x 513 x 2048); the padding columns carry zero gradients."""
+        return N % 128 != 0 and N > 256 and M >= 4096 and K % 16 == 0 and not act2 and b2 is not None
+
+    @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, act1, act2):
         require_cuda(x, w1, w2)
         shp = x.shape
         x2 = _2d(f32c(x))
         h, t1 = ops.gemm(x2, w1, bias=b1, want_preact=True, act=act1)
-        if act2:
-            y, t2 = ops.gemm(h, w2, bias=b2, want_preact=True, act=act2)
+        N, K = w2.shape
+        ctx.pad = _MLP2._padded_out(x2.shape[0], N, K, act2, b2)
+        if ctx.pad:
+            Np = (N + 127) // 128 * 128
+            w2p = torch.zeros((Np, K), dtype=torch.float32, device=w2.device)
+            w2p[:N].copy_(w2.detach())
+            b2p = torch.zeros(Np, dtype=torch.float32, device=w2.device)
+            b2p[:N].copy_(b2.detach())
+            y, t2 = ops.gemm(h, w2p, bias=b2p)[:, :N].contiguous(), None
+            ctx.save_for_backward(x2, w1, w2p, t1, h, t2)
         else:
-            y, t2 = ops.gemm(h, w2, bias=b2), None
-        ctx.save_for_backward(x2, w1, w2, t1, h, t2)
+            if act2:
+                y, t2 = ops.gemm(h, w2, bias=b2, want_preact=True, act=act2)
+            else:
+                y, t2 = ops.gemm(h, w2, bias=b2), None
+            ctx.save_for_backward(x2, w1, w2, t1, h, t2)
         ctx.act1, ctx.act2 = act1, act2
         ctx.params = (w1, b1, w2, b2)
-        return y.reshape(*shp[:-1], w2.shape[0])
+        return y.reshape(*shp[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         x2, w1, w2, t1, h, t2 = ctx.saved_tensors
         dy2 = _2d(f32c(dy))
-        dT2 = ops.act_bwd(dy2, t2, ctx.act2) if ctx.act2 else dy2
-        dT1 = ops.gemm(dT2, w2, a_kcontig=True, b_kcontig=False, gradz=t1, gact=ctx.act1)
         dx = dw1 = db1 = dw2 = db2 = None
-        if ctx.needs_input_grad[3]:
-            dw2, db2 = _wgrad(dT2, h, ctx.params[2], ctx.params[3], ctx.needs_input_grad[4])
-        elif ctx.needs_input_grad[4]:
-            db2 = _bgrad(dT2, ctx.params[3])
+        if ctx.pad:
+            N = ctx.params[2].shape[0]
+            Np = w2.shape[0]                      # w2 here is the zero-padded copy
+            dT2 = torch.zeros((dy2.shape[0], Np), dtype=torch.float32, device=dy2.device)
+            dT2[:, :N].copy_(dy2)
+            dT1 = ops.gemm(dT2, w2, a_kcontig=True, b_kcontig=False, gradz=t1, gact=ctx.act1)
+            if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+                dwp, dbp = _wgrad(dT2, h, None, None, True)
+                wslot, bslot = _grad_slot(ctx.params[2]), _grad_slot(ctx.params[3])
+                if ctx.needs_input_grad[3]:
+                    if wslot is not None:
+                        wslot.add_(dwp[:N])
+                        _report_done(ctx.params[2])
+                    else:
+                        dw2 = dwp[:N]
+                if ctx.needs_input_grad[4]:
+                    if bslot is not None:
+                        bslot.add_(dbp[:N])
+                        _report_done(ctx.params[3])
+                    else:
+                        db2 = dbp[:N]
+        else:
+            dT2 = ops.act_bwd(dy2, t2, ctx.act2) if ctx.act2 else dy2
+            dT1 = ops.gemm(dT2, w2, a_kcontig=True, b_kcontig=False, gradz=t1, gact=ctx.act1)
+            if ctx.needs_input_grad[3]:
+                dw2, db2 = _wgrad(dT2, h, ctx.params[2], ctx.params[3], ctx.needs_input_grad[4])
+            elif ctx.needs_input_grad[4]:
+                db2 = _bgrad(dT2, ctx.params[3])
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dT1, w1, a_kcontig=True, b_kcontig=False).reshape(
                 *dy.shape[:-1], w1.shape[1])

@@ -292,3 +292,27 @@ def test_readme_block_sizes_train_step_grads_vs_oracle(cond_table):
     for n, p in m.named_parameters():
         worst = max(worst, grad_err(p.grad, sd[n].grad, floor=1e-7))
     assert worst < 2e-4, worst   # fp32 vs fp32 with different summation orders, K up to 2048
+
+
+def test_mlp2_ragged_wide_output_runs_padded_and_matches_fp64():
+    """The classifier shape class (many rows, 513 = K_hr + 1 output columns): _MLP2 runs its second
+    layer on zero-padded weights so that forward, d-input and d-weight take the interior kernels;
+    values and every gradient against an fp64 evaluation."""
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(11)
+    M, Din, Hd, N = 4096, 256, 512, 513
+    assert QF._MLP2._padded_out(M, N, Hd, 0, True)
+    x = torch.randn((M, Din), generator=g).cuda().requires_grad_(True)
+    w1 = (torch.randn((Hd, Din), generator=g) * 0.05).cuda().requires_grad_(True)
+    b1 = torch.randn((Hd,), generator=g).cuda().requires_grad_(True)
+    w2 = (torch.randn((N, Hd), generator=g) * 0.05).cuda().requires_grad_(True)
+    b2 = torch.randn((N,), generator=g).cuda().requires_grad_(True)
+    gy = torch.randn((M, N), generator=g).cuda()
+    y = QF.mlp2(x, w1, b1, w2, b2, 1, 0)
+    got = torch.autograd.grad(y, (x, w1, b1, w2, b2), gy)
+    xd, w1d, b1d, w2d, b2d = (t.detach().double().cpu().requires_grad_(True) for t in (x, w1, b1, w2, b2))
+    yd = torch.nn.functional.silu(xd @ w1d.t() + b1d) @ w2d.t() + b2d
+    want = torch.autograd.grad(yd, (xd, w1d, b1d, w2d, b2d), gy.double().cpu())
+    assert y.shape == (M, N) and rel_err(y, yd) < 5e-6
+    for a, b in zip(got, want):
+        assert rel_err(a, b) < 2e-5
