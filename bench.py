@@ -10,17 +10,22 @@ One "step" = one pass of the hot loop of train_quantized_transformer.py (referen
   AdaLN-Zero on window positions) -> CE -> backward -> [RCCL all-reduce] -> Adam.
 value = image tokens trained per second, whole job (weak scaling: 64 latents / GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4|c5]
+
+With --gpus N > 1 and no torchrun environment the script launches its own N ranks
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py ...`) BEFORE anything
+touches a GPU and exits with their code; under torchrun it is one rank of the job.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
-(the fp32 MFMA GEMM family, timed live with HIP events around every launch of the
-timed region) and `cpu_baseline` (the torch-CPU oracle of the same step on the host
-cores, a bounded sample).
+(the MFMA GEMM family, timed with HIP events around every launch in a short second
+pass -- the headline loop carries no per-launch events) and `cpu_baseline` (the
+torch-CPU oracle of the same step on the host cores, a bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,12 +35,11 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
+PEAK_FP8_MFMA_TFLOPS = 5000.0    # dense fp8, MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBPS = 8000.0
+METRIC = "image-tokens/sec at 1/2/4/8 GPUs; BMU argmin GB/s vs HBM peak"
 
 CFG = dict(batch=64, latent=(4, 32, 32), k_lr=512, k_hr=512, lr_patch=32, hr_patch=2, window=256,
            in_dim=512, hidden=2048, heads=64, dec_layers=7, enc_layers=0, lr=1e-4, base=True,
@@ -50,9 +54,91 @@ CFG_C4 = dict(batch=8, latent=(4, 64, 64), k_lr=512, k_hr=512, lr_patch=4, hr_pa
               name="BASELINE configs[3] shard: BMU + encoder-decoder Transformer train step, "
                    "64x64x4 latents (256x256 images), 256 encoder tokens, 1025-token sequences, "
                    "window 256, 8 latents per GPU")
+# BASELINE configs[4] per-GPU shard: 8192-entry HR codebook on single latent pixels (patch 1:
+# 4096 tokens per 64x64x4 latent), full 4096-token window, encoder over the previous stage's
+# 1024 tokens (patch 2, K=512); reduced-precision (bf16 / fp8 MFMA) attention + Linear layers.
+CFG_C5 = dict(batch=2, latent=(4, 64, 64), k_lr=512, k_hr=8192, lr_patch=2, hr_patch=1, window=4096,
+              in_dim=512, hidden=2048, heads=64, dec_layers=7, enc_layers=5, lr=1e-4, base=False,
+              name="BASELINE configs[4] shard: BMU (K=8192, patch 1) + encoder-decoder Transformer "
+                   "train step, 64x64x4 latents, 1024 encoder tokens, 4097-token sequences, window "
+                   "4096, 2 latents per GPU")
+CONFIGS = {"c2": CFG, "c4": CFG_C4, "c5": CFG_C5}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "bf16", "fp8"], default=None,
+                    help="f32 = the parity mode and the headline number (default for c2/c4); bf16 / "
+                         "fp8 = opt-in reduced precision (Linear GEMMs + attention products on the "
+                         "bf16 / fp8 MFMA, fp32 accumulate), the default for --config c5 (bf16); "
+                         "reported under its own workload name, never as the c2 headline")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole training step from a captured HIP graph (single GPU; "
+                         "helps launch-bound per-GPU batches such as --config c4)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="c2 (default, the headline workload), or the per-GPU shard of config 4 / 5")
+    ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`bench.py --gpus N` outside torchrun: start the N ranks ourselves.  Nothing in this
+    process has touched a GPU (torch is not even imported yet), the ranks are CHILD processes
+    and this process only relays their exit code -- no exec of a GPU-initialised process."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def stub_main(args):
+    """QARIG_BENCH_STUB=1: the launch / rendezvous / max-over-ranks / one-line plumbing of a
+    multi-rank run over gloo on CPU, with no model and no GPU (tests/test_bench_launch.py).
+    The line says so ("stub": true) and carries no measurement."""
+    import torch
+    import torch.distributed as dist
+    from qarig import parallel
+    world, rank, _ = parallel.init(backend="gloo")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    flat = torch.full((1024,), float(rank + 1))
+    for _ in range(args.steps):
+        parallel.allreduce_flat(flat.clone())
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "stub": True, "value": None, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(t.item()) / max(1, args.steps) * 1e3, 3)}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def build_models(device, cfg, seed=3):
+    import torch
     from models.Codebook import Codebook
     from models.Transformer import Transformer
     g = torch.Generator().manual_seed(2)
@@ -81,8 +167,9 @@ def build_models(device, cfg, seed=3):
 
 def cpu_baseline(cfg, budget_s=float(os.environ.get("QARIG_CPU_BASELINE_SECONDS", "15"))):
     """The oracle (torch-CPU restatement, oracle/ref_models.py) running the same train
-    step on the host cores: batch 2 sequences of 256 tokens, as many steps as fit the
-    budget (>= 1)."""
+    step on the host cores: batch 2 sequences of 256 tokens with a random window per
+    sample (drawn as the GPU loop draws it), as many steps as fit the budget (>= 1)."""
+    import torch
     from oracle import ref_models as rm
     from oracle import bmu as obmu
     # the GPU box gives one GPU's share of the host: 16 cores (task statement)
@@ -100,6 +187,7 @@ def cpu_baseline(cfg, budget_s=float(os.environ.get("QARIG_CPU_BASELINE_SECONDS"
                 self_attn_heads=cfg["heads"], hidden_activation="silu")
     N, W = 2, cfg["window"]
     g = torch.Generator().manual_seed(1)
+    rng = torch.Generator().manual_seed(4)
     C, H, Wd = cfg["latent"]
     z = torch.tanh(torch.randn((N, C, H, Wd), generator=g))
     steps, t0 = 0, time.perf_counter()
@@ -108,9 +196,11 @@ def cpu_baseline(cfg, budget_s=float(os.environ.get("QARIG_CPU_BASELINE_SECONDS"
                                            (cfg["lr_patch"],) * 2)).reshape(N, -1)
         hr_idx = torch.from_numpy(obmu.bmu(z.numpy(), hr_cb.codebook.weight.detach().numpy(),
                                            (cfg["hr_patch"],) * 2)).reshape(N, -1)
-        x = torch.cat((lr_idx, hr_idx + cfg["k_lr"]), 1)[:, :W]
-        t = torch.cat((hr_idx, torch.full((N, 1), cfg["k_hr"])), 1)[:, :W]
-        pos = torch.arange(W)[None].repeat(N, 1)
+        x_full = torch.cat((lr_idx, hr_idx + cfg["k_lr"]), 1)
+        t_full = torch.cat((hr_idx, torch.full((N, 1), cfg["k_hr"])), 1)
+        rand = torch.randint(0, x_full.shape[1] - W + 1, (N,), generator=rng)
+        pos = rand[:, None] + torch.arange(W)[None]
+        x, t = x_full.gather(1, pos), t_full.gather(1, pos)
         for k in names:
             sd[k].grad = None
         loss = rm.cross_entropy(rm.transformer_forward(sd, mcfg, x, None, pos), t)
@@ -124,18 +214,19 @@ def cpu_baseline(cfg, budget_s=float(os.environ.get("QARIG_CPU_BASELINE_SECONDS"
             break
     return {"value": round(steps * N * W / el, 2), "unit": "image-tokens/s",
             "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} train steps (BMU + fwd + CE + bwd + Adam) of batch {N} x {W} "
-                      f"tokens, torch-CPU oracle, {torch.get_num_threads()} threads of "
+            "sample": f"{steps} train steps (BMU + random window + fwd + CE + bwd + Adam) of batch "
+                      f"{N} x {W} tokens, torch-CPU oracle, {torch.get_num_threads()} threads of "
                       f"{os.cpu_count()} host cpus, {el:.1f} s"}
 
 
-def bmu_side_measure(device):
+def bmu_side_measure(device, K=512):
     """BMU argmin GB/s on a C4-sized launch (65,536 patch rows, K=512, D=16), timed
     with HIP events on the launch stream; algorithmic bytes = 4*D + 8 per row."""
+    import torch
     from qarig import ops
     g = torch.Generator().manual_seed(9)
     x = torch.tanh(torch.randn((64, 4, 64, 64), generator=g)).to(device)
-    w = torch.tanh(torch.randn((512, 16), generator=g)).to(device)
+    w = torch.tanh(torch.randn((K, 16), generator=g)).to(device)
     for _ in range(2):
         ops.bmu(x, w, (2, 2))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -148,8 +239,8 @@ def bmu_side_measure(device):
     ms = e0.elapsed_time(e1) / reps
     rows = 64 * 32 * 32
     gb = rows * (4 * 16 + 8) / 1e9
-    fl = rows * 2.0 * 512 * (16 + 2)
-    return {"rows": rows, "K": 512, "D": 16, "ms": round(ms, 4),
+    fl = rows * 2.0 * K * (16 + 2)
+    return {"rows": rows, "K": K, "D": 16, "ms": round(ms, 4),
             "rows_per_s": round(rows / ms * 1e3, 1),
             "algorithmic_GBps": round(gb / ms * 1e3, 2),
             "frac_of_hbm_peak": round(gb / ms * 1e3 / HBM_PEAK_GBPS, 5),
@@ -158,33 +249,27 @@ def bmu_side_measure(device):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
-                    help="f32 = the parity mode and the headline number; bf16 = opt-in reduced "
-                         "precision (Linear GEMMs on the bf16 MFMA, fp32 accumulate/storage), "
-                         "reported under its own workload name, never as the headline")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the whole training step from a captured HIP graph (single GPU; "
-                         "helps launch-bound per-GPU batches such as --config c4)")
-    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
-                    help="c2 (default, the headline workload) or the config-4 per-GPU shard")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if os.environ.get("QARIG_BENCH_STUB") == "1":
+        return stub_main(args)
 
+    import torch
+    import torch.distributed as dist
     from qarig import ops, parallel, pipeline
     from qarig.optim import FlatAdam
 
-    ops.PRECISION = args.precision
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["batch"] = args.batch
+    precision = args.precision or ("bf16" if args.config == "c5" else "f32")
+    ops.set_precision(precision)
     world, rank, local = parallel.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    cfg = CFG if args.config == "c2" else CFG_C4
 
     lr_cb, hr_cb, model = build_models(device, cfg)
     optim = FlatAdam(model.parameters(), lr=cfg["lr"], betas=(0.5, 0.999))
@@ -221,14 +306,11 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     fence()
-    if not args.no_kernel_events:
-        ops.GEMM_EVENTS = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
     loss_val = float(loss.item())
     ops.check_index_flag(device, "bench")
     if world > 1:
@@ -236,19 +318,56 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # second, short pass: HIP events around every GEMM launch (on the launch stream) for the
+    # roofline object; kept out of the headline loop, which carries no per-launch events
+    events = []
+    if not args.no_kernel_events and graphed is None:
+        ev_steps = min(2, args.steps)
+        ops.GEMM_EVENTS = []
+        t1 = time.perf_counter()
+        for _ in range(ev_steps):
+            step()
+        fence()
+        dt_ev = time.perf_counter() - t1
+        events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
+
+    # the gradient exchange on its own (the timed loop overlaps it with backward)
+    allreduce = None
+    if world > 1:
+        flat = optim.flat_grad
+        parallel.allreduce_flat(flat)
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(3):
+            parallel.allreduce_flat(flat)
+        fence()
+        ar_ms = (time.perf_counter() - t2) / 3 * 1e3
+        nbytes = flat.numel() * 4
+        allreduce = {"bytes_per_step": nbytes, "standalone_ms": round(ar_ms, 3),
+                     "algbw_GBps": round(nbytes / ar_ms / 1e6, 1),
+                     "busbw_GBps": round(nbytes / ar_ms / 1e6 * 2 * (world - 1) / world, 1),
+                     "bucket_MiB": 64, "overlapped_with_backward": bool(optim._overlap),
+                     "backend": dist.get_backend()}
+
     tokens = N * world * cfg["window"] * args.steps
-    out = {"metric": "image-tokens/sec at 1/2/4/8 GPUs; BMU argmin GB/s vs HBM peak",
+    dtype = {"f32": "f32", "bf16": "bf16 products / f32 accumulate",
+             "fp8": "fp8 (e4m3) products / f32 accumulate"}[precision]
+    tag = "" if precision == "f32" else (f" [{precision}-MFMA Linear + attention products, f32 "
+                                         "accumulate; NOT the fp32 parity configuration]")
+    out = {"metric": METRIC,
            "value": round(tokens / dt, 1), "unit": "image-tokens/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32" if args.precision == "f32" else "bf16 products / f32 accumulate+storage",
-           "data": "synthetic",
-           "config": {"workload": cfg["name"] + ("" if args.precision == "f32" else " [opt-in bf16-MFMA Linear mode, NOT the parity/headline configuration]"),
+           "dtype": dtype, "data": "synthetic",
+           "config": {"workload": cfg["name"] + tag,
                       "batch_per_gpu": N, "global_batch": N * world, "seq_len": cfg["window"],
                       "in_dim": cfg["in_dim"], "hidden_dim": cfg["hidden"], "heads": cfg["heads"],
-                      "dec_layers": cfg["dec_layers"], "params": int(optim.total),
+                      "dec_layers": cfg["dec_layers"], "enc_layers": cfg["enc_layers"],
+                      "params": int(optim.total),
                       "parallelism": f"dp{world}", "loss": round(loss_val, 5),
                       "launch": "captured HIP graph replay" if args.graph else "eager stream launches"}}
+    if allreduce is not None:
+        out["allreduce"] = allreduce
     if rank == 0:
         if events:
             times = [(e[0], e[1].elapsed_time(e[2])) for e in events]
@@ -260,22 +379,31 @@ def main():
             fl, ms = sum(t[0] for t in big), sum(t[1] for t in big)
             fl_all, ms_all = sum(t[0] for t in times), sum(t[1] for t in times)
             ach = fl / ms / 1e9
-            traffic = None
+            traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-            if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
-            kname = ("qarig::gemm_dma_kernel<*> / gemm_kernel<*> (fp32 MFMA 32x32x2)" if args.precision == "f32"
-                     else "qarig::gemm_bf16_kernel<*> (bf16 MFMA 32x32x16; HBM-bound on its fp32 operands)")
+            if os.path.exists(pmc) and precision == "f32" and args.config == "c2":
+                tj = json.load(open(pmc))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = (f"profiles/gemm_traffic.json (round {tj.get('round')}: rocprofv3 --pmc "
+                               "FETCH_SIZE / WRITE_SIZE passes of this command, reads doubled per the "
+                               "gfx950 calibration; not re-measured by this run)")
+            peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS,
+                    "fp8": PEAK_FP8_MFMA_TFLOPS}[precision]
+            kname = {"f32": "qarig::gemm_dma_kernel<*> / gemm_kernel<*> (fp32 MFMA 32x32x2)",
+                     "bf16": "qarig::gemm_lp_kernel<bf16,*> (bf16 MFMA 32x32x16, bf16 operands in HBM)",
+                     "fp8": "qarig::gemm_lp_kernel<fp8,*> (fp8 e4m3 MFMA 32x32x16, fp8 operands in HBM)"}[precision]
             out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": round(ach, 2), "peak": peak,
                                "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": traffic, "launches": len(big),
+                               "traffic": traffic, "traffic_source": traffic_src,
+                               "launches": len(big),
                                "avg_launch_us": round(ms / len(big) * 1e3, 2),
                                "avg_launch_gflop": round(fl / len(big) / 1e9, 3),
-                               "gemm_share_of_step": round(ms_all / (dt * 1e3), 3),
+                               "event_pass": f"{ev_steps} extra steps after the timed region "
+                                             f"({dt_ev / ev_steps * 1e3:.2f} ms/step with events)",
+                               "gemm_share_of_step": round(ms_all / (dt_ev * 1e3), 3),
                                "small_launches": {"count": len(small), "what": "position-table and other < 1 GFLOP GEMMs",
-                                                  "ms_per_step": round(sum(t[1] for t in small) / args.steps, 3),
+                                                  "ms_per_step": round(sum(t[1] for t in small) / ev_steps, 3),
                                                   "achieved_all_launches_TFLOPs": round(fl_all / ms_all / 1e9, 2)}}
         out["bmu"] = bmu_side_measure(device)
         if not args.no_cpu_baseline and world == 1 and args.config == "c2":

@@ -106,11 +106,8 @@ class Transformer(nn.Module):
         cond = ops.posemb(pos_cond.flatten(), D).reshape(N, S, D)
         return _mlp2_forward(self.pos_cond_layer, cond)
 
-    def _cond_linear_groups(self):
-        """The nn.Linear modules that project `cond` inside the decoder blocks, grouped for the
-        grouped launches of the position table: ONE group (all layers) on a single GPU; one group
-        per decoder layer under data parallelism, so that each layer's projection gradients
-        are final when that layer's backward is and its all-reduce bucket can leave early."""
+    def _cond_linears_per_layer(self):
+        """Per decoder layer, the nn.Linear modules that project `cond` inside its blocks."""
         per_layer = []
         for layer in self.decoder_layers:
             out = []
@@ -125,6 +122,14 @@ class Transformer(nn.Module):
                 if res.use_scale_layer:
                     out.append(res.scale_layer.scale)
             per_layer.append(out)
+        return per_layer
+
+    def _cond_linear_groups(self):
+        """The projections of `cond` grouped for the grouped launches of the position table: ONE
+        group (all layers) on a single GPU; one group per decoder layer under data parallelism,
+        so that each layer's projection gradients are final when that layer's backward is and
+        its all-reduce bucket can leave early."""
+        per_layer = self._cond_linears_per_layer()
         mode = QF.COND_TABLE_GROUPING
         if mode is None:
             import torch.distributed as dist
@@ -142,8 +147,15 @@ class Transformer(nn.Module):
         cond = None
         if self.use_pos_cond:
             cond = self._cond(pos_cond, N, S, D, pos_bound)
-        for layer in self.decoder_layers:
-            if self.use_activation_checkpoint and torch.is_grad_enabled():
+        ckpt = self.use_activation_checkpoint and torch.is_grad_enabled()
+        per_layer = self._cond_linears_per_layer() if ckpt and isinstance(cond, QF.CondTable) else None
+        for li, layer in enumerate(self.decoder_layers):
+            if ckpt:
+                if per_layer is not None:
+                    # grouped table projections are cached on `cond`: evaluate this layer's group
+                    # OUTSIDE the checkpointed region, so that the original forward and the
+                    # recomputation both find them cached and save the same tensors
+                    cond.ensure(per_layer[li])
                 x = checkpoint.checkpoint(layer, x, cross_cond=enc, pos_cond=cond,
                                           use_reentrant=False)
             else:

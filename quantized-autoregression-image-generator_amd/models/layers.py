@@ -228,6 +228,11 @@ class AttentionLayer(nn.Module):
     def __init__(self, heads=8, in_dim=512, cross_cond_dim=512, hidden_dim=2_048,
                  use_cross_attn=True, use_masked_attn=True, activation_type="silu"):
         super().__init__()
+        if in_dim % heads or (in_dim // heads) not in ops.ATTENTION_HEAD_DIMS:
+            # the reference accepts any divisor; the HIP attention kernels are built for these
+            raise ValueError(f"AttentionLayer: in_dim {in_dim} / heads {heads} gives head dim "
+                             f"{in_dim / heads:g}; the MI355X kernels support head dims "
+                             f"{ops.ATTENTION_HEAD_DIMS}")
         self.heads = heads
         self.use_cross_attn = use_cross_attn
         self.use_masked_attn = use_masked_attn

@@ -139,14 +139,22 @@ def f32c(t):
 
 
 _ws_cache = {}
+_ws_retired = []     # outgrown buffers whose address a captured graph may still hold
 
 
 def workspace(nbytes, device, tag="default"):
     """Grow-only per-device scratch buffer (uint8).  Kernels that use it run on the
-    current stream in issue order, so one buffer per tag can be shared."""
+    current stream in issue order, so one buffer per tag can be shared.
+
+    A captured HIP graph (GraphedTrainStep, the decode graphs) bakes the buffer's raw address
+    into its kernel nodes.  An outgrown buffer is therefore never handed back to the caching
+    allocator: it is parked in `_ws_retired`, so a later replay of an older graph writes into
+    memory nobody else owns (a few MB per growth step, bounded by the largest request)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _ws_retired.append(buf)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf

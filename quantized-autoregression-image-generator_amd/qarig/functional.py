@@ -464,6 +464,9 @@ class _Conv2dAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, act):
+        require_cuda(x, weight, bias)
+        assert weight.is_contiguous() and weight.dtype == torch.float32, "conv weight must be dense fp32"
+        x = f32c(x)     # the kernels (forward AND both gradients) read dense NCHW fp32: save this one
         need = any(ctx.needs_input_grad)
         if need and act:
             y, pre = ops.conv2d_fwd(x, weight, bias, stride, pad, act, want_preact=True)
@@ -491,6 +494,9 @@ class _ConvT2dAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, act):
+        require_cuda(x, weight, bias)
+        assert weight.is_contiguous() and weight.dtype == torch.float32, "conv weight must be dense fp32"
+        x = f32c(x)
         need = any(ctx.needs_input_grad)
         if need and act:
             y, pre = ops.conv_transpose2d_fwd(x, weight, bias, act, want_preact=True)
@@ -571,6 +577,16 @@ class CondTable:
                     and all(l.weight.shape == (D, D) and l.bias is not None for l in group)):
                 for l in group:
                     self._group_of[id(l)] = group
+
+    def ensure(self, linears):
+        """Evaluates (and caches) the grouped projections that `linears` belong to.  Callers that
+        wrap a layer in torch.utils.checkpoint call this BEFORE entering the checkpointed region:
+        a projection first evaluated inside it would be computed (and its inputs saved) in the
+        original forward but found cached by the recomputation, and non-reentrant checkpointing
+        rejects a recomputation that saves a different number of tensors."""
+        for l in linears:
+            if id(l) in self._group_of:
+                self.projection(l)
 
     def projection(self, linear):
         """linear(table) (P, out).  Linears registered in a group are evaluated together, as one

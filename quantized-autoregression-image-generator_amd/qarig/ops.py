@@ -51,6 +51,15 @@ GEMM_EVENTS = None
 # tensors; BASELINE config 5 direction, tolerance stated in tests/test_gpu_bf16.py).
 # QARIG_PRECISION in the environment sets the default.
 PRECISION = os.environ.get("QARIG_PRECISION", "f32")
+PRECISIONS = ("f32", "bf16")
+
+
+def set_precision(name):
+    """Selects the contraction precision of the Linear / attention products for the process."""
+    global PRECISION
+    if name not in PRECISIONS:
+        raise ValueError(f"qarig.ops precision must be one of {PRECISIONS}, not {name!r}")
+    PRECISION = name
 
 
 def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_preact=False,
@@ -395,6 +404,9 @@ def mul_rows_bwd(dy, a, tab, idx):
     check(_lib.load().qarig_mul_rows_bwd(ptr(dy), ptr(a), ptr(tab), ptr(idx), ptr(da), ptr(db), M, D,
                                          stream()), "qarig_mul_rows_bwd")
     return da, db
+
+
+ATTENTION_HEAD_DIMS = (4, 8, 16, 32, 64)   # csrc/attention.hip instantiations
 
 
 def attention_fwd(q, k, v, heads, causal):

@@ -17,9 +17,12 @@ def save_model(dest_path, file_name, model_dict, logging=print):
         return False
 
 
-def load_model(checkpoint_path, logging=print, weights_only=False):
-    """weights_only=False mirrors the reference (its checkpoints hold plain python
-    containers + tensors; pass True for files from an untrusted source)."""
+def load_model(checkpoint_path, logging=print, weights_only=True):
+    """Loads with torch's weights-only unpickler by default: every checkpoint dict of this
+    pipeline (tensors, numbers, strings, tuples, None, an optimizer state_dict) -- and of the
+    reference, whose schemas are the same -- loads under it, and nothing in a downloaded
+    `--model-path` file can execute code.  weights_only=False is an explicit opt-out for a
+    legacy file the safe loader refuses."""
     if not os.path.exists(checkpoint_path):
         logging("Checkpoint does not exist.")
         return False, None

@@ -187,3 +187,43 @@ def test_embedding_gradient_by_row_map_matches_index_add():
     want = torch.zeros((V, D), dtype=torch.float64).index_add_(0, ids.cpu().reshape(-1),
                                                                  gy.double().cpu().reshape(-1, D))
     assert rel_err(got, want) < 2e-6
+
+
+@pytest.mark.parametrize("grouping", ["all", "layer"])
+def test_activation_checkpoint_with_grouped_table_matches_plain_run(grouping):
+    """--use-activation-checkpoint with the position table in its grouped form (D % 256 == 0, the
+    README shapes): the projections are cached on the CondTable, so they must be evaluated
+    outside the checkpointed layer -- otherwise the recomputation saves fewer tensors than the
+    original forward and torch raises CheckpointError.  Gradients must equal the plain run's."""
+    from models.Transformer import Transformer
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(3)
+    N, S, total = 8, 64, 100
+    x = torch.randint(0, 60, (N, S), generator=g).cuda()
+    t = torch.randint(0, 41, (N, S), generator=g).cuda()
+    pos = (torch.randint(0, total - S + 1, (N, 1), generator=g) + torch.arange(S)[None]).cuda()
+    old = (QF.COND_TABLE_MIN_RATIO, QF.COND_TABLE_GROUPING)
+    res = {}
+    try:
+        QF.COND_TABLE_MIN_RATIO, QF.COND_TABLE_GROUPING = 0, grouping
+        for ckpt in (False, True):
+            torch.manual_seed(7)
+            m = Transformer(use_encoder=False, use_pos_cond=True, num_enc_layers=None, num_dec_layers=3,
+                            num_enc_embedding=None, num_dec_embedding=60, self_attn_heads=32,
+                            cross_attn_heads=None, transformer_in_dim=256, transformer_out_dim=41,
+                            transformer_hidden_dim=512, use_activation_checkpoint=ckpt).cuda()
+            gw = torch.Generator().manual_seed(4)
+            with torch.no_grad():
+                for p in m.parameters():
+                    if p.abs().max() == 0:
+                        p.copy_(torch.randn(p.shape, generator=gw) * 0.05)
+            logits = m(x, None, pos, pos_bound=total)
+            assert m._last_cond_form == "table"
+            loss = QF.cross_entropy(logits.view(-1, 41), t.flatten())
+            loss.backward()
+            res[ckpt] = (logits.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+    finally:
+        QF.COND_TABLE_MIN_RATIO, QF.COND_TABLE_GROUPING = old
+    assert torch.equal(res[True][0], res[False][0])
+    for n, gref in res[False][1].items():
+        assert torch.equal(res[True][1][n], gref), n      # same kernels, same order: bit-identical

@@ -85,3 +85,50 @@ def test_readme_transformer_param_counts():
                        cross_attn_heads=None, transformer_in_dim=512, transformer_out_dim=513,
                        transformer_hidden_dim=2048)
     assert sum(p.numel() for p in base.parameters()) == 78_226_433
+
+
+def test_unsupported_head_dim_fails_at_construction():
+    """The reference accepts any `heads` dividing in_dim; the HIP attention kernels exist for
+    head dims 4..64, so an unsupported one must fail when the model is built, not at the first
+    forward."""
+    import pytest
+    from models.layers import AttentionLayer
+    AttentionLayer(heads=64, in_dim=512, hidden_dim=64)
+    with pytest.raises(ValueError, match="head dim"):
+        AttentionLayer(heads=4, in_dim=512, hidden_dim=64)      # d = 128
+    with pytest.raises(ValueError, match="head dim"):
+        AttentionLayer(heads=7, in_dim=512, hidden_dim=64)      # not a divisor
+
+
+def test_checkpoint_dicts_load_with_the_weights_only_unpickler(tmp_path):
+    """utils.model_utils.load_model defaults to weights_only=True: the checkpoint dict schemas of
+    the four CLIs (reference train_quantized_transformer.py:519-534, train_codebook.py:271-278,
+    train_autoencoder.py:235-247) must round-trip through it."""
+    import torch
+    from utils.model_utils import load_model, save_model
+    sd = {"w": torch.randn(3, 4), "b": torch.zeros(4)}
+    opt = {"state": {0: {"step": torch.tensor(3.0), "exp_avg": torch.zeros(3, 4),
+                         "exp_avg_sq": torch.zeros(3, 4)}},
+           "param_groups": [{"lr": 1e-4, "betas": (0.5, 0.999), "eps": 1e-8, "weight_decay": 0,
+                             "amsgrad": False, "params": [0]}]}
+    dicts = {
+        "model_1.pt": {"train_base_model": True, "use_sliding_window": True, "sliding_window": 256,
+                       "num_enc_embedding": None, "num_dec_embedding": 1024, "num_enc_layers": None,
+                       "num_dec_layers": 7, "self_attn_heads": 64, "cross_attn_heads": None,
+                       "transformer_in_dim": 512, "transformer_out_dim": 513,
+                       "transformer_hidden_dim": 2048, "hidden_activation": "silu", "model": sd,
+                       "model_optimizer": opt},
+        "codebook_1.pt": {"patch_dim": (4, 4), "image_dim": (32, 32), "image_C": 4, "num_embeddings": 512,
+                          "neighbourhood_range": 1.0, "global_steps": 10, "checkpoint": sd},
+        "ae_1.pt": {"image_channel": 3, "min_channel": 256, "max_channel": 512, "latent_channel": 4,
+                    "num_layers": 2, "hidden_activation_type": "silu", "use_final_enc_activation": True,
+                    "encoder_final_activation": "tanh", "use_final_dec_activation": True,
+                    "decoder_final_activation": "tanh", "checkpoint": sd, "optimizer": opt},
+    }
+    for name, d in dicts.items():
+        assert save_model(str(tmp_path), name, d)
+        ok, got = load_model(str(tmp_path / "models_checkpoint" / name))
+        assert ok and set(got) == set(d)
+        assert got.get("patch_dim", (4, 4)) == (4, 4)
+        inner = got.get("model", got.get("checkpoint"))
+        assert torch.equal(inner["w"], sd["w"])
