@@ -217,10 +217,185 @@ def gen_transformer():
         save("transformer_" + tag, **out)
 
 
+def _tiny_transformer(use_enc, n_dec_emb, n_enc_emb, out_dim, seed):
+    torch.manual_seed(seed)
+    cfg = dict(use_encoder=use_enc, use_pos_cond=True, num_enc_layers=2 if use_enc else None,
+               num_dec_layers=2, num_enc_embedding=n_enc_emb if use_enc else None,
+               num_dec_embedding=n_dec_emb, self_attn_heads=4,
+               cross_attn_heads=2 if use_enc else None, transformer_in_dim=32,
+               transformer_out_dim=out_dim, transformer_hidden_dim=64, hidden_activation="silu")
+    m = Transformer(**cfg)
+    liven(m)
+    return m
+
+
+def _codebook(p, K, g, image_dim=(8, 8)):
+    cb = Codebook(patch_dim=(p, p), image_dim=image_dim, image_channel=4, num_embeddings=K,
+                  init_neighbour_range=4)
+    with torch.no_grad():
+        cb.codebook.weight.copy_(torch.tanh(torch.randn((K, 4 * p * p), generator=g)))
+    return cb
+
+
+def gen_train_step():
+    """ONE full training step as the reference's loop performs it
+    (train_quantized_transformer.py:404-508): BMU tokenisation with both codebooks, token
+    assembly (base: LR token + shifted HR ids; enc-dec: <start> + HR ids, LR ids to the
+    encoder), <end>-terminated target, unfold + per-sample random window + absolute window
+    positions, forward, CE, backward, Adam(0.5, 0.999).  The loop body below follows those
+    lines statement by statement on the reference's own Codebook / Transformer classes."""
+    g = torch.Generator().manual_seed(21)
+    N, window = 3, 8
+    fmap = torch.tanh(torch.randn((N, 4, 8, 8), generator=g))
+    for tag, base in (("base", True), ("encdec", False)):
+        K_lr, K_hr = 16, 32
+        lr_cb = _codebook(8 if base else 4, K_lr, g)     # base: one LR token per latent
+        hr_cb = _codebook(2, K_hr, g)
+        m = _tiny_transformer(not base, K_lr + K_hr if base else K_hr + 1, K_lr, K_hr + 1, seed=31)
+        sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
+        ce = torch.nn.CrossEntropyLoss()
+        with torch.no_grad():
+            lr_indices = lr_cb.get_patches_bmu(fmap, reshape=True)
+            hr_indices = hr_cb.get_patches_bmu(fmap, reshape=True)
+        if base:
+            hr_input = torch.cat((lr_indices, hr_indices + K_lr), dim=1)
+            lr_input = None
+        else:
+            start_tensor = torch.tensor([[K_hr]]).repeat(N, 1)
+            hr_input = torch.cat((start_tensor, hr_indices), dim=1)
+            lr_input = lr_indices
+        end_tensor = torch.tensor([[K_hr]]).repeat(N, 1)
+        hr_target = torch.cat((hr_indices, end_tensor), dim=1)
+        full_in, full_tg = hr_input.clone(), hr_target.clone()
+        hr_input_unfold = hr_input.unfold(dimension=1, size=window, step=1)
+        hr_target_unfold = hr_target.unfold(dimension=1, size=window, step=1)
+        _, num_sliding_windows, _ = hr_input_unfold.shape
+        torch.manual_seed(123)
+        rand_indices = torch.randint(low=0, high=num_sliding_windows, size=(N,))
+        hr_input = hr_input_unfold[torch.arange(N), rand_indices, :]
+        hr_target = hr_target_unfold[torch.arange(N), rand_indices, :]
+        sliding_window_indices = rand_indices.unsqueeze(dim=1) + torch.arange(window).unsqueeze(dim=0)
+        m.train()
+        opt.zero_grad()
+        out = m(x_dec=hr_input, x_enc=lr_input, pos_cond=sliding_window_indices)
+        _, Seq, C = out.shape
+        loss = ce(out.view(N * Seq, C), hr_target.flatten())
+        loss.backward()
+        grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+        opt.step()
+        arrays = dict(sd=sd0, fmap=fmap, lr_w=lr_cb.codebook.weight.detach().clone(),
+                      hr_w=hr_cb.codebook.weight.detach().clone(), lr_patch=np.int64(8 if base else 4),
+                      hr_patch=np.int64(2), window=np.int64(window), lr_indices=lr_indices,
+                      hr_indices=hr_indices, full_input=full_in, full_target=full_tg,
+                      num_windows=np.int64(num_sliding_windows), rand_indices=rand_indices,
+                      hr_input=hr_input, hr_target=hr_target, pos=sliding_window_indices,
+                      logits=out, loss=loss, grads=grads,
+                      sd_after_adam={k: v.clone() for k, v in m.state_dict().items()})
+        if not base:
+            arrays["lr_input"] = lr_input
+        save("train_step_" + tag, **arrays)
+
+
+def gen_generation():
+    """the sampling loop of generate_images.py:256-345 driven on the reference's
+    Transformer at LEGAL temperatures (0.5 and 1.0), num_beam 2 x beam_width 4, sliding window
+    8 on 16-token sequences (so the window slides for half of the run), torch.manual_seed(69).
+    Every draw is recorded: the probability row the reference sampled from (after the <end>
+    zeroing), the token torch.multinomial returned, and the sequences kept after each chunk.
+    The loop below follows the reference's statements; the test replays the product's loop with
+    the recorded draws injected, which pins softmax(logits / T), the <end> masking, the draw
+    order over beams, the vocabulary shift, the 0,2,3,... position numbering, the
+    probability-product comparison and the >= tie rule."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(41)
+    N, K_lr, K_hr = 3, 16, 32
+    total_Seq, num_beam, beam_width, sliding_window = 16, 2, 4, 8
+    prev_tokens = torch.randint(0, K_lr, (N, 4), generator=g)          # stage k-1's output
+    for tag, index, temperature in (("base", "0", 1.0), ("encdec", "1", 0.5)):
+        base = index == "0"
+        m = _tiny_transformer(not base, K_lr + K_hr if base else K_hr + 1, K_lr, K_hr + 1,
+                              seed=51 if base else 52)
+        m.eval()
+        torch.manual_seed(69)
+        draws_p, draws_t, kept = [], [], []
+        with torch.no_grad():
+            if base:
+                lr_input = None
+                hr_input = torch.randint(low=0, high=K_lr, size=(N, 1))
+            else:
+                lr_input = prev_tokens
+                hr_input = torch.tensor([[K_hr]]).repeat(N, 1)
+            first = hr_input.clone()
+            pos_indices = torch.zeros((N, 1))
+            start_index = 0
+            _, curr_num_seq = hr_input.shape
+            while curr_num_seq < total_Seq:
+                best_hr_input = None
+                best_combined_prob = None
+                for _ in range(num_beam):
+                    total_combined_prob = 1.0
+                    temp_index = start_index
+                    temp_hr_input = hr_input
+                    temp_pos_indices = pos_indices
+                    for token_count in range(beam_width):
+                        _, temp_Seq = temp_hr_input.shape
+                        if temp_Seq >= sliding_window:
+                            temp_index = temp_index + 1
+                            temp_pos_indices = temp_pos_indices[:, 1:]
+                        temp_hr_window = temp_hr_input[:, temp_index:]
+                        out_seq = m(x_dec=temp_hr_window, x_enc=lr_input, pos_cond=temp_pos_indices)
+                        out_seq = out_seq[:, -1, :]
+                        probs = F.softmax(out_seq / temperature, dim=1)
+                        probs[:, K_hr] = 0.0
+                        next_token = torch.multinomial(probs, 1)
+                        draws_p.append(probs.clone())
+                        draws_t.append(next_token.squeeze(1).clone())
+                        next_token_probs = probs[torch.arange(N), next_token.squeeze(dim=1)]
+                        total_combined_prob = total_combined_prob * next_token_probs
+                        if base:
+                            next_token = next_token + K_lr
+                        temp_hr_input = torch.cat((temp_hr_input, next_token), dim=1)
+                        temp_indices = torch.tensor([[curr_num_seq + token_count + 1]]).repeat(N, 1)
+                        temp_pos_indices = torch.cat((temp_pos_indices, temp_indices), dim=1)
+                    if best_combined_prob is None:
+                        best_hr_input = temp_hr_input
+                        best_combined_prob = total_combined_prob
+                    else:
+                        mask_prob = (best_combined_prob >= total_combined_prob).float()
+                        best_combined_prob = (mask_prob * best_combined_prob) + ((1 - mask_prob) * total_combined_prob)
+                        mask_seq = mask_prob[:, None]
+                        best_hr_input = (mask_seq * best_hr_input) + ((1 - mask_seq) * temp_hr_input)
+                start_index = temp_index
+                hr_input = best_hr_input.long()
+                pos_indices = temp_pos_indices.long()
+                _, curr_num_seq = hr_input.shape
+                kept.append(hr_input[:, -beam_width:].clone())
+            final = hr_input[:, 1:]
+            if base:
+                final = final - K_lr
+        arrays = dict(sd={k: v.clone() for k, v in m.state_dict().items()}, first_token=first,
+                      K_lr=np.int64(K_lr), K_hr=np.int64(K_hr), total_seq=np.int64(total_Seq),
+                      num_beam=np.int64(num_beam), beam_width=np.int64(beam_width),
+                      sliding_window=np.int64(sliding_window), temperature=np.float64(temperature),
+                      draw_probs=torch.stack(draws_p), draw_tokens=torch.stack(draws_t),
+                      kept_chunks=torch.stack(kept), final_tokens=final,
+                      final_positions=pos_indices)
+        if not base:
+            arrays["lr_input"] = lr_input
+        save("generation_" + tag, **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if "--only-new" in sys.argv:       # round 2 additions (the round-1 fixtures stay byte-identical)
+        gen_train_step()
+        gen_generation()
+        sys.exit(0)
     gen_layers()
     gen_autoencoder()
     gen_bmu()
     gen_codebook()
     gen_transformer()
+    gen_train_step()
+    gen_generation()

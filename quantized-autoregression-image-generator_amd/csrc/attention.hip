@@ -4,14 +4,29 @@
 // PV, merge heads.  q/k/v/o stay in the (N, S, H*d) layout the surrounding Linear
 // layers produce -- no head permute, no (N,H,Sq,Sk) score tensor in HBM.
 //
-// The reference runs 64 heads on a 512-wide model: head dim 8.  That is too thin for
-// MFMA (K=8 / N=8 tiles) and only ~2 % of the layer's FLOPs, so the kernel is a VALU
-// one shaped for the wave: one lane per query row (q, o, m, l in registers); key/value
-// rows are staged through LDS per block and read back as wave-wide broadcasts (same
-// address in every lane: conflict-free), online softmax over chunks of 8 keys; nothing
-// crosses lanes.  (A first version fed K/V through s_load: each key's scalar-load latency
-// sat exposed in front of its 8 FMAs -- 4x slower than this one.)
-// Backward = two such passes (lane per query for dQ, lane per key for dK/dV), scores
+// The reference runs 64 heads on a 512-wide model: head dim 8.  A 32x32 or 16x16 MFMA tile
+// wastes 2-4x of its lanes on a K = 8 / N = 8 contraction, so both contractions run on the
+// 16-block form v_mfma_f32_4x4x1_16B_f32: sixteen independent 4x4 outer products per
+// instruction, no padding at any head dim that is a multiple of 4, at the full fp32 matrix
+// rate.  The mapping keeps ONE QUERY PER LANE (block b = lane/4, column j = lane%4):
+//   S^T  : D[i][j] += A[i] * B[j],  A = K[key k0+i][c]  (4 key rows, from LDS),
+//                                   B = Q[query of the lane][c]  (the lane's own register)
+//          -> after c = 0..d-1 each lane holds the scores of ITS query against 4 keys;
+//   PV   : D[i][j] += A[i] * B[j],  A = V[key][c = 4g+i] (from a transposed LDS image),
+//                                   B = p(query of the lane, key)  (own register)
+//          -> each lane accumulates O[its query][4g..4g+3] in the 4 result registers.
+// So the online softmax (max, exp2, sum, rescale) needs no cross-lane traffic at all, the
+// matrix pipe does the 4*d FMAs per (query, key) pair and the VALU only the ~10 softmax
+// operations.  An MFMA is a k-ordered fma chain, so the numbers are those of the scalar loops
+// `dot = fma(q_c, k_c, dot)` (c ascending) and `o_c = fma(p, v_c, o_c)` (keys ascending).
+//
+// Work split: a workgroup = 4 ADJACENT HEADS x (QW x 64) queries, one wave per (head, 64-query
+// slice).  Four heads of head dim 8 are one 128-B line of every (N,S,512) row, so the K/V chunk
+// a workgroup stages (coalesced 128-B row segments -> LDS, once) serves all its waves and
+// every fetched line is used whole; with QW = 4 a 256-token sequence's K/V are read exactly once.
+// Chunks are double-buffered: the global loads of chunk t+1 are issued before the
+// MFMAs of chunk t and written to the other LDS buffer after them; one barrier per chunk.
+// Backward = two such passes (lane per query for dQ, lane per key for dK/dV), probabilities
 // recomputed from the saved log-sum-exp: deterministic, no atomics.
 //
 // Softmax runs in base 2: scores are scaled by c = log2(e)/sqrt(d) in one multiply and
@@ -19,11 +34,11 @@
 // probability by <= ~1e-7 absolute (the product rounding is |x| * 2^-24 in the exponent
 // and terms with large |x| are themselves tiny), two orders inside the 1e-5 tolerance
 // stated for attention tensors; the saved LSE is kept in base-2 units (internal).
+#include <stdlib.h>
+
 #include "qarig_common.h"
 
 namespace qarig {
-
-constexpr int KC = 8;  // keys per online-softmax chunk
 
 struct AttnDims {
     int N, Sq, Sk, H, causal;
@@ -33,232 +48,498 @@ struct AttnDims {
 
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// Cooperative stage of `rows` consecutive (n,h) rows [row0, row0+rows) of a (N,S,H*HD)
-// tensor into LDS as dst[r][HD]; rows at or beyond `limit` are zero-filled.
-template <int HD>
-__device__ __forceinline__ void stage_rows(const float* __restrict__ base, int D, int row0,
-                                           int rows, int limit, float* dst) {
-    constexpr int V4 = HD / 4;
-    for (int idx = threadIdx.x; idx < rows * V4; idx += 256) {
-        const int r = idx / V4, c4 = idx - r * V4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + r < limit)
-            v = *reinterpret_cast<const float4*>(base + (int64_t)(row0 + r) * D + c4 * 4);
-        *reinterpret_cast<float4*>(dst + r * HD + c4 * 4) = v;
-    }
+constexpr int HPB = 4;   // heads per workgroup (adjacent: one 128-B line at head dim 8)
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
-// Forward.  Block = 256 queries of one (n,h) (lane per query); K/V rows are staged through
-// LDS in chunks of KCH keys (8 KB each) and read back as wave-wide broadcasts, so the
-// inner loop is pure VALU with its operand reads pipelined (no per-key scalar-load wait).
+// Geometry shared by the three kernels.  A chunk holds CH rows (keys, or queries in the dK/dV
+// pass) of the workgroup's 4 heads; every thread moves exactly one float4 per tensor per chunk.
+//   row image  R[row][4*HD + 4]   : fragment = 16-B reads of row (r0 + lane%4): conflict-free
+//   transposed T[4*HD][CH + 4]    : fragment = 16-B reads of column group (4g + lane%4)
 template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q,
-                                                       const float* __restrict__ k,
-                                                       const float* __restrict__ v, AttnDims a,
-                                                       float* __restrict__ o,
-                                                       float* __restrict__ lse) {
-    constexpr int KCH = 2048 / HD;
-    __shared__ __attribute__((aligned(16))) float Ks[KCH * HD];
-    __shared__ __attribute__((aligned(16))) float Vs[KCH * HD];
-    const int qblocks = (a.Sq + 255) >> 8;
-    const int qb = blockIdx.x % qblocks, nh = blockIdx.x / qblocks;
-    const int h = nh % a.H, n = nh / a.H;
+struct Geo {
+    static constexpr int W = HPB * HD;       // floats per staged row
+    static constexpr int V4 = W / 4;         // float4 per staged row
+    static constexpr int RS = W + 4;         // row-image stride
+    __device__ static int chunk_rows() { return blockDim.x / V4; }
+};
+
+// One thread's float4 of a chunk: row = f / V4 of [row0, row0 + CH), columns 4*(f % V4) of the
+// workgroup's head group; zero outside the tensor or beyond the last head.
+template <int HD>
+__device__ __forceinline__ float4 chunk_load(const float* __restrict__ base, int D, int row0,
+                                             int limit, int cols_valid) {
+    const int f = threadIdx.x;
+    const int r = f / Geo<HD>::V4, c4 = f - r * Geo<HD>::V4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < limit && c4 * 4 < cols_valid)
+        v = *reinterpret_cast<const float4*>(base + (int64_t)(row0 + r) * D + c4 * 4);
+    return v;
+}
+template <int HD>
+__device__ __forceinline__ void chunk_store_rows(float* R, float4 v) {
+    const int f = threadIdx.x;
+    const int r = f / Geo<HD>::V4, c4 = f - r * Geo<HD>::V4;
+    *reinterpret_cast<float4*>(R + r * Geo<HD>::RS + c4 * 4) = v;
+}
+template <int HD>
+__device__ __forceinline__ void chunk_store_transposed(float* T, int ts, float4 v) {
+    const int f = threadIdx.x;
+    const int r = f / Geo<HD>::V4, c4 = f - r * Geo<HD>::V4;
+    float* t = T + (c4 * 4) * ts + r;
+    t[0] = v.x; t[ts] = v.y; t[2 * ts] = v.z; t[3 * ts] = v.w;
+}
+
+// Forward.  Lane = query; wave = (head hh = wave % 4, query slice qq = wave / 4).
+template <int HD, int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const float* __restrict__ q,
+                                                        const float* __restrict__ k,
+                                                        const float* __restrict__ v, AttnDims a,
+                                                        float* __restrict__ o,
+                                                        float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int G = HD / 4;
+    const int CH = Geo<HD>::chunk_rows();
+    const int TS = CH + 4;
+    const int QW = blockDim.x >> 8;                    // query slices (waves per head)
+    const int QB = QW * 64;
+    const int qblocks = (a.Sq + QB - 1) / QB;
+    const int hgroups = (a.H + HPB - 1) / HPB;
+    // heaviest (latest) query blocks first under the causal mask
+    int bid = blockIdx.x;
+    const int hg = bid % hgroups; bid /= hgroups;
+    const int n = bid % a.N; bid /= a.N;
+    const int qb = qblocks - 1 - bid;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
+    const int hh = wave & 3, qq = wave >> 2;
+    const int h = hg * HPB + hh;
+    const bool head_ok = h < a.H;
     const int D = a.H * HD;
-    const int i = qb * 256 + threadIdx.x;
-    const bool active = i < a.Sq;
-    const int wave_last = __builtin_amdgcn_readfirstlane(qb * 256 + (threadIdx.x >> 6) * 64 + 63);
+    const int q0 = qb * QB + qq * 64;                  // first query of this wave
+    const int i = q0 + lane;
+    const bool active = head_ok && i < a.Sq;
+    const int li = lane & 3;
+    const int cols_valid = (a.H - hg * HPB) * HD;      // columns of the head group inside the tensor
 
-    float qv[HD], ov[HD];
-    const float* qp = q + ((int64_t)n * a.Sq + (active ? i : 0)) * D + h * HD;
+    // buffer b: K rows at b * BUF, V transposed behind them (integer offsets into `smem`: the
+    // accesses stay ds_* instructions)
+    const int BUF = CH * Geo<HD>::RS + Geo<HD>::W * TS;
+    const int VOFF = CH * Geo<HD>::RS;
+
+    float qv[HD];
+    {
+        const float* qp = q + ((int64_t)n * a.Sq + (active ? i : 0)) * D + h * HD;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) {
-        qv[c] = active ? qp[c] : 0.0f;
-        ov[c] = 0.0f;
+        for (int c = 0; c < HD; c += 4) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (active) t = *reinterpret_cast<const float4*>(qp + c);
+            qv[c] = t.x; qv[c + 1] = t.y; qv[c + 2] = t.z; qv[c + 3] = t.w;
+        }
     }
+    f32x4 ov[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) ov[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.0f;
-    const float* kb = k + (int64_t)n * a.Sk * D + h * HD;
-    const float* vb = v + (int64_t)n * a.Sk * D + h * HD;
-    const int jend_blk = a.causal ? min(a.Sk, qb * 256 + 256) : a.Sk;
 
-    for (int c0 = 0; c0 < jend_blk; c0 += KCH) {
-        __syncthreads();
-        stage_rows<HD>(kb, D, c0, KCH, a.Sk, Ks);
-        stage_rows<HD>(vb, D, c0, KCH, a.Sk, Vs);
-        __syncthreads();
-        const int jw = a.causal ? min(c0 + KCH, min(a.Sk, wave_last + 1)) : min(c0 + KCH, a.Sk);
-        for (int j0 = c0; j0 < jw; j0 += KC) {
-            float s[KC];
-            float mc = -INFINITY;
+    const float* kb = k + (int64_t)n * a.Sk * D + hg * HPB * HD;
+    const float* vb = v + (int64_t)n * a.Sk * D + hg * HPB * HD;
+    const int jend_blk = a.causal ? min(a.Sk, qb * QB + QB) : a.Sk;   // keys the workgroup needs
+    const int jend = a.causal ? min(a.Sk, q0 + 64) : a.Sk;            // keys this wave needs
+    const int nchunks = (jend_blk + CH - 1) / CH;
+
+    float4 rk = chunk_load<HD>(kb, D, 0, a.Sk, cols_valid);
+    float4 rv = chunk_load<HD>(vb, D, 0, a.Sk, cols_valid);
+    chunk_store_rows<HD>(smem, rk);
+    chunk_store_transposed<HD>(smem + VOFF, TS, rv);
+    __syncthreads();
+    for (int t = 0; t < nchunks; ++t) {
+        const int c0 = t * CH;
+        if (t + 1 < nchunks) {                         // next chunk: loads in flight under the MFMAs
+            rk = chunk_load<HD>(kb, D, c0 + CH, a.Sk, cols_valid);
+            rv = chunk_load<HD>(vb, D, c0 + CH, a.Sk, cols_valid);
+        }
+        const float* Kc = smem + (t & 1) * BUF + hh * HD;
+        const float* Vc = smem + (t & 1) * BUF + VOFF + (hh * HD) * TS;
+        const int jw = min(c0 + CH, jend);
+        for (int j0 = c0; j0 < jw; j0 += 8) {
+            const int jj = j0 - c0;
+            // S^T for 8 keys: two accumulators (keys jj..jj+3, jj+4..jj+7), c ascending
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+            const float* kr = Kc + (jj + li) * Geo<HD>::RS;
 #pragma unroll
-            for (int jj = 0; jj < KC; ++jj) {
-                const int j = j0 + jj;
-                const float* kr = Ks + (j - c0) * HD;
-                float dot = 0.0f;
+            for (int g = 0; g < G; ++g) {
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(kr + 4 * g);
+                const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kr + 4 * Geo<HD>::RS + 4 * g);
 #pragma unroll
-                for (int c = 0; c < HD; ++c) dot = fmaf(qv[c], kr[c], dot);
-                float t = dot * a.c2;
-                if (j >= jw || (a.causal && j > i)) t = -INFINITY;
-                s[jj] = t;
-                mc = fmaxf(mc, t);
+                for (int c = 0; c < 4; ++c) {
+                    s0 = mfma4(ka[c], qv[4 * g + c], s0);
+                    s1 = mfma4(kb4[c], qv[4 * g + c], s1);
+                }
             }
+            float sc[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[r] = s0[r] * a.c2; sc[4 + r] = s1[r] * a.c2; }
+            if (j0 + 8 > jw || (a.causal && j0 + 7 > q0)) {          // wave-uniform: edge steps only
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (j0 + r >= jw || (a.causal && j0 + r > i)) sc[r] = -INFINITY;
+            }
+            float mc = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])),
+                             fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
             const float mn = fmaxf(m, mc);
-            const float msafe = mn == -INFINITY ? 0.0f : mn;  // fully masked so far: p = 0
+            const float msafe = mn == -INFINITY ? 0.0f : mn;     // fully masked so far: p = 0
             const float alpha = exp2_fast(m - msafe);
             l *= alpha;
 #pragma unroll
-            for (int c = 0; c < HD; ++c) ov[c] *= alpha;
+            for (int g = 0; g < G; ++g) ov[g] *= alpha;
+            float p[8];
 #pragma unroll
-            for (int jj = 0; jj < KC; ++jj) {
-                const float p = exp2_fast(s[jj] - msafe);
-                l += p;
-                const float* vr = Vs + (j0 + jj - c0) * HD;
-#pragma unroll
-                for (int c = 0; c < HD; ++c) ov[c] = fmaf(p, vr[c], ov[c]);
-            }
+            for (int r = 0; r < 8; ++r) { p[r] = exp2_fast(sc[r] - msafe); l += p[r]; }
             m = mn;
+            // PV: keys ascending per output column group
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float* vr = Vc + (4 * g + li) * TS + jj;
+                const f32x4 va = *reinterpret_cast<const f32x4*>(vr);
+                const f32x4 vb4 = *reinterpret_cast<const f32x4*>(vr + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[g] = mfma4(va[r], p[r], ov[g]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[g] = mfma4(vb4[r], p[4 + r], ov[g]);
+            }
         }
+        if (t + 1 < nchunks) {
+            chunk_store_rows<HD>(smem + ((t + 1) & 1) * BUF, rk);
+            chunk_store_transposed<HD>(smem + ((t + 1) & 1) * BUF + VOFF, TS, rv);
+        }
+        __syncthreads();
     }
     if (active) {
         float* op = o + ((int64_t)n * a.Sq + i) * D + h * HD;
         const float inv = 1.0f / l;
 #pragma unroll
-        for (int c = 0; c < HD; ++c) op[c] = ov[c] * inv;
+        for (int g = 0; g < G; ++g)
+            *reinterpret_cast<float4*>(op + 4 * g) =
+                make_float4(ov[g][0] * inv, ov[g][1] * inv, ov[g][2] * inv, ov[g][3] * inv);
         lse[((int64_t)n * a.H + h) * a.Sq + i] = m + log2f(l);   // base-2 units
     }
 }
 
-// dQ pass: lane per query, K/V through LDS.  Also emits delta[i] = sum_c dO[i][c]*O[i][c].
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
+// dQ pass: lane = query; per chunk the K rows, V rows and K transposed.  Also emits
+// delta[i] = sum_c dO[i][c] * O[i][c].
+template <int HD, int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ o, const float* __restrict__ dO, const float* __restrict__ lse,
     AttnDims a, float* __restrict__ dq, float* __restrict__ delta) {
-    constexpr int KCH = 2048 / HD;
-    __shared__ __attribute__((aligned(16))) float Ks[KCH * HD];
-    __shared__ __attribute__((aligned(16))) float Vs[KCH * HD];
-    const int qblocks = (a.Sq + 255) >> 8;
-    const int qb = blockIdx.x % qblocks, nh = blockIdx.x / qblocks;
-    const int h = nh % a.H, n = nh / a.H;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int G = HD / 4;
+    const int CH = Geo<HD>::chunk_rows();
+    const int TS = CH + 4;
+    const int QW = blockDim.x >> 8;
+    const int QB = QW * 64;
+    const int qblocks = (a.Sq + QB - 1) / QB;
+    const int hgroups = (a.H + HPB - 1) / HPB;
+    int bid = blockIdx.x;
+    const int hg = bid % hgroups; bid /= hgroups;
+    const int n = bid % a.N; bid /= a.N;
+    const int qb = qblocks - 1 - bid;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
+    const int hh = wave & 3, qq = wave >> 2;
+    const int h = hg * HPB + hh;
+    const bool head_ok = h < a.H;
     const int D = a.H * HD;
-    const int i = qb * 256 + threadIdx.x;
-    const bool active = i < a.Sq;
-    const int wave_last = __builtin_amdgcn_readfirstlane(qb * 256 + (threadIdx.x >> 6) * 64 + 63);
-    const int64_t roff = ((int64_t)n * a.Sq + (active ? i : 0)) * D + h * HD;
+    const int q0 = qb * QB + qq * 64;
+    const int i = q0 + lane;
+    const bool active = head_ok && i < a.Sq;
+    const int li = lane & 3;
+    const int cols_valid = (a.H - hg * HPB) * HD;
+    // buffer b at b * BUF: K rows | V rows | K transposed
+    const int BUF = 2 * CH * Geo<HD>::RS + Geo<HD>::W * TS;
+    const int VOFF = CH * Geo<HD>::RS, TOFF = 2 * CH * Geo<HD>::RS;
 
-    float qv[HD], dov[HD], acc[HD];
+    const int64_t roff = ((int64_t)n * a.Sq + (active ? i : 0)) * D + h * HD;
+    float qv[HD], dov[HD];
     float dl = 0.0f;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) {
-        qv[c] = active ? q[roff + c] : 0.0f;
-        dov[c] = active ? dO[roff + c] : 0.0f;
-        const float oc = active ? o[roff + c] : 0.0f;
-        dl = fmaf(dov[c], oc, dl);
-        acc[c] = 0.0f;
+    for (int c = 0; c < HD; c += 4) {
+        float4 tq = make_float4(0.f, 0.f, 0.f, 0.f), tg = tq, to = tq;
+        if (active) {
+            tq = *reinterpret_cast<const float4*>(q + roff + c);
+            tg = *reinterpret_cast<const float4*>(dO + roff + c);
+            to = *reinterpret_cast<const float4*>(o + roff + c);
+        }
+        qv[c] = tq.x; qv[c + 1] = tq.y; qv[c + 2] = tq.z; qv[c + 3] = tq.w;
+        dov[c] = tg.x; dov[c + 1] = tg.y; dov[c + 2] = tg.z; dov[c + 3] = tg.w;
+        dl = fmaf(tg.x, to.x, dl); dl = fmaf(tg.y, to.y, dl);
+        dl = fmaf(tg.z, to.z, dl); dl = fmaf(tg.w, to.w, dl);
     }
     const float L = active ? lse[((int64_t)n * a.H + h) * a.Sq + i] : 0.0f;
-    const float* kb = k + (int64_t)n * a.Sk * D + h * HD;
-    const float* vb = v + (int64_t)n * a.Sk * D + h * HD;
-    const int jend_blk = a.causal ? min(a.Sk, qb * 256 + 256) : a.Sk;
-    for (int c0 = 0; c0 < jend_blk; c0 += KCH) {
-        __syncthreads();
-        stage_rows<HD>(kb, D, c0, KCH, a.Sk, Ks);
-        stage_rows<HD>(vb, D, c0, KCH, a.Sk, Vs);
-        __syncthreads();
-        const int jw = a.causal ? min(c0 + KCH, min(a.Sk, wave_last + 1)) : min(c0 + KCH, a.Sk);
-#pragma unroll 4
-        for (int j = c0; j < jw; ++j) {
-            const float* kr = Ks + (j - c0) * HD;
-            const float* vr = Vs + (j - c0) * HD;
-            float dot = 0.0f, dp = 0.0f;
+    f32x4 acc[G];
 #pragma unroll
-            for (int c = 0; c < HD; ++c) {
-                dot = fmaf(qv[c], kr[c], dot);
-                dp = fmaf(dov[c], vr[c], dp);
-            }
-            float p = exp2_fast(fmaf(dot, a.c2, -L));
-            if (a.causal && j > i) p = 0.0f;
-            const float ds = p * (dp - dl);
-#pragma unroll
-            for (int c = 0; c < HD; ++c) acc[c] = fmaf(ds, kr[c], acc[c]);
+    for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float* kb = k + (int64_t)n * a.Sk * D + hg * HPB * HD;
+    const float* vb = v + (int64_t)n * a.Sk * D + hg * HPB * HD;
+    const int jend_blk = a.causal ? min(a.Sk, qb * QB + QB) : a.Sk;
+    const int jend = a.causal ? min(a.Sk, q0 + 64) : a.Sk;
+    const int nchunks = (jend_blk + CH - 1) / CH;
+
+    float4 rk = chunk_load<HD>(kb, D, 0, a.Sk, cols_valid);
+    float4 rv = chunk_load<HD>(vb, D, 0, a.Sk, cols_valid);
+    chunk_store_rows<HD>(smem, rk);
+    chunk_store_rows<HD>(smem + VOFF, rv);
+    chunk_store_transposed<HD>(smem + TOFF, TS, rk);
+    __syncthreads();
+    for (int t = 0; t < nchunks; ++t) {
+        const int c0 = t * CH;
+        if (t + 1 < nchunks) {
+            rk = chunk_load<HD>(kb, D, c0 + CH, a.Sk, cols_valid);
+            rv = chunk_load<HD>(vb, D, c0 + CH, a.Sk, cols_valid);
         }
+        const float* Kc = smem + (t & 1) * BUF + hh * HD;
+        const float* Vc = smem + (t & 1) * BUF + VOFF + hh * HD;
+        const float* Tc = smem + (t & 1) * BUF + TOFF + (hh * HD) * TS;
+        const int jw = min(c0 + CH, jend);
+        for (int j0 = c0; j0 < jw; j0 += 8) {
+            const int jj = j0 - c0;
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
+            const float* kr = Kc + (jj + li) * Geo<HD>::RS;
+            const float* vr = Vc + (jj + li) * Geo<HD>::RS;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(kr + 4 * g);
+                const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kr + 4 * Geo<HD>::RS + 4 * g);
+                const f32x4 va = *reinterpret_cast<const f32x4*>(vr + 4 * g);
+                const f32x4 vb4 = *reinterpret_cast<const f32x4*>(vr + 4 * Geo<HD>::RS + 4 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s0 = mfma4(ka[c], qv[4 * g + c], s0);
+                    s1 = mfma4(kb4[c], qv[4 * g + c], s1);
+                    d0 = mfma4(va[c], dov[4 * g + c], d0);
+                    d1 = mfma4(vb4[c], dov[4 * g + c], d1);
+                }
+            }
+            float ds[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ds[r] = exp2_fast(fmaf(s0[r], a.c2, -L)) * (d0[r] - dl);
+                ds[4 + r] = exp2_fast(fmaf(s1[r], a.c2, -L)) * (d1[r] - dl);
+            }
+            if (j0 + 8 > jw || (a.causal && j0 + 7 > q0)) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (j0 + r >= jw || (a.causal && j0 + r > i)) ds[r] = 0.0f;
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float* tr = Tc + (4 * g + li) * TS + jj;
+                const f32x4 ta = *reinterpret_cast<const f32x4*>(tr);
+                const f32x4 tb = *reinterpret_cast<const f32x4*>(tr + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[g] = mfma4(ta[r], ds[r], acc[g]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[g] = mfma4(tb[r], ds[4 + r], acc[g]);
+            }
+        }
+        if (t + 1 < nchunks) {
+            float* nb = smem + ((t + 1) & 1) * BUF;
+            chunk_store_rows<HD>(nb, rk);
+            chunk_store_rows<HD>(nb + VOFF, rv);
+            chunk_store_transposed<HD>(nb + TOFF, TS, rk);
+        }
+        __syncthreads();
     }
     if (active) {
 #pragma unroll
-        for (int c = 0; c < HD; ++c) dq[roff + c] = acc[c] * a.rsd;
+        for (int g = 0; g < G; ++g)
+            *reinterpret_cast<float4*>(dq + roff + 4 * g) =
+                make_float4(acc[g][0] * a.rsd, acc[g][1] * a.rsd, acc[g][2] * a.rsd, acc[g][3] * a.rsd);
         delta[((int64_t)n * a.H + h) * a.Sq + i] = dl;
     }
 }
 
-// dK/dV pass: lane per key; Q, dO, LSE and delta rows come through LDS.
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
+// dK/dV pass: lane = key; per chunk of queries the Q rows, dO rows and both transposed, plus
+// the chunk's LSE and delta values (wave-uniform per query: read as LDS broadcasts).
+template <int HD, int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ delta,
     AttnDims a, float* __restrict__ dk, float* __restrict__ dv) {
-    constexpr int QCH = 2048 / HD;
-    __shared__ __attribute__((aligned(16))) float Qs[QCH * HD];
-    __shared__ __attribute__((aligned(16))) float Gs[QCH * HD];
-    __shared__ float Ls[QCH];
-    __shared__ float Ds[QCH];
-    const int kblocks = (a.Sk + 255) >> 8;
-    const int kbk = blockIdx.x % kblocks, nh = blockIdx.x / kblocks;
-    const int h = nh % a.H, n = nh / a.H;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int G = HD / 4;
+    const int CH = Geo<HD>::chunk_rows();
+    const int TS = CH + 4;
+    const int KW = blockDim.x >> 8;
+    const int KB = KW * 64;
+    const int kblocks = (a.Sk + KB - 1) / KB;
+    const int hgroups = (a.H + HPB - 1) / HPB;
+    int bid = blockIdx.x;
+    const int hg = bid % hgroups; bid /= hgroups;
+    const int n = bid % a.N; bid /= a.N;
+    const int kbk = bid;                                // earliest key blocks are the heaviest (causal)
+    (void)kblocks;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hh = wave & 3, kq = wave >> 2;
+    const int h = hg * HPB + hh;
+    const bool head_ok = h < a.H;
     const int D = a.H * HD;
-    const int j = kbk * 256 + threadIdx.x;
-    const bool active = j < a.Sk;
-    const int wave_first = __builtin_amdgcn_readfirstlane(kbk * 256 + (threadIdx.x >> 6) * 64);
-    const int64_t roff = ((int64_t)n * a.Sk + (active ? j : 0)) * D + h * HD;
+    const int k0 = kbk * KB + kq * 64;                  // first key of this wave
+    const int j = k0 + lane;
+    const bool active = head_ok && j < a.Sk;
+    const int li = lane & 3;
+    const int cols_valid = (a.H - hg * HPB) * HD;
+    // per buffer: Q rows | dO rows | Q^T | dO^T | LSE[4][CH] | delta[4][CH]
+    const int BUF = 2 * CH * Geo<HD>::RS + 2 * Geo<HD>::W * TS + 2 * HPB * CH;
+    const int GOFF = CH * Geo<HD>::RS, QTOFF = 2 * CH * Geo<HD>::RS;
+    const int GTOFF = QTOFF + Geo<HD>::W * TS, LOFF = GTOFF + Geo<HD>::W * TS, DOFF = LOFF + HPB * CH;
 
-    float kv[HD], vv[HD], dka[HD], dva[HD];
+    const int64_t roff = ((int64_t)n * a.Sk + (active ? j : 0)) * D + h * HD;
+    float kv[HD], vv[HD];
 #pragma unroll
-    for (int c = 0; c < HD; ++c) {
-        kv[c] = active ? k[roff + c] : 0.0f;
-        vv[c] = active ? v[roff + c] : 0.0f;
-        dka[c] = 0.0f;
-        dva[c] = 0.0f;
+    for (int c = 0; c < HD; c += 4) {
+        float4 tk = make_float4(0.f, 0.f, 0.f, 0.f), tv = tk;
+        if (active) {
+            tk = *reinterpret_cast<const float4*>(k + roff + c);
+            tv = *reinterpret_cast<const float4*>(v + roff + c);
+        }
+        kv[c] = tk.x; kv[c + 1] = tk.y; kv[c + 2] = tk.z; kv[c + 3] = tk.w;
+        vv[c] = tv.x; vv[c + 1] = tv.y; vv[c + 2] = tv.z; vv[c + 3] = tv.w;
     }
-    const float* qb = q + (int64_t)n * a.Sq * D + h * HD;
-    const float* dob = dO + (int64_t)n * a.Sq * D + h * HD;
-    const float* lb = lse + ((int64_t)n * a.H + h) * a.Sq;
-    const float* db = delta + ((int64_t)n * a.H + h) * a.Sq;
-    // causal: only queries i >= first key of the block matter
-    const int ibeg_blk = a.causal ? (kbk * 256) / QCH * QCH : 0;
-    for (int c0 = ibeg_blk; c0 < a.Sq; c0 += QCH) {
-        __syncthreads();
-        stage_rows<HD>(qb, D, c0, QCH, a.Sq, Qs);
-        stage_rows<HD>(dob, D, c0, QCH, a.Sq, Gs);
-        for (int r = threadIdx.x; r < QCH; r += 256) {
-            Ls[r] = c0 + r < a.Sq ? lb[c0 + r] : 0.0f;
-            Ds[r] = c0 + r < a.Sq ? db[c0 + r] : 0.0f;
+    f32x4 dka[G], dva[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { dka[g] = f32x4{0.f, 0.f, 0.f, 0.f}; dva[g] = dka[g]; }
+
+    const float* qbase = q + (int64_t)n * a.Sq * D + hg * HPB * HD;
+    const float* gbase = dO + (int64_t)n * a.Sq * D + hg * HPB * HD;
+    const float* lb = lse + ((int64_t)n * a.H + hg * HPB) * a.Sq;
+    const float* db = delta + ((int64_t)n * a.H + hg * HPB) * a.Sq;
+    // causal: only queries i >= first key of the workgroup matter
+    const int ibeg_blk = a.causal ? (kbk * KB) / CH * CH : 0;
+    const int ibeg = a.causal ? k0 : 0;                 // first query this wave needs
+    const int nchunks = a.Sq > ibeg_blk ? (a.Sq - ibeg_blk + CH - 1) / CH : 0;
+    // LSE / delta of the chunk: HPB * CH values, one per thread while they last
+    const int lrow = threadIdx.x / CH, lcol = threadIdx.x - lrow * CH;
+    const bool lth = threadIdx.x < HPB * CH;
+    auto load_ld = [&](int c0, float& rl, float& rd) {
+        rl = 0.0f; rd = 0.0f;
+        if (lth && hg * HPB + lrow < a.H && c0 + lcol < a.Sq) {
+            rl = lb[(int64_t)lrow * a.Sq + c0 + lcol];
+            rd = db[(int64_t)lrow * a.Sq + c0 + lcol];
+        }
+    };
+    float4 rq, rg;
+    float rl, rd;
+    if (nchunks > 0) {
+        rq = chunk_load<HD>(qbase, D, ibeg_blk, a.Sq, cols_valid);
+        rg = chunk_load<HD>(gbase, D, ibeg_blk, a.Sq, cols_valid);
+        load_ld(ibeg_blk, rl, rd);
+        chunk_store_rows<HD>(smem, rq);
+        chunk_store_rows<HD>(smem + GOFF, rg);
+        chunk_store_transposed<HD>(smem + QTOFF, TS, rq);
+        chunk_store_transposed<HD>(smem + GTOFF, TS, rg);
+        if (lth) { smem[LOFF + threadIdx.x] = rl; smem[DOFF + threadIdx.x] = rd; }
+    }
+    __syncthreads();
+    for (int t = 0; t < nchunks; ++t) {
+        const int c0 = ibeg_blk + t * CH;
+        if (t + 1 < nchunks) {
+            rq = chunk_load<HD>(qbase, D, c0 + CH, a.Sq, cols_valid);
+            rg = chunk_load<HD>(gbase, D, c0 + CH, a.Sq, cols_valid);
+            load_ld(c0 + CH, rl, rd);
+        }
+        const float* cb = smem + (t & 1) * BUF;
+        const float* Qc = cb + hh * HD;
+        const float* Gc = cb + GOFF + hh * HD;
+        const float* QTc = cb + QTOFF + (hh * HD) * TS;
+        const float* GTc = cb + GTOFF + (hh * HD) * TS;
+        const float* Lc = cb + LOFF + hh * CH;
+        const float* Dc = cb + DOFF + hh * CH;
+        const int i1 = min(c0 + CH, a.Sq);
+        // first 8-aligned step that holds a query this wave needs
+        int i0 = c0;
+        if (ibeg > c0) i0 = c0 + ((ibeg - c0) & ~7);
+        for (; i0 < i1; i0 += 8) {
+            const int ii = i0 - c0;
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
+            const float* qr = Qc + (ii + li) * Geo<HD>::RS;
+            const float* gr = Gc + (ii + li) * Geo<HD>::RS;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(qr + 4 * g);
+                const f32x4 qb4 = *reinterpret_cast<const f32x4*>(qr + 4 * Geo<HD>::RS + 4 * g);
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(gr + 4 * g);
+                const f32x4 gb4 = *reinterpret_cast<const f32x4*>(gr + 4 * Geo<HD>::RS + 4 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s0 = mfma4(qa[c], kv[4 * g + c], s0);
+                    s1 = mfma4(qb4[c], kv[4 * g + c], s1);
+                    d0 = mfma4(ga[c], vv[4 * g + c], d0);
+                    d1 = mfma4(gb4[c], vv[4 * g + c], d1);
+                }
+            }
+            const f32x4 La = *reinterpret_cast<const f32x4*>(Lc + ii);
+            const f32x4 Lb = *reinterpret_cast<const f32x4*>(Lc + ii + 4);
+            const f32x4 Da = *reinterpret_cast<const f32x4*>(Dc + ii);
+            const f32x4 Db = *reinterpret_cast<const f32x4*>(Dc + ii + 4);
+            float p[8], ds[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = exp2_fast(fmaf(s0[r], a.c2, -La[r]));
+                p[4 + r] = exp2_fast(fmaf(s1[r], a.c2, -Lb[r]));
+            }
+            if (i0 + 8 > i1 || (a.causal && i0 < k0 + 63)) {         // wave-uniform: edge steps only
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (i0 + r >= i1 || (a.causal && j > i0 + r)) p[r] = 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ds[r] = p[r] * (d0[r] - Da[r]);
+                ds[4 + r] = p[4 + r] * (d1[r] - Db[r]);
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float* gt = GTc + (4 * g + li) * TS + ii;
+                const float* qt = QTc + (4 * g + li) * TS + ii;
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(gt);
+                const f32x4 gb4 = *reinterpret_cast<const f32x4*>(gt + 4);
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(qt);
+                const f32x4 qb4 = *reinterpret_cast<const f32x4*>(qt + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dva[g] = mfma4(ga[r], p[r], dva[g]);
+                    dka[g] = mfma4(qa[r], ds[r], dka[g]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dva[g] = mfma4(gb4[r], p[4 + r], dva[g]);
+                    dka[g] = mfma4(qb4[r], ds[4 + r], dka[g]);
+                }
+            }
+        }
+        if (t + 1 < nchunks) {
+            float* nb = smem + ((t + 1) & 1) * BUF;
+            chunk_store_rows<HD>(nb, rq);
+            chunk_store_rows<HD>(nb + GOFF, rg);
+            chunk_store_transposed<HD>(nb + QTOFF, TS, rq);
+            chunk_store_transposed<HD>(nb + GTOFF, TS, rg);
+            if (lth) { nb[LOFF + threadIdx.x] = rl; nb[DOFF + threadIdx.x] = rd; }
         }
         __syncthreads();
-        const int i0 = a.causal ? max(c0, wave_first) : c0;
-        const int i1 = min(c0 + QCH, a.Sq);
-#pragma unroll 4
-        for (int i = i0; i < i1; ++i) {
-            const float* qr = Qs + (i - c0) * HD;
-            const float* dor = Gs + (i - c0) * HD;
-            float dot = 0.0f, dp = 0.0f;
-#pragma unroll
-            for (int c = 0; c < HD; ++c) {
-                dot = fmaf(qr[c], kv[c], dot);
-                dp = fmaf(dor[c], vv[c], dp);
-            }
-            float p = exp2_fast(fmaf(dot, a.c2, -Ls[i - c0]));
-            if (a.causal && j > i) p = 0.0f;
-            const float ds = p * (dp - Ds[i - c0]);
-#pragma unroll
-            for (int c = 0; c < HD; ++c) {
-                dva[c] = fmaf(p, dor[c], dva[c]);
-                dka[c] = fmaf(ds, qr[c], dka[c]);
-            }
-        }
     }
     if (active) {
 #pragma unroll
-        for (int c = 0; c < HD; ++c) {
-            dk[roff + c] = dka[c] * a.rsd;
-            dv[roff + c] = dva[c];
+        for (int g = 0; g < G; ++g) {
+            *reinterpret_cast<float4*>(dk + roff + 4 * g) =
+                make_float4(dka[g][0] * a.rsd, dka[g][1] * a.rsd, dka[g][2] * a.rsd, dka[g][3] * a.rsd);
+            *reinterpret_cast<float4*>(dv + roff + 4 * g) =
+                make_float4(dva[g][0], dva[g][1], dva[g][2], dva[g][3]);
         }
     }
 }
@@ -348,13 +629,13 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(
 
 using namespace qarig;
 
-#define QARIG_HD_DISPATCH(d, CALL)                                               \
+#define QARIG_HD_DISPATCH(d, ...)                                              \
     switch (d) {                                                                 \
-        case 4: { constexpr int HD = 4; CALL; } break;                           \
-        case 8: { constexpr int HD = 8; CALL; } break;                           \
-        case 16: { constexpr int HD = 16; CALL; } break;                         \
-        case 32: { constexpr int HD = 32; CALL; } break;                         \
-        case 64: { constexpr int HD = 64; CALL; } break;                         \
+        case 4: { constexpr int HD = 4; __VA_ARGS__; } break;                           \
+        case 8: { constexpr int HD = 8; __VA_ARGS__; } break;                           \
+        case 16: { constexpr int HD = 16; __VA_ARGS__; } break;                         \
+        case 32: { constexpr int HD = 32; __VA_ARGS__; } break;                         \
+        case 64: { constexpr int HD = 64; __VA_ARGS__; } break;                         \
         default:                                                                 \
             qarig_set_error("attention: head dim %d unsupported (4,8,16,32,64)", d); \
             return QARIG_ERR_ARG;                                                \
@@ -366,6 +647,47 @@ static int attn_check(int N, int Sq, int Sk, int H, int d, int causal) {
     return QARIG_OK;
 }
 
+// Launch geometry: a workgroup covers 4 adjacent heads x (W x 64) rows (queries; keys in the
+// dK/dV pass), W waves per head.  W = 4 reads a 256-token sequence's K/V exactly once; the
+// backward passes hold more LDS per chunk (three / four images), so they default to W = 2.
+// QARIG_ATTN_QW / QARIG_ATTN_BW override (1, 2 or 4; tuning knob, any value is correct).
+static int attn_waves(int rows, int d, const char* env, int dflt, int wmax) {
+    int w = dflt;
+    if (const char* e = getenv(env)) w = atoi(e);
+    w = w >= 4 ? 4 : (w >= 2 ? 2 : 1);
+    if (w > wmax) w = wmax;
+    while (w > 1 && (w / 2) * 64 >= rows) w /= 2;      // no more slices than the rows need
+    while (w < wmax && (w * 256) / d < 8) w *= 2;       // a chunk holds at least 8 rows
+    return w;
+}
+
+// register budget: 1024-thread workgroups (4 waves per SIMD) cap a wave at 128 VGPRs, enough for
+// the forward pass up to head dim 16; wider heads and the backward passes run 512 threads
+#define QARIG_FWD_MAXT(HD) ((HD) <= 16 ? 1024 : 512)
+
+template <typename K>
+static int attn_set_lds(K kernel, size_t bytes, const char* what) {
+    if (bytes > 160 * 1024) {
+        qarig_set_error("%s: needs %zu B of LDS", what, bytes);
+        return QARIG_ERR_ARG;
+    }
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) {
+            qarig_set_error("%s: hipFuncSetAttribute(%zu B LDS): %s", what, bytes, hipGetErrorString(e));
+            return QARIG_ERR_LAUNCH;
+        }
+    }
+    return QARIG_OK;
+}
+
+// floats of LDS per double-buffered chunk set: `rows` row images + `tr` transposed images (+ LSE/delta)
+static size_t attn_lds_bytes(int threads, int d, int rows, int tr, bool ld) {
+    const int W = HPB * d, CH = threads / (W / 4);
+    return 2 * sizeof(float) * ((size_t)rows * CH * (W + 4) + (size_t)tr * W * (CH + 4) + (ld ? 2 * HPB * CH : 0));
+}
+
 // q: (N,Sq,H*d); k,v: (N,Sk,H*d); o: (N,Sq,H*d); lse: (N,H,Sq).  sqrt_d is passed by
 // the host as float(d ** 0.5), the divisor the reference uses (layers.py:446).
 extern "C" int qarig_attention_fwd(const float* q, const float* k, const float* v, int N, int Sq,
@@ -374,9 +696,15 @@ extern "C" int qarig_attention_fwd(const float* q, const float* k, const float* 
     QARIG_CHECK_ARG(q && k && v && o && lse, "attention_fwd: null pointer");
     if (int e = attn_check(N, Sq, Sk, H, d, causal)) return e;
     AttnDims a{N, Sq, Sk, H, causal, 1.4426950408889634f / sqrt_d, 1.0f / sqrt_d};
-    dim3 grid(N * H * ((Sq + 255) / 256)), block(256);
-    QARIG_HD_DISPATCH(d, hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, block, 0,
-                                            (hipStream_t)stream, q, k, v, a, o, lse));
+    const int W = attn_waves(Sq, d, "QARIG_ATTN_QW", 4, d <= 16 ? 4 : 2);
+    const int threads = 256 * W, rows = 64 * W;
+    const size_t lds = attn_lds_bytes(threads, d, 1, 1, false);
+    dim3 grid((unsigned)(N * ((H + HPB - 1) / HPB) * ((Sq + rows - 1) / rows))), block(threads);
+    QARIG_HD_DISPATCH(d, {
+        auto kern = attn_fwd_kernel<HD, QARIG_FWD_MAXT(HD)>;
+        if (int e = attn_set_lds(kern, lds, "attention_fwd")) return e;
+        hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, q, k, v, a, o, lse);
+    });
     QARIG_CHECK_LAUNCH("attention_fwd");
     return QARIG_OK;
 }
@@ -390,17 +718,31 @@ extern "C" int qarig_attention_bwd(const float* q, const float* k, const float* 
                     "attention_bwd: null pointer");
     if (int e = attn_check(N, Sq, Sk, H, d, causal)) return e;
     AttnDims a{N, Sq, Sk, H, causal, 1.4426950408889634f / sqrt_d, 1.0f / sqrt_d};
-    const int qblocks = N * H * ((Sq + 255) / 256);
-    const int kblocks = N * H * ((Sk + 255) / 256);
-    dim3 block(256);
-    QARIG_HD_DISPATCH(d, hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), dim3(qblocks), block,
-                                            0, (hipStream_t)stream, q, k, v, o, dO, lse, a, dq,
-                                            delta));
-    QARIG_CHECK_LAUNCH("attention_bwd dq");
-    QARIG_HD_DISPATCH(d, hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD>), dim3(kblocks), block,
-                                            0, (hipStream_t)stream, q, k, v, dO, lse, delta, a, dk,
-                                            dv));
-    QARIG_CHECK_LAUNCH("attention_bwd dkv");
+    const int hgroups = (H + HPB - 1) / HPB;
+    {
+        const int W = attn_waves(Sq, d, "QARIG_ATTN_BW", 2, 2);
+        const int threads = 256 * W, rows = 64 * W;
+        const size_t lds = attn_lds_bytes(threads, d, 2, 1, false);
+        dim3 grid((unsigned)(N * hgroups * ((Sq + rows - 1) / rows))), block(threads);
+        QARIG_HD_DISPATCH(d, {
+            auto kern = attn_bwd_dq_kernel<HD, 512>;
+            if (int e = attn_set_lds(kern, lds, "attention_bwd dq")) return e;
+            hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, q, k, v, o, dO, lse, a, dq, delta);
+        });
+        QARIG_CHECK_LAUNCH("attention_bwd dq");
+    }
+    {
+        const int W = attn_waves(Sk, d, "QARIG_ATTN_BW", 2, 2);
+        const int threads = 256 * W, rows = 64 * W;
+        const size_t lds = attn_lds_bytes(threads, d, 2, 2, true);
+        dim3 grid((unsigned)(N * hgroups * ((Sk + rows - 1) / rows))), block(threads);
+        QARIG_HD_DISPATCH(d, {
+            auto kern = attn_bwd_dkv_kernel<HD, 512>;
+            if (int e = attn_set_lds(kern, lds, "attention_bwd dkv")) return e;
+            hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, q, k, v, dO, lse, delta, a, dk, dv);
+        });
+        QARIG_CHECK_LAUNCH("attention_bwd dkv");
+    }
     return QARIG_OK;
 }
 

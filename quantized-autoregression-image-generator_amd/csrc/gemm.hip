@@ -92,13 +92,28 @@ struct RowSumHook {
     }
 };
 
+// Co-resident workgroups of the first dispatch round start together, run their k-loops in
+// lockstep and so reach their epilogues together: the 2 x 64 KB of stores per tile (C and the
+// saved pre-activation) then hit HBM from every CU at once while every matrix pipe idles, and
+// the following rounds inherit the phase (measured: MFMA pipe busy 0.71-0.76 of the kernel's
+// cycles, profiles/r02a_sq_by_kernel.csv).  De-phase them once: a wave in SIMD wave slot s
+// (HW_ID.wave_id, 0..3 with four resident workgroups per CU) sleeps s * `units` * 8128 cycles
+// before its first load, first round only; the epilogue of one workgroup then runs under the
+// MFMAs of the other three for the rest of the launch.  Placement only changes speed.
+__device__ __forceinline__ void stagger_first_round(int units) {
+    if (units <= 0 || blockIdx.x >= 1024u) return;
+    const int slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15;   // HW_REG_HW_ID[3:0]
+    for (int i = 0; i < slot * units; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 // FAST: every tile interior (M,N multiples of 128, every K split a multiple of 16,
 // vector-loadable operands) -- branch-free main loop, unguarded epilogue.
 template <class SA, class SB, bool FAST>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpilogue ep, int M,
                                                            int N, int K, int tiles_n, int splitk,
-                                                           float* slabs, int vec_epi) {
+                                                           float* slabs, int vec_epi, int stagger) {
     __shared__ __attribute__((aligned(16))) float lds[GEMM_LDS_FLOATS];
+    if (FAST) stagger_first_round(stagger);
     const int nwg = gridDim.x;
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
@@ -226,8 +241,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const float* __re
                                                                const float* __restrict__ B,
                                                                int64_t ldb, GemmEpilogue ep, int M,
                                                                int N, int K, int tiles_n, int splitk,
-                                                               float* slabs) {
+                                                               float* slabs, int stagger) {
     __shared__ __attribute__((aligned(16))) float lds[DMA_STAGES * DMA_STAGE_FLOATS];   // 32 KB
+    stagger_first_round(stagger);
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -657,6 +673,11 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     // there), so pick per shape
     static const bool dma_all = []() { const char* e = getenv("QARIG_GEMM_DMA_ALL"); return e && e[0] == '1'; }();
     const bool dma_shape = dma_all || per >= 1024 || N <= 512;
+    // stagger (units of 8128-cycle sleeps per wave slot) only where the grid spans more than
+    // one dispatch round of ~4 workgroups per CU; QARIG_GEMM_STAGGER overrides (0 = off)
+    const char* stagger_e = getenv("QARIG_GEMM_STAGGER");
+    const int stagger_env = stagger_e ? atoi(stagger_e) : -1;
+    const int stagger = (long)grid.x * grid.z >= 1024 ? (stagger_env >= 0 ? stagger_env : 2) : 0;
     if (bf16 && fast && vec_epi && !a_rowsum && K % HK == 0 && per % HK == 0) {
         if (a_kcontig && b_kcontig)
             hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
@@ -674,13 +695,13 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
         !(!a_kcontig && b_kcontig)) {
         if (a_kcontig && b_kcontig)
             hipLaunchKernelGGL((gemm_dma_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
-                               N, K, tiles_n, splitk, slabs);
+                               N, K, tiles_n, splitk, slabs, stagger);
         else if (a_kcontig)
             hipLaunchKernelGGL((gemm_dma_kernel<true, false>), grid, block, 0, st, A, lda, B, ldb, ep, M,
-                               N, K, tiles_n, splitk, slabs);
+                               N, K, tiles_n, splitk, slabs, stagger);
         else
             hipLaunchKernelGGL((gemm_dma_kernel<false, false>), grid, block, 0, st, A, lda, B, ldb, ep,
-                               M, N, K, tiles_n, splitk, slabs);
+                               M, N, K, tiles_n, splitk, slabs, stagger);
     } else {
 #define QARIG_LAUNCH_GEMM(TA, TB)                                                              \
     do {                                                                                       \
@@ -688,10 +709,10 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
         TB sb{B, ldb, N, K, 1.0f, vb};                                                         \
         if (fast)                                                                              \
             hipLaunchKernelGGL((gemm_kernel<TA, TB, true>), grid, block, 0, st, sa, sb, ep, M, \
-                               N, K, tiles_n, splitk, slabs, vec_epi);                         \
+                               N, K, tiles_n, splitk, slabs, vec_epi, stagger);                \
         else                                                                                   \
             hipLaunchKernelGGL((gemm_kernel<TA, TB, false>), grid, block, 0, st, sa, sb, ep, M,\
-                               N, K, tiles_n, splitk, slabs, 0);                               \
+                               N, K, tiles_n, splitk, slabs, 0, 0);                            \
     } while (0)
     if (a_kcontig && b_kcontig) QARIG_LAUNCH_GEMM(SrcKContig, SrcKContig);
     else if (a_kcontig && !b_kcontig) QARIG_LAUNCH_GEMM(SrcKContig, SrcXContig);

@@ -63,6 +63,10 @@ def parse_args():
     p.add_argument("--graph-step", action="store_true",
                    help="(additive) replay the training step from a captured HIP graph: removes the "
                         "Python launch overhead for small per-GPU batches; single process, full batches only")
+    p.add_argument("--packed-dataset", default=None,
+                   help="(additive) one (N,C,H,W) float32 .npy holding every latent of --dataset-path "
+                        "(dataset_loader.prefetch.pack_feature_maps): read through one mmap instead of "
+                        "one file per item; same items, same order")
     p.add_argument("--max-steps", type=int, default=None,
                    help="(additive) stop after this many optimiser steps.")
     return vars(p.parse_args())
@@ -124,7 +128,16 @@ def main():
 
     dataset = FeatureMapDataset(dataset_path=args["dataset_path"], load_image=False,
                                 return_filepaths=False)
-    loader = cc.ShardedLoader(dataset, args["batch_size"], num_workers=4, shuffle=True)
+    train_set = dataset
+    if args["packed_dataset"]:
+        from dataset_loader.prefetch import PackedFeatureMapDataset
+        train_set = PackedFeatureMapDataset(args["packed_dataset"])
+        assert len(train_set) == len(dataset), "--packed-dataset does not match --dataset-path"
+    # batches are copied to the device from pinned memory on a side stream, two ahead of the
+    # step that consumes them (the reference copies each batch synchronously, :407)
+    from dataset_loader.prefetch import DevicePrefetcher
+    loader = DevicePrefetcher(cc.ShardedLoader(train_set, args["batch_size"], num_workers=4, shuffle=True),
+                              device, depth=2)
     test_loader = torch.utils.data.DataLoader(dataset, batch_size=test_num_sample, num_workers=2,
                                               shuffle=True)
 

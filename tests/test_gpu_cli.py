@@ -68,6 +68,13 @@ def test_cli_pipeline(tmp_path):
     with torch.no_grad():
         zz = enc.cuda()(ImageDataset(f"{t}/dataset.json")[0][None].cuda())[0].cpu().numpy()
     assert np.array_equal(zz, z0)
+    # ... and against the ORACLE encoder (fp64) on the same decoded image: the dump is the
+    # reference's encoder output, not merely self-consistent
+    from oracle import ref_models as rm
+    x0 = ImageDataset(f"{t}/dataset.json")[0][None]
+    sd64 = {k: v.double() for k, v in ae["model"].items()}
+    zref = rm.fc_encoder(sd64, x0.double(), final_act="tanh", prefix="fc_encoder.fc_encoder_layer")[0]
+    assert float((torch.from_numpy(z0).double() - zref).abs().max() / zref.abs().max()) < 1e-5
     os.replace(f"{t}/fmaps/all_dataset.json", f"{t}/fmaps.json")
 
     for name, p, k in (("lr", 8, 8), ("mid", 2, 16), ("hr", 1, 16)):
@@ -93,6 +100,14 @@ def test_cli_pipeline(tmp_path):
     assert ok and len(counts) == 16 and sum(counts) == 12 * 16
     assert pr["num_embeddings"] == sum(c >= 3 for c in counts) \
         == pr["checkpoint"]["codebook.weight"].shape[0]
+    # the histogram against the oracle: np.bincount of the C oracle's BMU indices over the dump
+    from oracle import bmu as obmu
+    ok, cbm = load_model(f"{t}/cb_mid/models_checkpoint/codebook_2.pt")
+    wmid = cbm["checkpoint"]["codebook.weight"].numpy()
+    fm_all = np.stack([np.load(r["fmap_path"]) for r in read_all(f"{t}/fmaps.json")])
+    want = np.bincount(obmu.bmu(fm_all, wmid, (2, 2)), minlength=16)
+    assert counts == want.tolist()
+    assert np.array_equal(pr["checkpoint"]["codebook.weight"].numpy(), wmid[want >= 3])
 
     tcfg = dict(model_lr=1e-3, num_enc_layers=1, num_dec_layers=2, cross_attn_heads=2,
                 self_attn_heads=4, in_dim=32, hidden_dim=64, hidden_activation="silu",

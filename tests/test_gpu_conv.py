@@ -157,3 +157,86 @@ def test_autoencoder_train_grads_vs_reference_golden():
     assert grad_err(x.grad, g["x_grad"]) < 2e-5
     for n, p in m.named_parameters():
         assert grad_err(p.grad, g["grads"][n]) < 2e-5, n
+
+
+# ---- interior ("FAST") kernels at README channel counts ---------------------------------------
+# conv.hip takes its branch-free interior kernels only when the channel counts are multiples
+# of 128 (forward: Cout % 128, weight gradient: Cg % 128, pixels % 128); the small shapes above
+# never reach them.  N=2 at 32x32 (1024 pixels per image) does, for every layer type of the
+# README autoencoder (256/512 channels): forward, d-input, d-weight, d-bias vs fp64.
+@pytest.mark.parametrize("Cin,Cout,stride", [(256, 256, 1), (256, 512, 2), (512, 512, 1), (512, 512, 2)])
+def test_conv2d_readme_channels_fwd_bwd_vs_fp64(Cin, Cout, stride):
+    from conftest import grad_err
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(Cin + Cout + stride)
+    N, H, W = 2, 32, 32
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    a = [t.double().requires_grad_(True) for t in (x, w, b)]
+    ya = torch.nn.functional.silu(torch.nn.functional.conv2d(a[0], a[1], a[2], stride=stride, padding=1))
+    dy = torch.randn(ya.shape, generator=g)
+    (ya * dy.double()).sum().backward()
+    c = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    yc = QF.conv2d_act(c[0], c[1], c[2], stride, 1, 1)
+    assert rel_err(yc, ya) < 4e-6
+    (yc * dy.cuda()).sum().backward()
+    for p, q in zip(c, a):
+        assert grad_err(p.grad, q.grad) < 1e-5
+
+
+@pytest.mark.parametrize("Cin,Cout", [(512, 256), (256, 256)])
+def test_conv_transpose2d_readme_channels_fwd_bwd_vs_fp64(Cin, Cout):
+    from conftest import grad_err
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(Cin * 3 + Cout)
+    N, H, W = 2, 16, 16
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cin, Cout, 4, 4), generator=g) / (4 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    a = [t.double().requires_grad_(True) for t in (x, w, b)]
+    ya = torch.nn.functional.silu(torch.nn.functional.conv_transpose2d(a[0], a[1], a[2], stride=2, padding=1))
+    dy = torch.randn(ya.shape, generator=g)
+    (ya * dy.double()).sum().backward()
+    c = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    yc = QF.conv_transpose2d_act(c[0], c[1], c[2], 1)
+    assert rel_err(yc, ya) < 4e-6
+    (yc * dy.cuda()).sum().backward()
+    for p, q in zip(c, a):
+        assert grad_err(p.grad, q.grad) < 1e-5
+
+
+def test_encoder_readme_shape_latent_vs_oracle_fp64():
+    """README encoder (256/512 channels, 2 down levels, 3x64x64 -> 4x16x16), default init: latent
+    rel-err vs the oracle in fp64 (the stride-2 and 512-channel interior kernels)."""
+    from models.FC_Encoder import FC_Encoder
+    from oracle import ref_models as rm
+    torch.manual_seed(5)
+    enc = FC_Encoder(num_layers=2, image_channel=3, min_channel=256, max_channel=512, latent_channel=4,
+                     use_final_activation=True, final_activation_type="tanh")
+    x = 2 * torch.rand((2, 3, 64, 64), generator=torch.Generator().manual_seed(0)) - 1
+    sd64 = {k: v.double() for k, v in enc.state_dict().items()}
+    ref = rm.fc_encoder(sd64, x.double(), final_act="tanh")
+    with torch.no_grad():
+        z = enc.cuda()(x.cuda())
+    assert z.shape == (2, 4, 16, 16)
+    assert rel_err(z, ref) < PIX_TOL
+
+
+def test_conv_autograd_node_accepts_non_contiguous_input():
+    """The autograd node normalises its input once and saves THAT tensor: a channels-last view
+    must give the gradients of the dense tensor."""
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((2, 8, 10, 12), generator=g).cuda()
+    w = (torch.randn((16, 8, 3, 3), generator=g) / 8).cuda().requires_grad_(True)
+    b = torch.randn(16, generator=g).cuda().requires_grad_(True)
+    dy = torch.randn((2, 16, 10, 12), generator=g).cuda()
+    res = []
+    for xin in (x, x.to(memory_format=torch.channels_last)):
+        xin = xin.detach().requires_grad_(True)
+        w.grad = b.grad = None
+        (QF.conv2d_act(xin, w, b, 1, 1, 1) * dy).sum().backward()
+        res.append((xin.grad.contiguous().clone(), w.grad.clone(), b.grad.clone()))
+    for a, c in zip(*res):
+        assert torch.equal(a, c)

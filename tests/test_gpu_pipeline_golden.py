@@ -1,0 +1,114 @@
+"""The hot loop's host-visible steps against reference-derived fixtures:
+ - pipeline.tokenize / pipeline.slide / pipeline.train_step vs ONE full reference training step
+   (BMU tokens, token assembly, <start>/<end>, vocabulary shift, window slicing at the recorded
+   random offsets, window positions, loss, every gradient, post-Adam weights);
+ - sampling.generate_tokens vs the reference's generation loop at legal temperatures, with the
+   reference's recorded multinomial draws injected: the probabilities the product samples from
+   must equal the reference's at every draw, and the chunks it keeps must be the reference's."""
+import pytest
+import torch
+
+from conftest import grad_err, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny(use_enc, n_dec_emb, n_enc_emb, out_dim):
+    from models.Transformer import Transformer
+    return Transformer(use_encoder=use_enc, use_pos_cond=True, num_enc_layers=2 if use_enc else None,
+                       num_dec_layers=2, num_enc_embedding=n_enc_emb if use_enc else None,
+                       num_dec_embedding=n_dec_emb, self_attn_heads=4,
+                       cross_attn_heads=2 if use_enc else None, transformer_in_dim=32,
+                       transformer_out_dim=out_dim, transformer_hidden_dim=64, hidden_activation="silu")
+
+
+def _codebook(w, p, image_dim=(8, 8)):
+    from models.Codebook import Codebook
+    cb = Codebook(patch_dim=(p, p), image_dim=image_dim, image_channel=4, num_embeddings=w.shape[0],
+                  init_neighbour_range=4)
+    with torch.no_grad():
+        cb.codebook.weight.copy_(w)
+    return cb.cuda()
+
+
+@pytest.mark.parametrize("tag", ["base", "encdec"])
+@pytest.mark.parametrize("table", [False, True])
+def test_train_step_matches_reference_step(tag, table):
+    from qarig import functional as QF
+    from qarig import ops, pipeline
+    from qarig.optim import FlatAdam
+    g = load_golden("train_step_" + tag)
+    base = tag == "base"
+    K_lr, K_hr = g["lr_w"].shape[0], g["hr_w"].shape[0]
+    lr_cb, hr_cb = _codebook(g["lr_w"], int(g["lr_patch"])), _codebook(g["hr_w"], int(g["hr_patch"]))
+    m = _tiny(not base, K_lr + K_hr if base else K_hr + 1, K_lr, K_hr + 1)
+    m.custom_load_state_dict(g["sd"])
+    m = m.cuda()
+    hr_in, lr_in, hr_tg = pipeline.tokenize(g["fmap"].cuda(), lr_cb, hr_cb, train_base_model=base)
+    assert torch.equal(hr_in.cpu(), g["full_input"]) and torch.equal(hr_tg.cpu(), g["full_target"])
+    if base:
+        assert lr_in is None
+    else:
+        assert torch.equal(lr_in.cpu(), g["lr_input"])
+    window = int(g["window"])
+    assert pipeline.num_windows(hr_in.shape[1], window) == int(g["num_windows"])
+    w_in, w_tg, pos = pipeline.slide(hr_in, hr_tg, window, g["rand_indices"])
+    assert torch.equal(w_in.cpu(), g["hr_input"]) and torch.equal(w_tg.cpu(), g["hr_target"])
+    assert torch.equal(pos.cpu(), g["pos"])
+    opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    old = (QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO)
+    try:
+        QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO = table, 0
+        with torch.no_grad():
+            logits = m(w_in, lr_in, pos, pos_bound=hr_in.shape[1])
+        assert m._last_cond_form == ("table" if table else "per_token")
+        assert rel_err(logits, g["logits"]) < 1e-5
+        # gradients before the optimiser consumes them
+        opt.zero_grad()
+        QF.cross_entropy(m(w_in, lr_in, pos, pos_bound=hr_in.shape[1]).view(-1, K_hr + 1),
+                         w_tg.flatten()).backward()
+        for n, p in m.named_parameters():
+            assert grad_err(p.grad, g["grads"][n]) < 5e-5, n
+        loss = pipeline.train_step(m, opt, w_in, lr_in, w_tg, pos, pos_bound=hr_in.shape[1])
+    finally:
+        QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO = old
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    for k, v in m.state_dict().items():
+        assert rel_err(v, g["sd_after_adam"][k]) < 1e-5, k
+    ops.check_index_flag(torch.device("cuda"), "train step golden")
+
+
+@pytest.mark.parametrize("tag", ["base", "encdec"])
+@pytest.mark.parametrize("use_kv_cache", [False, True])
+def test_generation_loop_matches_reference_draw_by_draw(tag, use_kv_cache, monkeypatch):
+    from qarig import sampling
+    g = load_golden("generation_" + tag)
+    base = tag == "base"
+    K_lr, K_hr = int(g["K_lr"]), int(g["K_hr"])
+    m = _tiny(not base, K_lr + K_hr if base else K_hr + 1, K_lr, K_hr + 1)
+    m.custom_load_state_dict(g["sd"])
+    m = m.cuda().eval()
+    state = {"d": 0, "worst": 0.0}
+    probs_ref, toks_ref = g["draw_probs"], g["draw_tokens"]
+
+    def injected(probs, num_samples, *a, **k):
+        d = state["d"]
+        assert num_samples == 1 and d < toks_ref.shape[0], "more draws than the reference made"
+        err = float((probs.detach().cpu() - probs_ref[d]).abs().max())
+        state["worst"] = max(state["worst"], err)
+        assert err < 1e-5, f"draw {d}: probabilities differ from the reference's by {err}"
+        state["d"] = d + 1
+        return toks_ref[d].to(probs.device)[:, None]
+
+    monkeypatch.setattr(torch, "multinomial", injected)
+    got = sampling.generate_tokens(
+        m, g["first_token"].cuda(), None if base else g["lr_input"].cuda(), int(g["total_seq"]),
+        float(g["temperature"]), True, int(g["sliding_window"]), end_token=K_hr,
+        shift=K_lr if base else 0, num_beam=int(g["num_beam"]), beam_width=int(g["beam_width"]),
+        mode="generate", use_kv_cache=use_kv_cache)
+    assert state["d"] == toks_ref.shape[0], "fewer draws than the reference made"
+    final = got[:, 1:].cpu() - (K_lr if base else 0)
+    assert torch.equal(final, g["final_tokens"])
+    bw = int(g["beam_width"])
+    for c in range(g["kept_chunks"].shape[0]):
+        assert torch.equal(got[:, 1 + c * bw:1 + (c + 1) * bw].cpu(), g["kept_chunks"][c])

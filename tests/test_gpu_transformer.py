@@ -84,6 +84,69 @@ def test_attention_fwd_bwd(N, Sq, Sk, H, d, causal):
         assert rel_err(x.grad, y.grad) < 5e-6
 
 
+def _attn_ref64(q, k, v, H, causal):
+    """fp64 attention on the GPU with plain torch ops (the checker for the large shapes)."""
+    N, Sq, D = q.shape
+    Sk, d = k.shape[1], D // H
+    qh = q.reshape(N, Sq, H, d).permute(0, 2, 1, 3)
+    kh = k.reshape(N, Sk, H, d).permute(0, 2, 1, 3)
+    vh = v.reshape(N, Sk, H, d).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) / (d ** 0.5)
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(Sq, Sk, dtype=torch.bool, device=q.device), 1), float("-inf"))
+    return (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(N, Sq, D)
+
+
+@pytest.mark.parametrize("qw,bw", [(1, 1), (2, 2), (4, 2), (4, 4)])
+@pytest.mark.parametrize("N,Sq,Sk,H,d,causal", [(2, 300, 300, 6, 8, True), (1, 1024, 1024, 8, 8, True),
+                                                (2, 200, 333, 5, 8, False), (1, 520, 520, 4, 16, True)])
+def test_attention_workgroup_shapes(N, Sq, Sk, H, d, causal, qw, bw, monkeypatch):
+    """Every workgroup geometry of the MFMA attention kernels (1, 2 or 4 query / key slices per
+    head, several K/V chunks per workgroup, ragged last chunk, a head count that is not a
+    multiple of the 4 heads a workgroup covers) against fp64."""
+    from qarig import functional as QF
+    monkeypatch.setenv("QARIG_ATTN_QW", str(qw))
+    monkeypatch.setenv("QARIG_ATTN_BW", str(bw))
+    g = torch.Generator().manual_seed(Sq + Sk + H)
+    D = H * d
+    q, k, v = (torch.randn((N, S, D), generator=g).cuda() for S in (Sq, Sk, Sk))
+    do = torch.randn((N, Sq, D), generator=g).cuda()
+    a = [t.double().requires_grad_(True) for t in (q, k, v)]
+    oa = _attn_ref64(*a, H, causal)
+    (oa * do.double()).sum().backward()
+    b = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    o = QF.attention(b[0], b[1], b[2], H, causal)
+    (o * do).sum().backward()
+    assert rel_err(o, oa) < 2e-6
+    for x, y in zip(b, a):
+        assert rel_err(x.grad, y.grad) < 5e-6
+
+
+def test_attention_4096_tokens_64_heads_vs_fp64():
+    """BASELINE config 5's sequence: one 4096-token sequence, 64 heads of dim 8, causal; forward
+    and all three gradients vs fp64 (computed head group by head group to bound memory)."""
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(4096)
+    N, S, H, d = 1, 4096, 64, 8
+    D = H * d
+    q, k, v = (torch.randn((N, S, D), generator=g).cuda() for _ in range(3))
+    do = torch.randn((N, S, D), generator=g).cuda()
+    b = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    o = QF.attention(b[0], b[1], b[2], H, True)
+    (o * do).sum().backward()
+    worst = 0.0
+    for h0 in range(0, H, 8):                      # 8 heads at a time: 8 x 4096^2 fp64 scores = 1 GiB
+        sl = slice(h0 * d, (h0 + 8) * d)
+        a = [t[:, :, sl].double().requires_grad_(True) for t in (q, k, v)]
+        oa = _attn_ref64(*a, 8, True)
+        (oa * do[:, :, sl].double()).sum().backward()
+        worst = max(worst, rel_err(o[:, :, sl], oa))
+        for x, y in zip(b, a):
+            worst = max(worst, rel_err(x.grad[:, :, sl], y.grad) / 2.5)
+        del a, oa
+    assert worst < 2e-6, worst
+
+
 def test_attention_causal_invariance():
     from qarig import ops
     g = torch.Generator().manual_seed(0)

@@ -179,3 +179,89 @@ def test_causal_invariance_property():
     b = rm.transformer_forward(g["sd"], cfg, x)
     assert torch.equal(a[:, :-1], b[:, :-1])
     assert not torch.equal(a[:, -1], b[:, -1])
+
+
+# --- full train step and generation chunk fixtures (round 2) --------------
+def _tiny_cfg(use_enc):
+    return dict(use_encoder=use_enc, use_pos_cond=True, num_enc_layers=2 if use_enc else None,
+                num_dec_layers=2, self_attn_heads=4, cross_attn_heads=2 if use_enc else None,
+                hidden_activation="silu")
+
+
+@pytest.mark.parametrize("tag", ["base", "encdec"])
+def test_train_step_golden_pins_oracle(tag):
+    """The oracle's BMU, forward, CE, gradients and Adam against one full reference training step
+    (train_quantized_transformer.py:404-508) incl. the window it was taken on."""
+    g = load_golden("train_step_" + tag)
+    lp, hp = int(g["lr_patch"]), int(g["hr_patch"])
+    x = g["fmap"].numpy()
+    assert np.array_equal(obmu.bmu(x, g["lr_w"].numpy(), (lp, lp)).reshape(3, -1), g["lr_indices"].numpy())
+    assert np.array_equal(obmu.bmu(x, g["hr_w"].numpy(), (hp, hp)).reshape(3, -1), g["hr_indices"].numpy())
+    sd = {k: v.clone().requires_grad_(True) for k, v in g["sd"].items()}
+    logits = rm.transformer_forward(sd, _tiny_cfg(tag == "encdec"), g["hr_input"],
+                                    g.get("lr_input"), g["pos"])
+    assert rel_err(logits, g["logits"]) < 1e-5
+    loss = rm.cross_entropy(logits, g["hr_target"])
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    loss.backward()
+    names = list(g["grads"])
+    for k in names:
+        assert grad_err(sd[k].grad, g["grads"][k]) < 5e-5, k
+    with torch.no_grad():
+        ps = [sd[k] for k in names]
+        rm.adam_step(ps, [p.grad for p in ps], [torch.zeros_like(p) for p in ps],
+                     [torch.zeros_like(p) for p in ps], 1, 1e-3)
+    for k in names:
+        assert rel_err(sd[k], g["sd_after_adam"][k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("tag", ["base", "encdec"])
+def test_generation_golden_is_self_consistent_and_pins_oracle_probabilities(tag):
+    """Replays the recorded draws on the oracle model: every probability row the reference
+    sampled from must come out of the oracle's logits (softmax(logits / T), <end> zeroed) at the
+    recorded window / positions, and the kept chunks must follow the product-of-probabilities
+    rule with >= ties."""
+    g = load_golden("generation_" + tag)
+    base = tag == "base"
+    K_lr, K_hr = int(g["K_lr"]), int(g["K_hr"])
+    total, nb, bw, sw = int(g["total_seq"]), int(g["num_beam"]), int(g["beam_width"]), int(g["sliding_window"])
+    T = float(g["temperature"])
+    cfg = _tiny_cfg(not base)
+    N = g["first_token"].shape[0]
+    hr, pos, start, d = g["first_token"], torch.zeros((N, 1)), 0, 0
+    chunk = 0
+    with torch.no_grad():
+        while hr.shape[1] < total:
+            cur = hr.shape[1]
+            best_in = best_p = None
+            for _ in range(nb):
+                comb, t_idx, t_in, t_pos = 1.0, start, hr, pos
+                for tok in range(bw):
+                    if t_in.shape[1] >= sw:
+                        t_idx += 1
+                        t_pos = t_pos[:, 1:]
+                    logits = rm.transformer_forward(g["sd"], cfg, t_in[:, t_idx:], g.get("lr_input"),
+                                                    t_pos)[:, -1, :]
+                    probs = torch.softmax(logits / T, dim=1)
+                    probs[:, K_hr] = 0.0
+                    assert float((probs - g["draw_probs"][d]).abs().max()) < 2e-6, (chunk, tok)
+                    nxt = g["draw_tokens"][d][:, None]
+                    assert bool((g["draw_probs"][d][torch.arange(N), nxt.squeeze(1)] > 0).all())
+                    comb = comb * g["draw_probs"][d][torch.arange(N), nxt.squeeze(1)]
+                    d += 1
+                    t_in = torch.cat((t_in, nxt + (K_lr if base else 0)), dim=1)
+                    t_pos = torch.cat((t_pos, torch.full((N, 1), float(cur + tok + 1))), dim=1)
+                if best_p is None:
+                    best_in, best_p = t_in, comb
+                else:
+                    keep = best_p >= comb
+                    best_p = torch.where(keep, best_p, comb)
+                    best_in = torch.where(keep[:, None], best_in, t_in)
+            start, hr, pos = t_idx, best_in, t_pos
+            assert torch.equal(hr[:, -bw:], g["kept_chunks"][chunk])
+            chunk += 1
+    assert d == g["draw_tokens"].shape[0]
+    final = hr[:, 1:] - (K_lr if base else 0)
+    assert torch.equal(final, g["final_tokens"])
+    assert torch.equal(pos.long(), g["final_positions"])
+    assert g["final_positions"][0, :3].tolist() != [0, 1, 2]        # the 0, 2, 3, ... numbering quirk

@@ -44,6 +44,24 @@ def main():
         cases.append((name, m, n, k, dict(A=A, B=B, a_kcontig=ak, b_kcontig=bk, bias=bias,
                                           want_preact=kw.get("pre", False), act=kw.get("act", 0),
                                           gradz=gz, gact=1 if gz is not None else 0, splitk=sk)))
+    sweep = [int(v) for v in os.environ.get("STAGGER_SWEEP", "").split(",") if v]
+    if sweep:     # first-round stagger of co-resident workgroups (csrc/gemm.hip), interleaved rounds
+        res = {}
+        for rnd in range(5):
+            for st in sweep:
+                os.environ["QARIG_GEMM_STAGGER"] = str(st)
+                for name, m, n, k, kw in cases[:9]:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ops.gemm(**kw)
+                    e0.record()
+                    for _ in range(10):
+                        ops.gemm(**kw)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    res.setdefault((name, st), []).append(2.0 * m * n * k / (e0.elapsed_time(e1) / 10) / 1e9)
+        for name, m, n, k, kw in cases[:9]:
+            print(f"{name:36s} " + "  ".join(f"st{st}: {sorted(res[(name, st)])[2]:6.1f}" for st in sweep))
+        return
     for rnd in range(4):
         for name, m, n, k, kw in cases:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
