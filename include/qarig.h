@@ -73,17 +73,28 @@ int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const float* B, i
                    const float* gradz, int64_t ldz, int gact, int splitk, int accumulate,
                    float* a_rowsum, void* workspace, size_t ws_bytes, void* stream);
 
-/* Opt-in reduced precision (BASELINE config 5 direction; not the fp32 parity mode): the same
- * contract as qarig_gemm_f32 -- nn.Linear forward/backward, models/layers.py:234-304,
- * 389-418 -- with the operand products taken by v_mfma_f32_32x32x16_bf16 (inputs rounded
- * fp32 -> bf16 round-to-nearest-even in flight, fp32 accumulation, fp32 tensors in HBM).
- * Interior shapes only (M, N % 128 == 0, every K split % 32 == 0, 16-B aligned, no
- * a_rowsum); any other call runs the fp32 kernels. */
-int qarig_gemm_bf16(const float* A, int64_t lda, int a_kcontig, const float* B, int64_t ldb,
-                   int b_kcontig, float* C, int64_t ldc, int M, int N, int K, const float* bias,
-                   const float* residual, int64_t ldr, float* preact, int64_t ldp, int act,
-                   const float* gradz, int64_t ldz, int gact, int splitk, int accumulate,
-                   float* a_rowsum, void* workspace, size_t ws_bytes, void* stream);
+/* Opt-in reduced precision (BASELINE config 5: "fp8/bf16 MFMA attn/FFN"; never the fp32 parity
+ * mode).  The Linear contractions of models/layers.py:234-304, 330-340, 389-418 with bf16
+ * OPERANDS IN HBM, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation and the same fused
+ * fp32 epilogue as qarig_gemm_f32.  layout 0 = NT: A (M,K), B (N,K), reduction-contiguous
+ * (forward x W^T; input gradient dT W with the W^T shadow as B); layout 1 = TN: A (K,M), B (K,N),
+ * reduction-major (weight gradient dT^T x from the row-major activations, transposed on the LDS
+ * read by ds_read_b64_tr_b16).  A, B: bf16 (16-bit) elements, lda / ldb in elements.
+ * C: fp32 output (may be NULL when Cb is given); Cb / Pb: optional bf16 copies of the output /
+ * of the saved pre-activation for a consumer GEMM.  Shapes: qarig_gemm_lp_supported. */
+int qarig_gemm_lp_supported(int M, int N, int K, int splitk);
+size_t qarig_gemm_lp_workspace_bytes(int M, int N, int splitk);
+int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t ldb, int layout, float* C,
+                  int64_t ldc, int M, int N, int K, const float* bias, const float* residual,
+                  int64_t ldr, float* preact, int64_t ldp, int act, const float* gradz, int64_t ldz,
+                  int gact, int splitk, int accumulate, void* Cb, int64_t ldcb, void* Pb,
+                  int64_t ldpb, void* workspace, size_t ws_bytes, void* stream);
+
+/* Operand conversion of the reduced-precision mode (no reference counterpart): fp32 -> bf16,
+ * round to nearest even; n contiguous elements, or the transpose (C, R) of a (R, C) matrix
+ * with row stride ld (the W^T shadow of an nn.Linear weight). */
+int qarig_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+int qarig_cast_transpose_bf16(const float* src, int64_t ld, int R, int C, void* dst, void* stream);
 
 /* `groups` independent skinny products in one launch, C_g = act(A_g W_g^T + bias_g) with
  * X_g = X + g * x_gs (a_gs == 0 shares the activations).  Decode steps use it for the q/k/v

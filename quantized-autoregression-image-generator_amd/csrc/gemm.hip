@@ -11,73 +11,9 @@
 #include <stdlib.h>
 
 #include "qarig_common.h"
+#include "gemm_epilogue.h"
 
 namespace qarig {
-
-struct GemmEpilogue {
-    float* C; int64_t ldc;
-    const float* bias;                    // [N], per column, or null
-    const float* residual; int64_t ldr;   // [M][N] added before the activation, or null
-    float* preact; int64_t ldp;           // receives acc+bias+residual, or null
-    int act;                              // activation applied to what goes to C
-    const float* gradz; int64_t ldz;      // C *= act'(gradz[m][n]) (backward fusion), or null
-    int gact;
-    float* rowsum;                        // [splitk][M]: sum_k A(m,k) per K split, or null
-};
-
-// Wide epilogue (interior tiles): the wave's 64x64 tile goes through its private 8 KB of
-// LDS in two 32-row halves, so that every global access of the epilogue (C, preact,
-// residual, gradz, slabs) is a 16-B-per-lane, 256-B-per-row dwordx4 instead of 4x as many
-// 4-B accesses (the epilogue is store-issue bound otherwise).  `lds`: >= 32 KB, free.
-__device__ __forceinline__ void gemm_epilogue_wide(const Acc& acc, const GemmEpilogue& ep, float* lds,
-                                                   int m0, int n0, int M, int N, int splitk,
-                                                   float* slabs) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int cl = lane & 31;
-    // 4 waves x 32 x 64 floats = 32 KB; unpadded rows are conflict-free for both the b32
-    // writes (half-waves hit different rows) and the b128 reads
-    constexpr int EL = 64;
-    float* stage = lds + wave * (32 * EL);
-    const int er = lane >> 4, ec = (lane & 15) * 4;
-    const int gc = n0 + wn * 64 + ec;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ep.bias && splitk == 1) bv = *reinterpret_cast<const float4*>(ep.bias + gc);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stage[acc_row(r, lane) * EL + j * 32 + cl] = acc.t[i][j][r];
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int lr = it * 4 + er;
-            const int64_t row = m0 + wm * 64 + i * 32 + lr;
-            float4 t = *reinterpret_cast<const float4*>(stage + lr * EL + ec);
-            if (splitk > 1) {
-                *reinterpret_cast<float4*>(slabs + ((int64_t)blockIdx.z * M + row) * N + gc) = t;
-                continue;
-            }
-            t.x += bv.x; t.y += bv.y; t.z += bv.z; t.w += bv.w;
-            if (ep.residual) {
-                const float4 rv = *reinterpret_cast<const float4*>(ep.residual + row * ep.ldr + gc);
-                t.x += rv.x; t.y += rv.y; t.z += rv.z; t.w += rv.w;
-            }
-            if (ep.preact) *reinterpret_cast<float4*>(ep.preact + row * ep.ldp + gc) = t;
-            float4 y = make_float4(act_fwd(t.x, ep.act), act_fwd(t.y, ep.act),
-                                   act_fwd(t.z, ep.act), act_fwd(t.w, ep.act));
-            if (ep.gradz) {
-                const float4 z = *reinterpret_cast<const float4*>(ep.gradz + row * ep.ldz + gc);
-                y.x *= act_grad(z.x, ep.gact); y.y *= act_grad(z.y, ep.gact);
-                y.z *= act_grad(z.z, ep.gact); y.w *= act_grad(z.w, ep.gact);
-            }
-            *reinterpret_cast<float4*>(ep.C + row * ep.ldc + gc) = y;
-        }
-        __syncthreads();
-    }
-}
 
 // sum_k A(m0 + tid, k) from the staged A tiles (bias gradient riding on the dW GEMM).
 struct RowSumHook {
@@ -320,6 +256,122 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const float* __re
     gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, slabs);
 }
 
+// ---------------------------------------------------------------------------------
+// Interior GEMM, operands straight from global memory to the MFMA registers: no LDS, no
+// barrier in the k-loop.  The fp32 MFMA consumes ONE dword of each operand per lane per
+// 64-cycle instruction, so operand bandwidth is tiny (a wave's 64x64 tile needs 8 KB per
+// 16-deep k-tile = per 2048 MFMA cycles); what the LDS-staged kernels lose is not bandwidth
+// but the per-k-tile barrier + DMA wait + fragment-read latency that four waves pay in
+// lockstep (counters: MFMA pipe busy 0.71-0.76 of the kernel's cycles, wave time in
+// s_waitcnt/s_barrier 19 %, profiles/r02a_sq_by_kernel.csv).  Here every wave streams its own
+// fragments -- row-major operands as two 16-B loads per 32-row tile (lane half h owns
+// k = 8h..8h+7: MFMA step s contracts k = {s, 8+s}, the order of gemm_dma_kernel),
+// reduction-major operands as one coalesced dword per k -- one k-tile ahead of the MFMAs that
+// use them (register double buffer, counted vmcnt by the compiler), and waves never wait for
+// each other until the epilogue.  The two waves that share an operand panel hit the CU's L1.
+// ---------------------------------------------------------------------------------
+struct Frag {            // one k-tile (16 deep) of a wave's 64 rows/columns of one operand
+    float v[2][8];       // [32-wide tile][k = 8h + s]
+};
+
+template <bool KC>
+__device__ __forceinline__ void frag_load(Frag& f, const float* __restrict__ P, int64_t ld, int x0,
+                                          int k0, int lane) {
+    const int x = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (KC) {
+            const float4* q = reinterpret_cast<const float4*>(P + (int64_t)(x0 + 32 * t + x) * ld + k0 + 8 * h);
+            const float4 a = q[0], b = q[1];
+            f.v[t][0] = a.x; f.v[t][1] = a.y; f.v[t][2] = a.z; f.v[t][3] = a.w;
+            f.v[t][4] = b.x; f.v[t][5] = b.y; f.v[t][6] = b.z; f.v[t][7] = b.w;
+        } else {
+            const float* q = P + (int64_t)(k0 + 8 * h) * ld + x0 + 32 * t + x;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) f.v[t][s] = q[(int64_t)s * ld];
+        }
+    }
+}
+
+__device__ __forceinline__ void frag_mma(Acc& acc, const Frag& a, const Frag& b) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        acc.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[0][s], b.v[0][s], acc.t[0][0], 0, 0, 0);
+        acc.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[0][s], b.v[1][s], acc.t[0][1], 0, 0, 0);
+        acc.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[1][s], b.v[0][s], acc.t[1][0], 0, 0, 0);
+        acc.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[1][s], b.v[1][s], acc.t[1][1], 0, 0, 0);
+    }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_direct_kernel(const float* __restrict__ A, int64_t lda,
+                                                                  const float* __restrict__ B, int64_t ldb,
+                                                                  GemmEpilogue ep, int M, int N, int K,
+                                                                  int tiles_n, int splitk, float* slabs) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * 64];   // epilogue staging only (32 KB)
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    int k_begin = 0, k_end = K;
+    if (splitk > 1) {
+        const int per = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
+        k_begin = blockIdx.z * per;
+        k_end = min(K, k_begin + per);
+    }
+    const int nk = (k_end - k_begin) / BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int am = m0 + wm * 64, bn = n0 + wn * 64;
+
+    Acc acc;
+    acc_zero(acc);
+    // bias gradient riding on the dW GEMM (A = dT^T stored [k][m]): partial row sums of this
+    // wave's A fragments; the wn == 0 waves of the tn == 0 tiles own them
+    const bool do_rs = !AKC && ep.rowsum != nullptr && tn == 0 && wn == 0;
+    float rs0 = 0.0f, rs1 = 0.0f;
+    Frag a0, b0, a1, b1;
+    if (nk > 0) {
+        frag_load<AKC>(a0, A, lda, am, k_begin, lane);
+        frag_load<BKC>(b0, B, ldb, bn, k_begin, lane);
+        int kt = 0;
+        for (; kt + 2 <= nk; kt += 2) {
+            const int k1 = k_begin + (kt + 1) * BK;
+            frag_load<AKC>(a1, A, lda, am, k1, lane);
+            frag_load<BKC>(b1, B, ldb, bn, k1, lane);
+            if (do_rs) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { rs0 += a0.v[0][s]; rs1 += a0.v[1][s]; }
+            }
+            frag_mma(acc, a0, b0);
+            const int k2 = min(k_begin + (kt + 2) * BK, k_end - BK);     // tail: harmless re-load
+            frag_load<AKC>(a0, A, lda, am, k2, lane);
+            frag_load<BKC>(b0, B, ldb, bn, k2, lane);
+            if (do_rs) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { rs0 += a1.v[0][s]; rs1 += a1.v[1][s]; }
+            }
+            frag_mma(acc, a1, b1);
+        }
+        if (kt < nk) {
+            if (do_rs) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { rs0 += a0.v[0][s]; rs1 += a0.v[1][s]; }
+            }
+            frag_mma(acc, a0, b0);
+        }
+    }
+    if (do_rs) {      // halves h = 0, 1 hold k = 0..7 / 8..15 of every tile: add them, lane x writes
+        rs0 += __shfl_xor(rs0, 32, 64);
+        rs1 += __shfl_xor(rs1, 32, 64);
+        if (lane < 32) {
+            ep.rowsum[(int64_t)blockIdx.z * M + am + lane] = rs0;
+            ep.rowsum[(int64_t)blockIdx.z * M + am + 32 + lane] = rs1;
+        }
+    }
+    gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, slabs);
+}
+
 // out[i] (+ld handling) = sum_z slabs[z][i], z ascending: deterministic.
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                    int64_t ldc, int M, int N, int nslab, int accumulate) {
@@ -468,130 +520,6 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(const float* __restri
     }
 }
 
-// ---------------------------------------------------------------------------------
-// Opt-in reduced-precision contraction (BASELINE config 5 direction; NOT the parity mode):
-// operands are rounded fp32 -> bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on their
-// way into LDS and multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation; tensors
-// in HBM, the epilogue and everything around the GEMM stay fp32.  At 16x the fp32 MFMA
-// rate the kernel is bound by its fp32 HBM traffic instead of the matrix pipe.
-// Interior shapes only (M,N % 128, every K split % 32, 16-B aligned operands).
-//
-// LDS image per operand tile: [128 rows][32 k] bf16, row stride 40 (80 B: the 16-B
-// fragment reads of 32 consecutive rows fall on distinct bank groups).  Lane l of a wave
-// reads row (l & 31), k = 8 (l >> 5) + 0..7 of each 16-wide k-step with one ds_read_b128.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int HK = 32;
-constexpr int HLD = 40;
-constexpr int HTILE = 128 * HLD;   // bf16 elements per operand tile
-
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-    const f32x2 f = {a, b};
-    const bf16x2 r = __builtin_convertvector(f, bf16x2);
-    return __builtin_bit_cast(uint32_t, r);
-}
-
-// One thread's share (4 x 16 B) of a 128 x 32 fp32 operand tile, register-staged.
-template <bool KC>
-struct HalfLoader {
-    const float* p;   // tile origin: row x0 (KC: [x][K]) / column x0 (XC: [K][X]), k = 0
-    int64_t ld;
-    float4 r[4];
-    __device__ __forceinline__ void load(int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (KC) {
-                const int idx = threadIdx.x + 256 * i;
-                r[i] = *reinterpret_cast<const float4*>(p + (int64_t)(idx >> 3) * ld + k0 + (idx & 7) * 4);
-            } else {   // 32 lanes cover 512 contiguous bytes of one k row
-                r[i] = *reinterpret_cast<const float4*>(p + (int64_t)(k0 + (threadIdx.x >> 5) * 4 + i) * ld +
-                                                        (threadIdx.x & 31) * 4);
-            }
-        }
-    }
-    __device__ __forceinline__ void store(unsigned short* tile) const {
-        if (KC) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = threadIdx.x + 256 * i;
-                const uint2 v = make_uint2(pack_bf16(r[i].x, r[i].y), pack_bf16(r[i].z, r[i].w));
-                *reinterpret_cast<uint2*>(tile + (idx >> 3) * HLD + (idx & 7) * 4) = v;
-            }
-        } else {   // the thread holds a 4(k) x 4(x) block: transposed in registers
-            const int x = (threadIdx.x & 31) * 4, kq = (threadIdx.x >> 5) * 4;
-            *reinterpret_cast<uint2*>(tile + (x + 0) * HLD + kq) =
-                make_uint2(pack_bf16(r[0].x, r[1].x), pack_bf16(r[2].x, r[3].x));
-            *reinterpret_cast<uint2*>(tile + (x + 1) * HLD + kq) =
-                make_uint2(pack_bf16(r[0].y, r[1].y), pack_bf16(r[2].y, r[3].y));
-            *reinterpret_cast<uint2*>(tile + (x + 2) * HLD + kq) =
-                make_uint2(pack_bf16(r[0].z, r[1].z), pack_bf16(r[2].z, r[3].z));
-            *reinterpret_cast<uint2*>(tile + (x + 3) * HLD + kq) =
-                make_uint2(pack_bf16(r[0].w, r[1].w), pack_bf16(r[2].w, r[3].w));
-        }
-    }
-};
-
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(const float* __restrict__ A, int64_t lda,
-                                                                const float* __restrict__ B, int64_t ldb,
-                                                                GemmEpilogue ep, int M, int N, int K,
-                                                                int tiles_n, int splitk, float* slabs) {
-    __shared__ __attribute__((aligned(16))) unsigned short lds[4 * HTILE];   // 2 stages x (A,B): 40 KB
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    int k_begin = 0, k_end = K;
-    if (splitk > 1) {
-        const int per = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
-        k_begin = blockIdx.z * per;
-        k_end = min(K, k_begin + per);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    HalfLoader<AKC> la{AKC ? A + (int64_t)m0 * lda : A + m0, lda, {}};
-    HalfLoader<BKC> lb{BKC ? B + (int64_t)n0 * ldb : B + n0, ldb, {}};
-    Acc acc;
-    acc_zero(acc);
-    la.load(k_begin);
-    lb.load(k_begin);
-    la.store(lds);
-    lb.store(lds + HTILE);
-    __syncthreads();
-    const int frag = (lane & 31) * HLD + (lane >> 5) * 8;
-    int cur = 0;
-    for (int k = k_begin; k < k_end; k += HK) {
-        const bool more = k + HK < k_end;
-        if (more) {
-            la.load(k + HK);
-            lb.load(k + HK);
-        }
-        const unsigned short* ta = lds + cur * 2 * HTILE + wm * 64 * HLD + frag;
-        const unsigned short* tb = lds + cur * 2 * HTILE + HTILE + wn * 64 * HLD + frag;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const bf16x8*>(ta + i * 32 * HLD + s * 16);
-                fb[i] = *reinterpret_cast<const bf16x8*>(tb + i * 32 * HLD + s * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc.t[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc.t[i][j], 0, 0, 0);
-        }
-        if (more) {
-            la.store(lds + (cur ^ 1) * 2 * HTILE);
-            lb.store(lds + (cur ^ 1) * 2 * HTILE + HTILE);
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-    gemm_epilogue_wide(acc, ep, reinterpret_cast<float*>(lds), m0, n0, M, N, splitk, slabs);
-}
 }  // namespace qarig
 
 using namespace qarig;
@@ -623,7 +551,7 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
                          int K, const float* bias, const float* residual, int64_t ldr,
                          float* preact, int64_t ldp, int act, const float* gradz,
                          int64_t ldz, int gact, int splitk, int accumulate, float* a_rowsum,
-                         void* workspace, size_t ws_bytes, void* stream, bool bf16) {
+                         void* workspace, size_t ws_bytes, void* stream) {
     QARIG_CHECK_ARG(A && B && C, "gemm: null operand");
     QARIG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad extents M=%d N=%d K=%d", M, N, K);
     QARIG_CHECK_ARG(act >= 0 && act <= 3 && gact >= 0 && gact <= 3, "gemm: bad activation id");
@@ -644,8 +572,7 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     }
     hipStream_t st = (hipStream_t)stream;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    // (the reduced-precision mode keeps its interior shapes on the bf16 kernel)
-    if (M <= (bf16 ? 64 : SKINNY_MAX_ROWS) && a_kcontig && b_kcontig && K % 256 == 0 && !accumulate && !a_rowsum &&
+    if (M <= SKINNY_MAX_ROWS && a_kcontig && b_kcontig && K % 256 == 0 && !accumulate && !a_rowsum &&
         al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0) {
         GemmEpilogue eps{C, ldc, bias, residual, ldr, preact, ldp, act, gradz, ldz, gact, nullptr};
         launch_skinny(A, lda, B, ldb, eps, M, N, K, 0, 0, 0, 0, 1, st);
@@ -678,18 +605,20 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     const char* stagger_e = getenv("QARIG_GEMM_STAGGER");
     const int stagger_env = stagger_e ? atoi(stagger_e) : -1;
     const int stagger = (long)grid.x * grid.z >= 1024 ? (stagger_env >= 0 ? stagger_env : 2) : 0;
-    if (bf16 && fast && vec_epi && !a_rowsum && K % HK == 0 && per % HK == 0) {
+    const char* direct_e = getenv("QARIG_GEMM_DIRECT");
+    const bool direct = direct_e && direct_e[0] == '1';
+    if (direct && fast && vec_epi && !(a_rowsum && a_kcontig)) {
         if (a_kcontig && b_kcontig)
-            hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
+            hipLaunchKernelGGL((gemm_direct_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
                                N, K, tiles_n, splitk, slabs);
         else if (a_kcontig)
-            hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, st, A, lda, B, ldb, ep, M,
+            hipLaunchKernelGGL((gemm_direct_kernel<true, false>), grid, block, 0, st, A, lda, B, ldb, ep, M,
                                N, K, tiles_n, splitk, slabs);
         else if (b_kcontig)
-            hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
+            hipLaunchKernelGGL((gemm_direct_kernel<false, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
                                N, K, tiles_n, splitk, slabs);
         else
-            hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, st, A, lda, B, ldb, ep,
+            hipLaunchKernelGGL((gemm_direct_kernel<false, false>), grid, block, 0, st, A, lda, B, ldb, ep,
                                M, N, K, tiles_n, splitk, slabs);
     } else if (dma_on && dma_shape && fast && vec_epi && !(a_rowsum && a_kcontig) &&
         !(!a_kcontig && b_kcontig)) {
@@ -787,21 +716,7 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
                               void* workspace, size_t ws_bytes, void* stream) {
     return gemm_dispatch(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, residual, ldr,
                          preact, ldp, act, gradz, ldz, gact, splitk, accumulate, a_rowsum, workspace,
-                         ws_bytes, stream, false);
-}
-
-// Same contract as qarig_gemm_f32 with the products taken in bf16 (fp32 accumulate) on
-// interior shapes; every other shape, and any call with a_rowsum, runs the fp32 kernels.
-// Opt-in reduced precision (BASELINE config 5 direction): not covered by the fp32 parity bar.
-extern "C" int qarig_gemm_bf16(const float* A, int64_t lda, int a_kcontig, const float* B,
-                               int64_t ldb, int b_kcontig, float* C, int64_t ldc, int M, int N,
-                               int K, const float* bias, const float* residual, int64_t ldr,
-                               float* preact, int64_t ldp, int act, const float* gradz,
-                               int64_t ldz, int gact, int splitk, int accumulate, float* a_rowsum,
-                               void* workspace, size_t ws_bytes, void* stream) {
-    return gemm_dispatch(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, residual, ldr,
-                         preact, ldp, act, gradz, ldz, gact, splitk, accumulate, a_rowsum, workspace,
-                         ws_bytes, stream, true);
+                         ws_bytes, stream);
 }
 
 // `groups` independent skinny products in one launch (decode step: the q/k/v MLPs of an

@@ -1,0 +1,92 @@
+// The GEMM epilogue shared by the fp32 (gemm.hip) and reduced-precision (gemm_lp.hip) kernels:
+// bias, residual, saved pre-activation, activation, `* act'(z)` backward fusion, split-K slabs,
+// through a 16-B-wide LDS-staged store path.  Accumulators are the 2x2 32x32 MFMA tiles of a
+// wave's 64x64 sub-tile (the C/D register map is the same for the f32 and bf16 MFMAs).
+#pragma once
+#include "qarig_common.h"
+
+namespace qarig {
+
+struct GemmEpilogue {
+    float* C; int64_t ldc;
+    const float* bias;                    // [N], per column, or null
+    const float* residual; int64_t ldr;   // [M][N] added before the activation, or null
+    float* preact; int64_t ldp;           // receives acc+bias+residual, or null
+    int act;                              // activation applied to what goes to C
+    const float* gradz; int64_t ldz;      // C *= act'(gradz[m][n]) (backward fusion), or null
+    int gact;
+    float* rowsum;                        // [splitk][M]: sum_k A(m,k) per K split, or null
+    unsigned short* Cb; int64_t ldcb;     // optional bf16 copy of what goes to C (consumer GEMMs), or null
+    unsigned short* Pb; int64_t ldpb;     // optional bf16 copy of the saved pre-activation, or null
+};
+
+// two fp32 -> one dword of two bf16 (round to nearest even, v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t f = {a, b};
+    const bf16x2_t r = __builtin_convertvector(f, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// Wide epilogue (interior tiles): the wave's 64x64 tile goes through its private 8 KB of
+// LDS in two 32-row halves, so that every global access of the epilogue (C, preact,
+// residual, gradz, slabs) is a 16-B-per-lane, 256-B-per-row dwordx4 instead of 4x as many
+// 4-B accesses (the epilogue is store-issue bound otherwise).  `lds`: >= 32 KB, free.
+__device__ __forceinline__ void gemm_epilogue_wide(const Acc& acc, const GemmEpilogue& ep, float* lds,
+                                                   int m0, int n0, int M, int N, int splitk,
+                                                   float* slabs) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cl = lane & 31;
+    // 4 waves x 32 x 64 floats = 32 KB; unpadded rows are conflict-free for both the b32
+    // writes (half-waves hit different rows) and the b128 reads
+    constexpr int EL = 64;
+    float* stage = lds + wave * (32 * EL);
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+    const int gc = n0 + wn * 64 + ec;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ep.bias && splitk == 1) bv = *reinterpret_cast<const float4*>(ep.bias + gc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stage[acc_row(r, lane) * EL + j * 32 + cl] = acc.t[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int lr = it * 4 + er;
+            const int64_t row = m0 + wm * 64 + i * 32 + lr;
+            float4 t = *reinterpret_cast<const float4*>(stage + lr * EL + ec);
+            if (splitk > 1) {
+                *reinterpret_cast<float4*>(slabs + ((int64_t)blockIdx.z * M + row) * N + gc) = t;
+                continue;
+            }
+            t.x += bv.x; t.y += bv.y; t.z += bv.z; t.w += bv.w;
+            if (ep.residual) {
+                const float4 rv = *reinterpret_cast<const float4*>(ep.residual + row * ep.ldr + gc);
+                t.x += rv.x; t.y += rv.y; t.z += rv.z; t.w += rv.w;
+            }
+            if (ep.preact) *reinterpret_cast<float4*>(ep.preact + row * ep.ldp + gc) = t;
+            if (ep.Pb)
+                *reinterpret_cast<uint2*>(ep.Pb + row * ep.ldpb + gc) =
+                    make_uint2(pack_bf16x2(t.x, t.y), pack_bf16x2(t.z, t.w));
+            float4 y = make_float4(act_fwd(t.x, ep.act), act_fwd(t.y, ep.act),
+                                   act_fwd(t.z, ep.act), act_fwd(t.w, ep.act));
+            if (ep.gradz) {
+                const float4 z = *reinterpret_cast<const float4*>(ep.gradz + row * ep.ldz + gc);
+                y.x *= act_grad(z.x, ep.gact); y.y *= act_grad(z.y, ep.gact);
+                y.z *= act_grad(z.z, ep.gact); y.w *= act_grad(z.w, ep.gact);
+            }
+            if (ep.C) *reinterpret_cast<float4*>(ep.C + row * ep.ldc + gc) = y;
+            if (ep.Cb)
+                *reinterpret_cast<uint2*>(ep.Cb + row * ep.ldcb + gc) =
+                    make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace qarig

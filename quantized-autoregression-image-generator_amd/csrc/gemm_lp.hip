@@ -1,0 +1,295 @@
+// Reduced-precision GEMM for BASELINE config 5 (opt-in; never the fp32 parity path):
+// bf16 operands IN HBM, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation, the same
+// fused fp32 epilogue as the fp32 kernels (gemm_epilogue.h) plus optional bf16 copies of the
+// outputs for the next GEMM.  Replaces the Linear contractions of models/layers.py:234-254,
+// 330-340, 389-418 when qarig.ops precision is "bf16".
+//
+//   NT:  C[M,N] = sum_k A[m][k] * B[n][k]      A (M,K), B (N,K) bf16, reduction-contiguous
+//        (forward  x W^T;  input gradient  dT W  with the W^T shadow as B)
+//   TN:  C[M,N] = sum_k A[k][m] * B[k][n]      A (K,M), B (K,N) bf16, reduction-major
+//        (weight gradient  dT^T x: both operands are the row-major activations as they lie)
+//
+// Tile 128 x 128 x 64, 4 waves (2x2), each wave 2x2 accumulators of 32x32; the operand tiles
+// go global -> LDS by global_load_lds_dwordx4 (no VGPR staging) into a 2-stage ring, one
+// barrier per k-tile (the structure of gemm_dma_kernel).  The LDS image is lane-linear, so
+// the bank swizzles sit on the SOURCE address and on the read (guide rule 21):
+//   NT tile [128 rows][64 k]   (128-B rows):  16-B chunk c of row r at chunk c ^ (r & 7);
+//        fragments = one ds_read_b128 per (32-row tile, 16-deep k-step);
+//   TN tile [64 k][128 x]      (256-B rows):  chunk c of k-row r at c ^ (((r&3)<<2) | ((r>>2)&3));
+//        fragments = two ds_read_b64_tr_b16 (the hardware transpose read: 4 k-rows x 16 columns
+//        per 16-lane group, delivered column-major), so the reduction-major activations feed
+//        the MFMA without a transposed copy in HBM.
+#include <stdlib.h>
+
+#include "gemm_epilogue.h"
+
+namespace qarig {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_lp;
+typedef __attribute__((address_space(1))) const void* glb_ptr_lp;
+typedef unsigned short bf16_t;   // storage type of a bf16 element
+
+constexpr int LBK = 64;                         // reduction depth per staged tile
+constexpr int LP_OP = 128 * LBK;                // bf16 elements per operand tile (16 KB)
+constexpr int LP_STAGE = 2 * LP_OP;             // A then B
+
+__device__ __forceinline__ unsigned lds_addr_lp(const bf16_t* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const bf16_t*)p;
+}
+__device__ __forceinline__ int tn_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+// This wave's share (4 x 1 KiB) of one operand tile.
+template <bool TN>
+__device__ __forceinline__ void lp_stage(const bf16_t* __restrict__ P, int64_t ld, int x0, int k0,
+                                         bf16_t* tile, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave * 4 + i;
+        const bf16_t* src;
+        if (!TN) {   // [x][k]: 8 rows x 128 B per instruction
+            const int r = q * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            src = P + (int64_t)(x0 + r) * ld + k0 + c * 8;
+        } else {     // [k][x]: 4 k-rows x 256 B per instruction
+            const int r = q * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ tn_swz(r);
+            src = P + (int64_t)(k0 + r) * ld + x0 + c * 8;
+        }
+        __builtin_amdgcn_global_load_lds((glb_ptr_lp)src, (lds_ptr_lp)(tile + q * 512), 16, 0, 0);
+    }
+}
+
+// Fragment of the 32-row (column) tile starting at x0 for k-step ks (16 deep): lane l holds
+// element j = operand(x0 + (l & 31), k = 16 ks + 8 (l >> 5) + j).
+template <bool TN>
+__device__ __forceinline__ void lp_frag(const bf16_t* tile, int x0, int ks, int lane, bf16x8& f) {
+    if (!TN) {
+        const int r = x0 + (lane & 31);
+        const int c = (ks * 2 + (lane >> 5)) ^ (r & 7);
+        const unsigned a = lds_addr_lp(tile) + r * 128 + (c << 4);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f) : "v"(a));
+    } else {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
+        const int ch = ((x0 + 16 * (g & 1)) >> 3) + (p >> 1);
+        const int r0 = ks * 16 + 8 * (g >> 1) + q;
+        const int r1 = r0 + 4;
+        const unsigned base = lds_addr_lp(tile) + 8 * (p & 1);
+        const unsigned a0 = base + 256 * r0 + ((ch ^ tn_swz(r0)) << 4);
+        const unsigned a1 = base + 256 * r1 + ((ch ^ tn_swz(r1)) << 4);
+        s16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        f = __builtin_bit_cast(bf16x8, both);
+    }
+}
+
+template <bool TN>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_lp_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                              const bf16_t* __restrict__ B, int64_t ldb,
+                                                              GemmEpilogue ep, int M, int N, int K,
+                                                              int tiles_n, int splitk, float* slabs) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * LP_STAGE];   // 64 KB: 2 workgroups per CU
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    int k_begin = 0, k_end = K;
+    if (splitk > 1) {
+        const int per = K / splitk;           // host guarantees per % LBK == 0
+        k_begin = blockIdx.z * per;
+        k_end = k_begin + per;
+    }
+    const int nk = (k_end - k_begin) / LBK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    Acc acc;
+    acc_zero(acc);
+    if (nk > 0) {
+        lp_stage<TN>(A, lda, m0, k_begin, lds, wave, lane);
+        lp_stage<TN>(B, ldb, n0, k_begin, lds + LP_OP, wave, lane);
+        for (int kt = 0; kt < nk; ++kt) {
+            // this wave's DMAs of tile kt have landed, then (barrier) everybody's; the same barrier
+            // retires all reads of tile kt-1, whose stage is refilled right after it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int st = kt & 1;
+            if (kt + 1 < nk) {
+                const int kn = k_begin + (kt + 1) * LBK;
+                lp_stage<TN>(A, lda, m0, kn, lds + (st ^ 1) * LP_STAGE, wave, lane);
+                lp_stage<TN>(B, ldb, n0, kn, lds + (st ^ 1) * LP_STAGE + LP_OP, wave, lane);
+            }
+            const bf16_t* ta = lds + st * LP_STAGE;
+            const bf16_t* tb = ta + LP_OP;
+            bf16x8 fa[4][2], fb[4][2];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    lp_frag<TN>(ta, wm * 64 + i * 32, ks, lane, fa[ks][i]);
+                    lp_frag<TN>(tb, wn * 64 + i * 32, ks, lane, fb[ks][i]);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc.t[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j],
+                                                                              acc.t[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();                      // ring no longer in use: the epilogue stages through it
+    gemm_epilogue_wide(acc, ep, reinterpret_cast<float*>(lds), m0, n0, M, N, splitk, slabs);
+}
+
+// dst[i] = bf16(src[i]), round to nearest even; n % 8 == 0, 16-B aligned.
+__global__ void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * i];
+        const float4 b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        reinterpret_cast<uint4*>(dst)[i] = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w),
+                                                      pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+    }
+}
+__global__ void cast_bf16_tail_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                      int64_t begin, int64_t n) {
+    const int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (bf16_t)(pack_bf16x2(src[i], 0.0f) & 0xffffu);
+}
+
+// dst[c][r] = bf16(src[r][c]) for src (R, C) row-major with leading dimension lds_: the W^T
+// shadow of a Linear weight.  64 x 64 tiles through LDS, coalesced on both sides.
+__global__ __launch_bounds__(256) void cast_transpose_bf16_kernel(const float* __restrict__ src,
+                                                                  int64_t ld, int R, int C,
+                                                                  bf16_t* __restrict__ dst) {
+    __shared__ float t[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        t[r][c] = (r0 + r < R && c0 + c < C) ? src[(int64_t)(r0 + r) * ld + c0 + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
+        const int c = idx >> 5, r = (idx & 31) * 2;
+        if (c0 + c < C && r0 + r < R) {
+            const uint32_t v = pack_bf16x2(t[r][c], t[r + 1][c]);
+            if (r0 + r + 1 < R && ((R & 1) == 0))
+                *reinterpret_cast<uint32_t*>(dst + (int64_t)(c0 + c) * R + r0 + r) = v;
+            else {
+                dst[(int64_t)(c0 + c) * R + r0 + r] = (bf16_t)(v & 0xffffu);
+                if (r0 + r + 1 < R) dst[(int64_t)(c0 + c) * R + r0 + r + 1] = (bf16_t)(v >> 16);
+            }
+        }
+    }
+}
+}  // namespace qarig
+
+using namespace qarig;
+
+extern "C" int qarig_slab_reduce_f32(const float* slabs, float* out, int64_t ldc, int M, int N,
+                                     int nslab, int accumulate, void* stream);
+
+// fp32 -> bf16 (round to nearest even) of n contiguous elements; dst holds n 16-bit values.
+// New entry (no reference counterpart): the operand conversion of the reduced-precision mode.
+extern "C" int qarig_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    QARIG_CHECK_ARG(src && dst && n > 0, "cast_bf16: bad arguments");
+    QARIG_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "cast_bf16: 16-B aligned buffers");
+    const int64_t n8 = n / 8;
+    if (n8 > 0) {
+        int blocks = (int)((n8 + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
+                           (bf16_t*)dst, n8);
+    }
+    if (n8 * 8 < n)
+        hipLaunchKernelGGL(cast_bf16_tail_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src,
+                           (bf16_t*)dst, n8 * 8, n);
+    QARIG_CHECK_LAUNCH("cast_bf16");
+    return QARIG_OK;
+}
+
+// dst (C, R) bf16 = transpose of src (R, C) fp32 (row stride ld).
+extern "C" int qarig_cast_transpose_bf16(const float* src, int64_t ld, int R, int C, void* dst,
+                                         void* stream) {
+    QARIG_CHECK_ARG(src && dst && R > 0 && C > 0 && ld >= C, "cast_transpose_bf16: bad arguments");
+    QARIG_CHECK_ARG(((uintptr_t)dst & 3) == 0, "cast_transpose_bf16: 4-B aligned destination");
+    hipLaunchKernelGGL(cast_transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0,
+                       (hipStream_t)stream, src, ld, R, C, (bf16_t*)dst);
+    QARIG_CHECK_LAUNCH("cast_transpose_bf16");
+    return QARIG_OK;
+}
+
+extern "C" size_t qarig_gemm_lp_workspace_bytes(int M, int N, int splitk) {
+    return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0;
+}
+
+// 1 when the shape can run on the reduced-precision kernel (else the caller uses qarig_gemm_f32).
+extern "C" int qarig_gemm_lp_supported(int M, int N, int K, int splitk) {
+    if (splitk < 1) splitk = 1;
+    return M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % splitk == 0 &&
+           (K / splitk) % LBK == 0;
+}
+
+// C (fp32, optional) / Cb (bf16, optional) = epilogue(A B^T) with bf16 operands.
+// layout 0 = NT (A (M,K), B (N,K)), 1 = TN (A (K,M), B (K,N)); lda/ldb in elements.
+// Epilogue arguments as qarig_gemm_f32 (bias, residual, preact, act, gradz/gact, splitk,
+// accumulate); Cb / Pb: optional bf16 copies of the output / of the saved pre-activation.
+extern "C" int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t ldb, int layout,
+                             float* C, int64_t ldc, int M, int N, int K, const float* bias,
+                             const float* residual, int64_t ldr, float* preact, int64_t ldp, int act,
+                             const float* gradz, int64_t ldz, int gact, int splitk, int accumulate,
+                             void* Cb, int64_t ldcb, void* Pb, int64_t ldpb, void* workspace,
+                             size_t ws_bytes, void* stream) {
+    QARIG_CHECK_ARG(A && B && (C || Cb), "gemm_lp: null operand");
+    QARIG_CHECK_ARG(layout == 0 || layout == 1, "gemm_lp: layout must be 0 (NT) or 1 (TN)");
+    QARIG_CHECK_ARG(act >= 0 && act <= 3 && gact >= 0 && gact <= 3, "gemm_lp: bad activation id");
+    if (splitk < 1) splitk = 1;
+    QARIG_CHECK_ARG(qarig_gemm_lp_supported(M, N, K, splitk),
+                    "gemm_lp: needs M,N %% 128 == 0 and K/splitk %% 64 == 0 (M=%d N=%d K=%d splitk=%d)",
+                    M, N, K, splitk);
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    QARIG_CHECK_ARG(al16(A) && al16(B) && lda % 8 == 0 && ldb % 8 == 0, "gemm_lp: operands 16-B aligned, ld %% 8");
+    auto ok4 = [&](const void* p, int64_t ld) { return !p || (al16(p) && ld % 4 == 0); };
+    QARIG_CHECK_ARG(ok4(C, ldc) && ok4(bias, 4) && ok4(residual, ldr) && ok4(preact, ldp) && ok4(gradz, ldz),
+                    "gemm_lp: fp32 epilogue tensors 16-B aligned, ld %% 4");
+    QARIG_CHECK_ARG((!Cb || (((uintptr_t)Cb & 7) == 0 && ldcb % 4 == 0)) &&
+                        (!Pb || (((uintptr_t)Pb & 7) == 0 && ldpb % 4 == 0)),
+                    "gemm_lp: bf16 outputs 8-B aligned, ld %% 4");
+    if (accumulate) {
+        QARIG_CHECK_ARG(C && !bias && !residual && !preact && !gradz && act == ACT_NONE && !Cb && !Pb,
+                        "gemm_lp: accumulate supports the plain epilogue only");
+        if (splitk == 1) { residual = C; ldr = ldc; }
+    }
+    if (splitk > 1) {
+        QARIG_CHECK_ARG(C && !bias && !residual && !preact && !gradz && act == ACT_NONE && !Cb && !Pb,
+                        "gemm_lp: split-K supports the plain epilogue only");
+        if (!workspace || ws_bytes < qarig_gemm_lp_workspace_bytes(M, N, splitk)) {
+            qarig_set_error("gemm_lp: workspace too small");
+            return QARIG_ERR_WORKSPACE;
+        }
+    }
+    const int tiles_m = M / BM, tiles_n = N / BN;
+    dim3 grid(tiles_m * tiles_n, 1, splitk), block(NTHREADS);
+    GemmEpilogue ep{C, ldc, bias, residual, ldr, preact, ldp, act, gradz, ldz, gact, nullptr,
+                    (unsigned short*)Cb, ldcb, (unsigned short*)Pb, ldpb};
+    hipStream_t st = (hipStream_t)stream;
+    if (layout == 0)
+        hipLaunchKernelGGL((gemm_lp_kernel<false>), grid, block, 0, st, (const bf16_t*)A, lda,
+                           (const bf16_t*)B, ldb, ep, M, N, K, tiles_n, splitk, (float*)workspace);
+    else
+        hipLaunchKernelGGL((gemm_lp_kernel<true>), grid, block, 0, st, (const bf16_t*)A, lda,
+                           (const bf16_t*)B, ldb, ep, M, N, K, tiles_n, splitk, (float*)workspace);
+    QARIG_CHECK_LAUNCH("gemm_lp");
+    if (splitk > 1)
+        return qarig_slab_reduce_f32((const float*)workspace, C, ldc, M, N, splitk, accumulate, stream);
+    return QARIG_OK;
+}

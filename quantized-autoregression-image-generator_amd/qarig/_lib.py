@@ -30,8 +30,12 @@ SIGNATURES = {
     "qarig_gemm_workspace_bytes": (Z, [I, I, I]),
     "qarig_gemm_f32": (I, [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, I, P, P, Z,
                            P]),
-    "qarig_gemm_bf16": (I, [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, I, P, P, Z,
-                           P]),
+    "qarig_gemm_lp_supported": (I, [I, I, I, I]),
+    "qarig_gemm_lp_workspace_bytes": (Z, [I, I, I]),
+    "qarig_gemm_lp": (I, [P, L, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, I, P, L, P, L, P, Z,
+                          P]),
+    "qarig_cast_bf16": (I, [P, P, L, P]),
+    "qarig_cast_transpose_bf16": (I, [P, L, I, I, P, P]),
     "qarig_colsum_workspace_bytes": (Z, [I, I]),
     "qarig_colsum_f32": (I, [P, L, I, I, P, I, P, Z, P]),
     "qarig_patchify_fwd": (I, [P, I, I, I, I, I, I, P, P]),

@@ -93,15 +93,14 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
         nws = lib.qarig_gemm_workspace_bytes(M, N, splitk)
         ws = workspace(nws, A.device, "gemm")
         nws = ws.numel()
-    fn, fn_name = lib.qarig_gemm_f32, "qarig_gemm_f32"
     if PRECISION == "bf16":
-        fn, fn_name = lib.qarig_gemm_bf16, "qarig_gemm_bf16"
-        if a_rowsum is not None and not a_kcontig:
-            # the bf16 kernel has no row-sum hook: the bias gradient is its own (fp32) pass
-            colsum(A, out=a_rowsum, accumulate=accumulate)
-            a_rowsum = None
+        done = _gemm_lp(lib, A, B, a_kcontig, b_kcontig, C, pre, M, N, K, bias, residual, act, gradz,
+                        gact, splitk, accumulate, a_rowsum)
+        if done:
+            return (C, pre) if want_preact else C
     elif PRECISION != "f32":
-        raise ValueError(f"qarig.ops.PRECISION must be 'f32' or 'bf16', not {PRECISION!r}")
+        raise ValueError(f"qarig.ops.PRECISION must be one of {PRECISIONS}, not {PRECISION!r}")
+    fn, fn_name = lib.qarig_gemm_f32, "qarig_gemm_f32"
     if GEMM_EVENTS is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -117,6 +116,131 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
         ev1.record()
         GEMM_EVENTS.append((2.0 * M * N * K, ev0, ev1))
     return (C, pre) if want_preact else C
+
+
+# ---- reduced precision (BASELINE config 5): bf16 operands in HBM -------------------------------
+# bf16 shadows of tensors that several GEMMs read (weights, in both layouts): keyed by storage,
+# shape, torch's in-place version counter and LP_EPOCH, which qarig.optim bumps whenever its
+# Adam kernel rewrites the parameters behind torch's back.
+LP_EPOCH = 0
+_lp_cache = {}
+
+
+def lp_invalidate():
+    global LP_EPOCH
+    LP_EPOCH += 1
+    if len(_lp_cache) > 4096:
+        _lp_cache.clear()
+
+
+def cast_bf16(x, cache=False):
+    """bf16 copy (torch.bfloat16, same shape) of a dense fp32 tensor, rounded to nearest even."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    key = None
+    if cache and not torch.cuda.is_current_stream_capturing():
+        key = ("n", x.data_ptr(), tuple(x.shape), x._version, LP_EPOCH)
+        hit = _lp_cache.get(key)
+        if hit is not None:
+            return hit
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().qarig_cast_bf16(ptr(x), ptr(out), x.numel(), stream()), "qarig_cast_bf16")
+    if key is not None:
+        _lp_cache[key] = out
+    return out
+
+
+def cast_transpose_bf16(x, cache=False):
+    """bf16 (C, R) transpose of a row-contiguous fp32 (R, C) matrix."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    key = None
+    if cache and not torch.cuda.is_current_stream_capturing():
+        key = ("t", x.data_ptr(), tuple(x.shape), x.stride(0), x._version, LP_EPOCH)
+        hit = _lp_cache.get(key)
+        if hit is not None:
+            return hit
+    R, Cc = x.shape
+    out = torch.empty((Cc, R), dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().qarig_cast_transpose_bf16(ptr(x), x.stride(0), R, Cc, ptr(out), stream()),
+          "qarig_cast_transpose_bf16")
+    if key is not None:
+        _lp_cache[key] = out
+    return out
+
+
+def _is_param_like(t):
+    """Weights (cached shadows) vs activations (cast per call)."""
+    return isinstance(t, torch.nn.Parameter) or getattr(t, "_qarig_weight", False)
+
+
+def gemm_lp(A_bf, B_bf, layout, M, N, K, C=None, bias=None, residual=None, preact=None, act=0, gradz=None,
+            gact=0, splitk=1, accumulate=False, Cb=None, Pb=None):
+    """Raw reduced-precision GEMM on bf16 operands (include/qarig.h qarig_gemm_lp)."""
+    lib = _lib.load()
+    ws, nws = None, 0
+    if splitk > 1:
+        nws = lib.qarig_gemm_lp_workspace_bytes(M, N, splitk)
+        ws = workspace(nws, A_bf.device, "gemm")
+        nws = ws.numel()
+    if GEMM_EVENTS is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib.qarig_gemm_lp(
+        ptr(A_bf), A_bf.stride(0), ptr(B_bf), B_bf.stride(0), layout,
+        ptr(C), C.stride(0) if C is not None else 0, M, N, K, ptr(bias),
+        ptr(residual), residual.stride(0) if residual is not None else 0,
+        ptr(preact), preact.stride(0) if preact is not None else 0, act,
+        ptr(gradz), gradz.stride(0) if gradz is not None else 0, gact, splitk, int(accumulate),
+        ptr(Cb), Cb.stride(0) if Cb is not None else 0, ptr(Pb), Pb.stride(0) if Pb is not None else 0,
+        ptr(ws), nws, stream()), "qarig_gemm_lp")
+    if GEMM_EVENTS is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        GEMM_EVENTS.append((2.0 * M * N * K, ev0, ev1))
+
+
+def _gemm_lp(lib, A, B, a_kcontig, b_kcontig, C, pre, M, N, K, bias, residual, act, gradz, gact, splitk,
+             accumulate, a_rowsum):
+    """The fp32-tensor GEMM contract on the bf16 MFMA: operands are cast to bf16 in HBM (weights
+    once per optimiser step, in the layout the product needs; activations per call) and
+    multiplied by qarig_gemm_lp.  Returns False when the shape is not an interior one (the
+    caller then runs the fp32 kernels).  The three Linear products map to
+        forward   (kc, kc): NT on  x_bf (M,K)    and W_bf (N,K)
+        d-input   (kc, xc): NT on  dT_bf (M,N')  and the W^T shadow (K',N')
+        d-weight  (xc, xc): TN on  dT_bf, x_bf as they lie (row-major, reduction-major)."""
+    if a_kcontig == (not b_kcontig) and not a_kcontig:
+        return False                       # (xc, kc) never occurs on the hot path
+    if splitk > 1 and (K % splitk or (K // splitk) % 64):
+        s = splitk
+        while s > 1 and (K % s or (K // s) % 64):
+            s -= 1
+        splitk = s
+    plain = bias is None and residual is None and pre is None and gradz is None and act == 0
+    if splitk > 1 and not plain:
+        splitk = 1
+    if not lib.qarig_gemm_lp_supported(M, N, K, splitk):
+        return False
+    for t in (A, B):
+        if t.data_ptr() % 16 or t.stride(0) % 8:
+            return False
+    if a_rowsum is not None:
+        if a_kcontig:
+            return False
+        colsum(A, out=a_rowsum, accumulate=accumulate)      # bias gradient: its own fp32 pass
+    if a_kcontig and b_kcontig:            # forward
+        A_bf = cast_bf16(A if A.is_contiguous() else A.contiguous())
+        B_bf = cast_bf16(B if B.is_contiguous() else B.contiguous(), cache=_is_param_like(B))
+        layout = 0
+    elif a_kcontig:                        # d-input: B is (K_red, N_out) = the weight as stored
+        A_bf = cast_bf16(A if A.is_contiguous() else A.contiguous())
+        B_bf = cast_transpose_bf16(B, cache=_is_param_like(B))
+        layout = 0
+    else:                                  # d-weight
+        A_bf = cast_bf16(A if A.is_contiguous() else A.contiguous())
+        B_bf = cast_bf16(B if B.is_contiguous() else B.contiguous())
+        layout = 1
+    gemm_lp(A_bf, B_bf, layout, M, N, K, C=C, bias=bias, residual=residual, preact=pre, act=act,
+            gradz=gradz, gact=gact, splitk=splitk, accumulate=accumulate)
+    return True
 
 
 def gemm_grouped_skinny(A, W, bias=None, act=0, shared_a=False):

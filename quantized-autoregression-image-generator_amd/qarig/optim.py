@@ -130,6 +130,7 @@ class FlatAdam:
         step_size, bc2_sqrt = self._step_scalars(self.step_count)
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, b1, b2,
                       g["eps"], step_size, bc2_sqrt, grad_scale)
+        ops.lp_invalidate()      # bf16 weight shadows of the reduced-precision mode are stale now
 
     # -- graph replay (qarig.pipeline.GraphedTrainStep) -----------------------------------
     def _dev_step_buffer(self):
@@ -145,6 +146,7 @@ class FlatAdam:
         b1, b2 = g["betas"]
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, b1, b2,
                       g["eps"], 0.0, 1.0, grad_scale, dev_step=self._dev_step_buffer())
+        ops.lp_invalidate()
 
     def advance_captured(self):
         self.step_count += 1
@@ -173,3 +175,4 @@ class FlatAdam:
             self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
             self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
             self.step_count = int(float(st["step"]))
+        ops.lp_invalidate()

@@ -1,9 +1,11 @@
-"""Opt-in reduced-precision mode (qarig.ops.PRECISION = "bf16"; BASELINE config 5 direction).
+"""Opt-in reduced-precision mode (qarig.ops.PRECISION = "bf16"; BASELINE config 5).
 NOT the parity mode: the fp32 tests elsewhere hold the reference bar.  Here the bf16-MFMA
-GEMM is pinned against its own definition - operands rounded to bf16 (round-to-nearest-even),
-exact products, fp32 accumulation - for which an fp64 contraction of the rounded operands
-is the reference (tolerance 3e-6 * sqrt(K/512), accumulation order only), and a training
-step is checked to track the fp32 step within the bf16 rounding budget (tolerances below)."""
+GEMM (csrc/gemm_lp.hip: bf16 operands in HBM, fp32 accumulation) is pinned against its own
+definition - operands rounded to bf16 (round-to-nearest-even), exact products, fp32
+accumulation - for which an fp64 contraction of the rounded operands is the reference
+(tolerance 3e-6 * sqrt(K/512), accumulation order only); the fragment maps of both layouts are
+checked on exact integer data; and a training step is checked to track the fp32 step within
+the bf16 rounding budget (tolerances below)."""
 import pytest
 import torch
 
@@ -25,8 +27,69 @@ def _rounded(t):
     return t.bfloat16().double()
 
 
-@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, False), (False, True)])
-@pytest.mark.parametrize("M,N,K,splitk", [(128, 128, 32, 1), (256, 384, 512, 1), (128, 256, 2048, 4),
+def test_cast_kernels_round_to_nearest_even():
+    from qarig import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((300, 264), generator=g).cuda()
+    x[0, :4] = torch.tensor([1.0 + 2 ** -8, 1.0 + 3 * 2 ** -8, -1.0 - 2 ** -8, 65504.0])   # ties -> even
+    assert torch.equal(ops.cast_bf16(x), x.bfloat16())
+    assert torch.equal(ops.cast_transpose_bf16(x), x.bfloat16().t().contiguous())
+    y = torch.randn((130, 70), generator=g).cuda()                # ragged tiles, tail kernel
+    assert torch.equal(ops.cast_bf16(y), y.bfloat16())
+    assert torch.equal(ops.cast_transpose_bf16(y), y.bfloat16().t().contiguous())
+    v = ops.cast_transpose_bf16(x[:, :128])                       # strided source
+    assert torch.equal(v, x[:, :128].bfloat16().t().contiguous())
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_lp_fragment_maps_on_exact_integer_data(layout):
+    """A = a permutation-like integer matrix, B asymmetric small integers: every product and sum
+    is exact in bf16/fp32, so any wrong lane map, swizzle or transposed read shows as a wrong
+    integer (guide: 'A = I check with ASYMMETRIC B')."""
+    from qarig import ops
+    M, N, K = 256, 384, 192
+    g = torch.Generator().manual_seed(3)
+    A = torch.zeros((M, K))
+    A[torch.arange(M), torch.randint(0, K, (M,), generator=g)] = 1.0
+    A[torch.arange(M), torch.randint(0, K, (M,), generator=g)] += 2.0
+    B = torch.randint(-8, 9, (N, K), generator=g).float() + torch.arange(N)[:, None] % 5
+    ref = A.double() @ B.double().t()
+    if layout == 0:
+        Ab, Bb = A.cuda().bfloat16(), B.cuda().bfloat16()
+    else:
+        Ab, Bb = A.t().contiguous().cuda().bfloat16(), B.t().contiguous().cuda().bfloat16()
+    C = torch.empty((M, N), device="cuda")
+    Cb = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    ops.gemm_lp(Ab, Bb, layout, M, N, K, C=C, Cb=Cb)
+    assert torch.equal(C.double().cpu(), ref)
+    assert torch.equal(Cb.double().cpu(), ref.bfloat16().double())
+    C2 = torch.empty((M, N), device="cuda")
+    ops.gemm_lp(Ab, Bb, layout, M, N, K, C=C2, splitk=3)
+    assert torch.equal(C2.double().cpu(), ref)
+
+
+def test_lp_epilogue_bf16_copies():
+    from qarig import ops
+    from oracle import ref_models as rm
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 128, 256, 128
+    A, W = torch.randn((M, K), generator=g).cuda(), (torch.randn((N, K), generator=g) * 0.1).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    C = torch.empty((M, N), device="cuda")
+    P = torch.empty((M, N), device="cuda")
+    Cb = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    Pb = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    ops.gemm_lp(ops.cast_bf16(A), ops.cast_bf16(W), 0, M, N, K, C=C, bias=b, preact=P, act=1, Cb=Cb, Pb=Pb)
+    t = _rounded(A.cpu()) @ _rounded(W.cpu()).t() + b.double().cpu()
+    assert rel_err(P, t) < 3e-6 and rel_err(C, rm.activation(t, "silu")) < 5e-6
+    assert torch.equal(Cb, C.bfloat16()) and torch.equal(Pb, P.bfloat16())
+    only = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)     # bf16-only output
+    ops.gemm_lp(ops.cast_bf16(A), ops.cast_bf16(W), 0, M, N, K, bias=b, act=1, Cb=only)
+    assert torch.equal(only, Cb)
+
+
+@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize("M,N,K,splitk", [(128, 128, 64, 1), (256, 384, 512, 1), (128, 256, 2048, 4),
                                           (384, 128, 4096, 8)])
 def test_bf16_gemm_is_exact_on_rounded_operands(bf16_mode, M, N, K, splitk, ak, bk):
     ops = bf16_mode

@@ -44,12 +44,17 @@ def main():
         cases.append((name, m, n, k, dict(A=A, B=B, a_kcontig=ak, b_kcontig=bk, bias=bias,
                                           want_preact=kw.get("pre", False), act=kw.get("act", 0),
                                           gradz=gz, gact=1 if gz is not None else 0, splitk=sk)))
-    sweep = [int(v) for v in os.environ.get("STAGGER_SWEEP", "").split(",") if v]
-    if sweep:     # first-round stagger of co-resident workgroups (csrc/gemm.hip), interleaved rounds
+    # SWEEP="ENV_NAME=v0,v1,...": A/B of a kernel knob read from the environment per launch
+    # (csrc/gemm.hip), interleaved rounds in one process
+    sweep_env, sweep = "QARIG_GEMM_STAGGER", []
+    if os.environ.get("SWEEP"):
+        sweep_env, vals = os.environ["SWEEP"].split("=")
+        sweep = vals.split(",")
+    if sweep:
         res = {}
         for rnd in range(5):
             for st in sweep:
-                os.environ["QARIG_GEMM_STAGGER"] = str(st)
+                os.environ[sweep_env] = str(st)
                 for name, m, n, k, kw in cases[:9]:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ops.gemm(**kw)
@@ -60,7 +65,7 @@ def main():
                     torch.cuda.synchronize()
                     res.setdefault((name, st), []).append(2.0 * m * n * k / (e0.elapsed_time(e1) / 10) / 1e9)
         for name, m, n, k, kw in cases[:9]:
-            print(f"{name:36s} " + "  ".join(f"st{st}: {sorted(res[(name, st)])[2]:6.1f}" for st in sweep))
+            print(f"{name:36s} " + "  ".join(f"{sweep_env[-8:]}={st}: {sorted(res[(name, st)])[2]:6.1f}" for st in sweep))
         return
     for rnd in range(4):
         for name, m, n, k, kw in cases:
