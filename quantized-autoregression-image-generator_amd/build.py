@@ -53,5 +53,50 @@ def build_lib(verbose=True, force=False):
     return LIB
 
 
+SAN_LIB = os.path.join(HERE, "lib", "libqarig_hip_san.so")
+SAN_FLAGS = ["--offload-arch=gfx950", "-O1", "-g", "-fPIC", "-std=c++17", "-ffp-contract=off",
+             "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-gpu-sanitize",
+             "-fno-omit-frame-pointer", "-Wno-unused-function"]
+
+
+def build_sanitizer_lib(verbose=False):
+    """Test-only build: the HOST side of every csrc/*.hip (argument validation, workspace and
+    launch-geometry arithmetic, dispatch) under AddressSanitizer + UndefinedBehaviorSanitizer;
+    device code is compiled normally (GPU ASan / xnack builds are not available on this pool).
+    tests/test_sanitizers.py loads it in a subprocess with the ASan runtime preloaded."""
+    obj_dir = os.path.join(HERE, "lib", "obj_san")
+    os.makedirs(obj_dir, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
+    jobs, objs = [], []
+    for s in srcs:
+        src, obj = os.path.join(CSRC, s), os.path.join(obj_dir, s[:-4] + ".o")
+        objs.append(obj)
+        if _newer(src, obj) or hdr_time > os.path.getmtime(obj):
+            jobs.append([HIPCC, *SAN_FLAGS, "-c", src, "-o", obj])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc (sanitizer build) failed:\n" + r.stdout + r.stderr)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            list(ex.map(run, jobs))
+    if jobs or not os.path.exists(SAN_LIB):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined",
+             "-fno-gpu-sanitize", "-o", SAN_LIB, *objs])
+    return SAN_LIB
+
+
+def asan_runtime():
+    r = subprocess.run([os.path.join(os.path.dirname(HIPCC), "..", "lib", "llvm", "bin", "clang"),
+                        "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    return r.stdout.strip()
+
+
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv))
+    if "--sanitizers" in sys.argv:
+        print(build_sanitizer_lib(verbose=True))
+    else:
+        print(build_lib(force="--force" in sys.argv))

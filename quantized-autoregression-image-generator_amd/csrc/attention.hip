@@ -643,6 +643,12 @@ using namespace qarig;
 
 static int attn_check(int N, int Sq, int Sk, int H, int d, int causal) {
     QARIG_CHECK_ARG(N > 0 && Sq > 0 && Sk > 0 && H > 0 && d > 0, "attention: bad extents");
+    QARIG_CHECK_DIMS("attention", N, Sq, H);
+    QARIG_CHECK_DIMS("attention", N, Sk, H);
+    QARIG_CHECK_ARG(d == 4 || d == 8 || d == 16 || d == 32 || d == 64,
+                    "attention: head dim %d unsupported (4,8,16,32,64)", d);
+    QARIG_CHECK_ARG((long long)N * ((H + 3) / 4) * ((Sq > Sk ? Sq : Sk) / 64 + 1) < (1LL << 31),
+                    "attention: too many workgroups");
     QARIG_CHECK_ARG(!causal || Sq == Sk, "attention: causal needs Sq == Sk (self-attention)");
     return QARIG_OK;
 }
@@ -762,6 +768,8 @@ extern "C" int qarig_attention_decode(const float* q, const float* k_new, const 
     QARIG_CHECK_ARG((k_new == nullptr) == (v_new == nullptr),
                     "attention_decode: k_new and v_new go together");
     QARIG_CHECK_ARG(B > 0 && H > 0 && d > 0 && max_len > 0, "attention_decode: bad extents");
+    QARIG_CHECK_DIMS("attention_decode", B, H, max_len);
+    QARIG_CHECK_ARG(d <= 64 && (long long)B * H < (1LL << 31), "attention_decode: bad extents");
     QARIG_CHECK_ARG(batch_stride >= (int64_t)max_len * H * d,
                     "attention_decode: batch_stride smaller than max_len rows");
     if (!len_dev) {

@@ -586,6 +586,7 @@ static int bmu_code_tiles(int K) { return (K + BM - 1) / BM; }
 static constexpr int FEWROWS_MAX = 128, FEWROWS_MIN_D = 512;
 
 extern "C" size_t qarig_bmu_workspace_bytes(int64_t rows, int K) {
+    if (rows < 0 || rows > (1LL << 31) || K < 1 || K > (1 << 24)) return 0;     // refused by qarig_bmu_fwd
     // per-split (min, idx, second) partials for up to code_tiles splits + |x|^2 per row
     size_t need = (size_t)bmu_code_tiles(K) * (size_t)rows * 12 + (size_t)rows * 4 + 64;
     // few-rows form: rows x K dot products + |w|^2 + |x|^2
@@ -600,6 +601,8 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
     QARIG_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && pH > 0 && pW > 0 && K > 0,
                     "bmu: bad extents");
     QARIG_CHECK_ARG(pH <= H && pW <= W, "bmu: patch larger than the latent");
+    QARIG_CHECK_DIMS("bmu", N, C, H, W);
+    QARIG_CHECK_DIMS("bmu", K, C, pH, pW);
     QARIG_CHECK_ARG(D == C * pH * pW, "bmu: codebook width %d != C*pH*pW = %d", D, C * pH * pW);
     PatchGeom g{x, N, C, H, W, pH, pW, H / pH, W / pW, D, 0};
     const int64_t rows = (int64_t)N * g.gh * g.gw;

@@ -104,6 +104,8 @@ static dim3 cb_grid(int64_t n) {
 static int make_geom(PGeom& g, int N, int C, int H, int W, int pH, int pW) {
     QARIG_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && pH > 0 && pW > 0, "patch geometry: bad extents");
     QARIG_CHECK_ARG(H % pH == 0 && W % pW == 0, "patch geometry: H,W must be multiples of the patch");
+    QARIG_CHECK_DIMS("patch geometry", N, C, H, W);
+    QARIG_CHECK_DIMS("patch geometry", C, pH, pW);
     g = PGeom{N, C, H, W, pH, pW, H / pH, W / pW, C * pH * pW};
     return QARIG_OK;
 }
@@ -148,6 +150,8 @@ extern "C" int qarig_codebook_gather_image(const int64_t* ids, int N, int C, int
 // nn.Embedding row gather (codebook rows; models/Codebook.py:132,144).
 extern "C" int qarig_gather_rows(const int64_t* ids, int64_t R, int D, int K, const float* table,
                                  float* out, int* bad_flag, void* stream) {
+    QARIG_CHECK_DIMS("gather_rows", R, D);
+    QARIG_CHECK_DIMS("gather_rows", K, D);
     QARIG_CHECK_ARG(ids && table && out && bad_flag && R > 0 && D > 0 && K > 0,
                     "gather_rows: bad arguments");
     hipLaunchKernelGGL(gather_rows_kernel, cb_grid(R * D), dim3(256), 0, (hipStream_t)stream, ids, R,
@@ -160,6 +164,7 @@ extern "C" int qarig_gather_rows(const int64_t* ids, int64_t R, int D, int K, co
 extern "C" int qarig_som_weights_fwd(const int64_t* bmu, int64_t R, int K, float two_var, float* g,
                                      void* stream) {
     QARIG_CHECK_ARG(bmu && g && R > 0 && K > 0 && two_var > 0, "som_weights: bad arguments");
+    QARIG_CHECK_DIMS("som_weights", R, K);
     hipLaunchKernelGGL(som_weights_kernel, cb_grid(R * K), dim3(256), 0, (hipStream_t)stream, bmu, R,
                        K, two_var, g);
     QARIG_CHECK_LAUNCH("som_weights");
@@ -171,6 +176,7 @@ extern "C" int qarig_som_weights_fwd(const int64_t* bmu, int64_t R, int K, float
 extern "C" int qarig_index_histogram(const int64_t* ids, int64_t n, int K, int64_t* counts,
                                      int* bad_flag, void* stream) {
     QARIG_CHECK_ARG(ids && counts && bad_flag && n > 0 && K > 0, "index_histogram: bad arguments");
+    QARIG_CHECK_ARG(n <= (1LL << 40) && K <= (1 << 24), "index_histogram: extents too large");
     hipLaunchKernelGGL(histogram_kernel, cb_grid(n), dim3(256), 0, (hipStream_t)stream, ids, n, K,
                        (unsigned long long*)counts, bad_flag);
     QARIG_CHECK_LAUNCH("index_histogram");

@@ -167,6 +167,8 @@ extern "C" int qarig_rowmap_build(const int* idx, int M, int P, int* counts, int
                                   int* bad_flag, void* stream) {
     QARIG_CHECK_ARG(idx && counts && offsets && rows && bad_flag && M > 0 && P > 0,
                     "rowmap_build: bad arguments");
+    QARIG_CHECK_DIMS("rowmap_build", M);
+    QARIG_CHECK_DIMS("rowmap_build", P);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(rowmap_count_kernel, dim3(P), dim3(256), 0, st, idx, M, P, counts, bad_flag);
     QARIG_CHECK_LAUNCH("rowmap count");
@@ -183,6 +185,7 @@ extern "C" int qarig_segment_sum(const float* src, const int* offsets, const int
     QARIG_CHECK_ARG(src && offsets && rows && out && P > 0 && D > 0 && D % 4 == 0 &&
                         ((((uintptr_t)src | (uintptr_t)out)) & 15) == 0,
                     "segment_sum: bad arguments (D %% 4 == 0, 16-B aligned)");
+    QARIG_CHECK_DIMS("segment_sum", P, D);
     hipLaunchKernelGGL(segment_sum_kernel, dim3(P, (D + 511) / 512), dim3(512), 0,
                        (hipStream_t)stream, src, offsets, rows, D, out);
     QARIG_CHECK_LAUNCH("segment_sum");
@@ -196,6 +199,7 @@ extern "C" int qarig_mul_rows_fwd(const float* a, const float* tab, const int* i
     QARIG_CHECK_ARG(a && tab && idx && y && M > 0 && D > 0 && D % 4 == 0 &&
                         ((((uintptr_t)a | (uintptr_t)tab | (uintptr_t)y)) & 15) == 0,
                     "mul_rows_fwd: bad arguments (D %% 4 == 0, 16-B aligned)");
+    QARIG_CHECK_DIMS("mul_rows_fwd", M, D);
     hipLaunchKernelGGL(mul_rows_kernel, ct_grid((int64_t)M * (D / 4)), dim3(256), 0,
                        (hipStream_t)stream, a, tab, idx, y, M, D / 4);
     QARIG_CHECK_LAUNCH("mul_rows_fwd");
@@ -208,6 +212,7 @@ extern "C" int qarig_mul_rows_bwd(const float* dy, const float* a, const float* 
                         ((((uintptr_t)dy | (uintptr_t)a | (uintptr_t)tab | (uintptr_t)da |
                            (uintptr_t)db_tok)) & 15) == 0,
                     "mul_rows_bwd: bad arguments (D %% 4 == 0, 16-B aligned)");
+    QARIG_CHECK_DIMS("mul_rows_bwd", M, D);
     hipLaunchKernelGGL(mul_rows_bwd_kernel, ct_grid((int64_t)M * (D / 4)), dim3(256), 0,
                        (hipStream_t)stream, dy, a, tab, idx, da, db_tok, M, D / 4);
     QARIG_CHECK_LAUNCH("mul_rows_bwd");

@@ -650,7 +650,12 @@ extern "C" int qarig_conv2d_fwd(const float* x, int N, int Cin, int H, int W, co
                                 float* y, float* preact, void* stream) {
     QARIG_CHECK_ARG(x && w && y, "conv2d: null pointer");
     QARIG_CHECK_ARG(N > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv2d: bad extents");
-    QARIG_CHECK_ARG(k >= 1 && k <= 4 && stride >= 1 && pad >= 0, "conv2d: kernel size 1..4 only");
+    QARIG_CHECK_ARG(k >= 1 && k <= 4 && stride >= 1 && stride <= 4 && pad >= 0 && pad <= 4,
+                    "conv2d: kernel size 1..4, stride 1..4, padding 0..4 only");
+    QARIG_CHECK_ARG(qarig_dims_ok({N, Cin, H, W}, 1LL << 20, 1LL << 31), "conv2d: extents too large");
+    QARIG_CHECK_ARG(qarig_dims_ok({N, Cout, H, W}, 1LL << 20, 1LL << 31), "conv2d: extents too large");
+    QARIG_CHECK_ARG(qarig_dims_ok({Cin, Cout}, 1LL << 20, 1LL << 31), "conv2d: extents too large");
+
     QARIG_CHECK_ARG(act >= 0 && act <= 3, "conv2d: bad activation id");
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     QARIG_CHECK_ARG(Ho > 0 && Wo > 0, "conv2d: empty output");
@@ -663,6 +668,7 @@ extern "C" int qarig_conv2d_fwd(const float* x, int N, int Cin, int H, int W, co
 }
 
 extern "C" size_t qarig_conv_transpose2d_workspace_bytes(int Cin, int Cout) {
+    if (Cin < 1 || Cout < 1 || Cin > (1 << 20) || Cout > (1 << 20)) return 0;
     return (size_t)16 * Cin * Cout * sizeof(float);
 }
 
@@ -674,6 +680,10 @@ extern "C" int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H,
                                           size_t ws_bytes, void* stream) {
     QARIG_CHECK_ARG(x && w && y, "conv_transpose2d: null pointer");
     QARIG_CHECK_ARG(N > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv_transpose2d: bad extents");
+    QARIG_CHECK_ARG(qarig_dims_ok({N, Cin, H, W, 4}, 1LL << 20, 1LL << 31), "conv_transpose2d: extents too large");
+    QARIG_CHECK_ARG(qarig_dims_ok({N, Cout, H, W, 4}, 1LL << 20, 1LL << 31), "conv_transpose2d: extents too large");
+    QARIG_CHECK_ARG(qarig_dims_ok({Cin, Cout, 16}, 1LL << 20, 1LL << 31), "conv_transpose2d: extents too large");
+
     QARIG_CHECK_ARG(act >= 0 && act <= 3, "conv_transpose2d: bad activation id");
     if (!workspace || ws_bytes < qarig_conv_transpose2d_workspace_bytes(Cin, Cout)) {
         qarig_set_error("conv_transpose2d: workspace too small");
@@ -699,6 +709,7 @@ extern "C" int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H,
 // ------------------------------------------------------------------ backward entry points
 
 extern "C" size_t qarig_conv2d_bwd_data_workspace_bytes(int Cin, int Cout, int k) {
+    if (Cin < 1 || Cout < 1 || k < 1 || k > 4 || Cin > (1 << 20) || Cout > (1 << 20)) return 0;
     return (size_t)Cin * Cout * k * k * sizeof(float);
 }
 
@@ -711,6 +722,10 @@ extern "C" int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, i
     QARIG_CHECK_ARG(dT && w && dx, "conv2d_bwd_data: null pointer");
     QARIG_CHECK_ARG(k >= 1 && k <= 4 && stride >= 1 && stride <= 2 && pad >= 0 && pad < k,
                     "conv2d_bwd_data: unsupported geometry");
+    QARIG_CHECK_ARG(qarig_dims_ok({N, Cout, Ho, Wo}, 1LL << 20, 1LL << 31), "conv2d_bwd_data: extents too large");
+    QARIG_CHECK_ARG(qarig_dims_ok({N, Cin, H, W}, 1LL << 20, 1LL << 31), "conv2d_bwd_data: extents too large");
+    QARIG_CHECK_ARG(qarig_dims_ok({Cin, Cout, 16}, 1LL << 20, 1LL << 31), "conv2d_bwd_data: extents too large");
+
     if (!workspace || ws_bytes < qarig_conv2d_bwd_data_workspace_bytes(Cin, Cout, k)) {
         qarig_set_error("conv2d_bwd_data: workspace too small");
         return QARIG_ERR_WORKSPACE;
@@ -746,6 +761,10 @@ extern "C" int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, i
 extern "C" int qarig_conv_transpose2d_bwd_data(const float* dT, int N, int Cout, int H, int W,
                                                const float* w, int Cin, float* dx, void* stream) {
     QARIG_CHECK_ARG(dT && w && dx, "conv_transpose2d_bwd_data: null pointer");
+    QARIG_CHECK_ARG(qarig_dims_ok({N, Cout, H, W, 4}, 1LL << 20, 1LL << 31), "conv_transpose2d_bwd_data: extents too large");
+    QARIG_CHECK_ARG(qarig_dims_ok({N, Cin, H, W}, 1LL << 20, 1LL << 31), "conv_transpose2d_bwd_data: extents too large");
+    QARIG_CHECK_ARG(qarig_dims_ok({Cin, Cout, 16}, 1LL << 20, 1LL << 31), "conv_transpose2d_bwd_data: extents too large");
+
     ConvGeom g{dT, N, Cout, 2 * H, 2 * W, H, W, 2, 4, 4, -1, 1, -1, 1, Cout * 16, N * H * W};
     ConvOut o{dx, nullptr, nullptr, Cin, H, W, 1, 0, 0, ACT_NONE};
     return launch_conv(w, g, o, (hipStream_t)stream);
@@ -844,6 +863,7 @@ static int wgrad_splits(int Cg, int K2, int P) {
 }
 
 extern "C" size_t qarig_conv_wgrad_workspace_bytes(int Cg, int K2, int P) {
+    if (!qarig_dims_ok({Cg, K2}, 1LL << 24, 1LL << 34) || P < 1 || P > (1 << 30)) return 0;
     const int s = wgrad_splits(Cg, K2, P);
     return (size_t)(Cg <= 4 && s < 64 ? 64 : s) * Cg * K2 * sizeof(float);   // direct path: <= 64 slabs
 }
@@ -856,6 +876,11 @@ extern "C" int qarig_conv_wgrad(const float* G, int N, int Cg, int Gh, int Gw, c
                                 void* workspace, size_t ws_bytes, void* stream) {
     QARIG_CHECK_ARG(G && X && dw, "conv_wgrad: null pointer");
     QARIG_CHECK_ARG(N > 0 && Cg > 0 && Cx > 0 && k >= 1 && k <= 4, "conv_wgrad: bad extents");
+    QARIG_CHECK_ARG(stride >= 1 && stride <= 2 && pad >= 0 && pad <= 4, "conv_wgrad: unsupported geometry");
+    QARIG_CHECK_ARG(qarig_dims_ok({N, Cg, Gh, Gw}, 1LL << 20, 1LL << 31), "conv_wgrad: extents too large");
+    QARIG_CHECK_ARG(qarig_dims_ok({N, Cx, H, W}, 1LL << 20, 1LL << 31), "conv_wgrad: extents too large");
+    QARIG_CHECK_ARG(qarig_dims_ok({Cg, Cx, 16}, 1LL << 20, 1LL << 31), "conv_wgrad: extents too large");
+
     QARIG_CHECK_ARG((int64_t)N * Gh * Gw < INT32_MAX, "conv_wgrad: too many pixels");
     WgradGeom g{G, Cg, Gh, Gw, X, Cx, H, W, N, k, stride, pad, N * Gh * Gw, Cx * k * k};
     if (!workspace || ws_bytes < qarig_conv_wgrad_workspace_bytes(Cg, g.K2, g.P)) {
@@ -897,6 +922,8 @@ extern "C" int qarig_conv_wgrad(const float* G, int N, int Cg, int Gh, int Gw, c
 // db[c] = sum_{n,y,x} G[n][c][y][x]  (bias gradient of both conv kinds).
 extern "C" int qarig_conv_bias_grad(const float* G, int N, int C, int HW, float* db, void* stream) {
     QARIG_CHECK_ARG(G && db && N > 0 && C > 0 && HW > 0, "conv_bias_grad: bad arguments");
+    QARIG_CHECK_ARG(qarig_dims_ok({N, C, HW}, 1LL << 20, 1LL << 31), "conv_bias_grad: extents too large");
+
     hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, G, N, C, HW,
                        db);
     QARIG_CHECK_LAUNCH("conv_bias_grad");

@@ -56,7 +56,7 @@ static dim3 ew_grid(int64_t n) {
 }
 
 extern "C" int qarig_mul_fwd(const float* a, const float* b, float* y, int64_t n, void* stream) {
-    QARIG_CHECK_ARG(a && b && y && n > 0, "mul_fwd: bad arguments");
+    QARIG_CHECK_ARG(a && b && y && n > 0 && n <= (1LL << 40), "mul_fwd: bad arguments");
     hipLaunchKernelGGL(mul_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
     QARIG_CHECK_LAUNCH("mul_fwd");
     return QARIG_OK;
@@ -64,7 +64,7 @@ extern "C" int qarig_mul_fwd(const float* a, const float* b, float* y, int64_t n
 
 extern "C" int qarig_mul_bwd(const float* dy, const float* a, const float* b, float* da, float* db,
                              int64_t n, void* stream) {
-    QARIG_CHECK_ARG(dy && a && b && da && db && n > 0, "mul_bwd: bad arguments");
+    QARIG_CHECK_ARG(dy && a && b && da && db && n > 0 && n <= (1LL << 40), "mul_bwd: bad arguments");
     hipLaunchKernelGGL(mul_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, dy, a, b, da,
                        db, n);
     QARIG_CHECK_LAUNCH("mul_bwd");
@@ -72,7 +72,7 @@ extern "C" int qarig_mul_bwd(const float* dy, const float* a, const float* b, fl
 }
 
 extern "C" int qarig_act_fwd(const float* x, float* y, int64_t n, int act, void* stream) {
-    QARIG_CHECK_ARG(x && y && n > 0 && act >= 0 && act <= 3, "act_fwd: bad arguments");
+    QARIG_CHECK_ARG(x && y && n > 0 && n <= (1LL << 40) && act >= 0 && act <= 3, "act_fwd: bad arguments");
     hipLaunchKernelGGL(act_fwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, x, y, n, act);
     QARIG_CHECK_LAUNCH("act_fwd");
     return QARIG_OK;
@@ -81,7 +81,7 @@ extern "C" int qarig_act_fwd(const float* x, float* y, int64_t n, int act, void*
 // dz = dy * act'(z), z the pre-activation.
 extern "C" int qarig_act_bwd(const float* dy, const float* z, float* dz, int64_t n, int act,
                              void* stream) {
-    QARIG_CHECK_ARG(dy && z && dz && n > 0 && act >= 0 && act <= 3, "act_bwd: bad arguments");
+    QARIG_CHECK_ARG(dy && z && dz && n > 0 && n <= (1LL << 40) && act >= 0 && act <= 3, "act_bwd: bad arguments");
     hipLaunchKernelGGL(act_bwd_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, dy, z, dz, n,
                        act);
     QARIG_CHECK_LAUNCH("act_bwd");
@@ -90,7 +90,7 @@ extern "C" int qarig_act_bwd(const float* dy, const float* z, float* dz, int64_t
 
 // y = x * s[0], s a device scalar (upstream gradient of a scalar loss).
 extern "C" int qarig_scale_by(const float* x, const float* s, float* y, int64_t n, void* stream) {
-    QARIG_CHECK_ARG(x && s && y && n > 0, "scale_by: bad arguments");
+    QARIG_CHECK_ARG(x && s && y && n > 0 && n <= (1LL << 40), "scale_by: bad arguments");
     hipLaunchKernelGGL(scale_by_kernel, ew_grid(n), dim3(256), 0, (hipStream_t)stream, x, s, y, n);
     QARIG_CHECK_LAUNCH("scale_by");
     return QARIG_OK;

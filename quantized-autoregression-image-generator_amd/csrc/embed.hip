@@ -78,6 +78,7 @@ static int ew_blocks(int64_t total) {
 extern "C" int qarig_posemb_fwd(const float* pos, int R, int D, const float* freq, float* out,
                                 void* stream) {
     QARIG_CHECK_ARG(pos && freq && out && R > 0 && D > 0 && (D % 2) == 0, "posemb: bad arguments");
+    QARIG_CHECK_DIMS("posemb", R, D);
     hipLaunchKernelGGL(posemb_kernel, dim3(ew_blocks((int64_t)R * D)), dim3(256), 0,
                        (hipStream_t)stream, pos, R, D, freq, out);
     QARIG_CHECK_LAUNCH("posemb");
@@ -92,6 +93,9 @@ extern "C" int qarig_embedding_fwd(const int64_t* ids, int M, int S, int D, int 
                                    void* stream) {
     QARIG_CHECK_ARG(ids && table && out && bad_flag && M > 0 && S > 0 && D > 0 && V > 0,
                     "embedding_fwd: bad arguments");
+    QARIG_CHECK_DIMS("embedding_fwd", M, D);
+    QARIG_CHECK_DIMS("embedding_fwd", V, D);
+    QARIG_CHECK_ARG(S <= (1 << 24), "embedding_fwd: bad arguments");
     hipLaunchKernelGGL(embedding_fwd_kernel, dim3(ew_blocks((int64_t)M * D)), dim3(256), 0,
                        (hipStream_t)stream, ids, M, S, D, V, table, pe, out, bad_flag);
     QARIG_CHECK_LAUNCH("embedding_fwd");
@@ -101,6 +105,8 @@ extern "C" int qarig_embedding_fwd(const int64_t* ids, int M, int S, int D, int 
 extern "C" int qarig_embedding_bwd(const int64_t* ids, int M, int D, int V, const float* dy,
                                    float* dtable, void* stream) {
     QARIG_CHECK_ARG(ids && dy && dtable && M > 0 && D > 0 && V > 0, "embedding_bwd: bad arguments");
+    QARIG_CHECK_DIMS("embedding_bwd", M, D);
+    QARIG_CHECK_DIMS("embedding_bwd", V, D);
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, M, D,
                        dy, dtable);
     QARIG_CHECK_LAUNCH("embedding_bwd");

@@ -121,7 +121,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpi
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* glb_ptr_t;
 
-constexpr int DMA_STAGES = 2;
 constexpr int DMA_OP_FLOATS = 128 * BK;              // 8 KB per operand per stage
 constexpr int DMA_STAGE_FLOATS = 2 * DMA_OP_FLOATS;  // A then B
 
@@ -171,14 +170,17 @@ __device__ __forceinline__ void frag_read(const float* tile, int x, int h, f32x4
     }
 }
 
-template <bool AKC, bool BKC>
+// STAGES = 2: tile t+1 is requested while tile t is multiplied (one k-tile of latency cover);
+// STAGES = 3: two tiles in flight, the wait before the barrier is a counted vmcnt(4) that leaves
+// the younger one outstanding (48 KB of LDS: three workgroups per CU).
+template <bool AKC, bool BKC, int STAGES>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const float* __restrict__ A,
                                                                int64_t lda,
                                                                const float* __restrict__ B,
                                                                int64_t ldb, GemmEpilogue ep, int M,
                                                                int N, int K, int tiles_n, int splitk,
                                                                float* slabs, int stagger) {
-    __shared__ __attribute__((aligned(16))) float lds[DMA_STAGES * DMA_STAGE_FLOATS];   // 32 KB
+    __shared__ __attribute__((aligned(16))) float lds[STAGES * DMA_STAGE_FLOATS];   // 32 / 48 KB
     stagger_first_round(stagger);
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
@@ -201,17 +203,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const float* __re
     float rs = 0.0f;
     const bool do_rs = !AKC && ep.rowsum != nullptr && tn == 0 && tid < 128;
     if (nk > 0) {
-        dma_tile<AKC>(A, lda, m0, k_begin, lds, wave, lane);
-        dma_tile<BKC>(B, ldb, n0, k_begin, lds + DMA_OP_FLOATS, wave, lane);
+#pragma unroll
+        for (int p = 0; p < STAGES - 1; ++p) {          // tiles 0 .. STAGES-2 (tail: harmless re-load)
+            const int kp = min(k_begin + p * BK, last);
+            dma_tile<AKC>(A, lda, m0, kp, lds + p * DMA_STAGE_FLOATS, wave, lane);
+            dma_tile<BKC>(B, ldb, n0, kp, lds + p * DMA_STAGE_FLOATS + DMA_OP_FLOATS, wave, lane);
+        }
         int st = 0;                       // stage of tile kt
         for (int kt = 0; kt < nk; ++kt) {
-            // this wave's DMAs of tile kt have landed, then (barrier) everybody's; the same
-            // barrier retires all reads of tile kt-1, whose stage is refilled right after it
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // this wave's DMAs of tile kt have landed (the STAGES-2 younger tiles stay in flight),
+            // then (barrier) everybody's; the same barrier retires all reads of tile kt-1, whose
+            // stage is refilled right after it
+            if (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            const int kn = min(k_begin + (kt + 1) * BK, last);        // tail: harmless re-load
-            dma_tile<AKC>(A, lda, m0, kn, lds + (st ^ 1) * DMA_STAGE_FLOATS, wave, lane);
-            dma_tile<BKC>(B, ldb, n0, kn, lds + (st ^ 1) * DMA_STAGE_FLOATS + DMA_OP_FLOATS, wave, lane);
+            const int kn = min(k_begin + (kt + STAGES - 1) * BK, last);        // tail: harmless re-load
+            const int sn = st == 0 ? STAGES - 1 : st - 1;                      // stage of tile kt-1
+            dma_tile<AKC>(A, lda, m0, kn, lds + sn * DMA_STAGE_FLOATS, wave, lane);
+            dma_tile<BKC>(B, ldb, n0, kn, lds + sn * DMA_STAGE_FLOATS + DMA_OP_FLOATS, wave, lane);
             const float* ta = lds + st * DMA_STAGE_FLOATS;
             const float* tb = ta + DMA_OP_FLOATS;
             f32x4 a0l, a0h, a1l, a1h, b0l, b0h, b1l, b1h;
@@ -247,128 +256,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const float* __re
                 acc.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc.t[1][0], 0, 0, 0);
                 acc.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc.t[1][1], 0, 0, 0);
             }
-            st ^= 1;
+            st = st + 1 == STAGES ? 0 : st + 1;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (do_rs) ep.rowsum[(int64_t)blockIdx.z * M + m0 + tid] = rs;
     __syncthreads();                      // ring no longer in use: the epilogue stages through it
-    gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, slabs);
-}
-
-// ---------------------------------------------------------------------------------
-// Interior GEMM, operands straight from global memory to the MFMA registers: no LDS, no
-// barrier in the k-loop.  The fp32 MFMA consumes ONE dword of each operand per lane per
-// 64-cycle instruction, so operand bandwidth is tiny (a wave's 64x64 tile needs 8 KB per
-// 16-deep k-tile = per 2048 MFMA cycles); what the LDS-staged kernels lose is not bandwidth
-// but the per-k-tile barrier + DMA wait + fragment-read latency that four waves pay in
-// lockstep (counters: MFMA pipe busy 0.71-0.76 of the kernel's cycles, wave time in
-// s_waitcnt/s_barrier 19 %, profiles/r02a_sq_by_kernel.csv).  Here every wave streams its own
-// fragments -- row-major operands as two 16-B loads per 32-row tile (lane half h owns
-// k = 8h..8h+7: MFMA step s contracts k = {s, 8+s}, the order of gemm_dma_kernel),
-// reduction-major operands as one coalesced dword per k -- one k-tile ahead of the MFMAs that
-// use them (register double buffer, counted vmcnt by the compiler), and waves never wait for
-// each other until the epilogue.  The two waves that share an operand panel hit the CU's L1.
-// ---------------------------------------------------------------------------------
-struct Frag {            // one k-tile (16 deep) of a wave's 64 rows/columns of one operand
-    float v[2][8];       // [32-wide tile][k = 8h + s]
-};
-
-template <bool KC>
-__device__ __forceinline__ void frag_load(Frag& f, const float* __restrict__ P, int64_t ld, int x0,
-                                          int k0, int lane) {
-    const int x = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (KC) {
-            const float4* q = reinterpret_cast<const float4*>(P + (int64_t)(x0 + 32 * t + x) * ld + k0 + 8 * h);
-            const float4 a = q[0], b = q[1];
-            f.v[t][0] = a.x; f.v[t][1] = a.y; f.v[t][2] = a.z; f.v[t][3] = a.w;
-            f.v[t][4] = b.x; f.v[t][5] = b.y; f.v[t][6] = b.z; f.v[t][7] = b.w;
-        } else {
-            const float* q = P + (int64_t)(k0 + 8 * h) * ld + x0 + 32 * t + x;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) f.v[t][s] = q[(int64_t)s * ld];
-        }
-    }
-}
-
-__device__ __forceinline__ void frag_mma(Acc& acc, const Frag& a, const Frag& b) {
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        acc.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[0][s], b.v[0][s], acc.t[0][0], 0, 0, 0);
-        acc.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[0][s], b.v[1][s], acc.t[0][1], 0, 0, 0);
-        acc.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[1][s], b.v[0][s], acc.t[1][0], 0, 0, 0);
-        acc.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[1][s], b.v[1][s], acc.t[1][1], 0, 0, 0);
-    }
-}
-
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_direct_kernel(const float* __restrict__ A, int64_t lda,
-                                                                  const float* __restrict__ B, int64_t ldb,
-                                                                  GemmEpilogue ep, int M, int N, int K,
-                                                                  int tiles_n, int splitk, float* slabs) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * 32 * 64];   // epilogue staging only (32 KB)
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    int k_begin = 0, k_end = K;
-    if (splitk > 1) {
-        const int per = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
-        k_begin = blockIdx.z * per;
-        k_end = min(K, k_begin + per);
-    }
-    const int nk = (k_end - k_begin) / BK;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int am = m0 + wm * 64, bn = n0 + wn * 64;
-
-    Acc acc;
-    acc_zero(acc);
-    // bias gradient riding on the dW GEMM (A = dT^T stored [k][m]): partial row sums of this
-    // wave's A fragments; the wn == 0 waves of the tn == 0 tiles own them
-    const bool do_rs = !AKC && ep.rowsum != nullptr && tn == 0 && wn == 0;
-    float rs0 = 0.0f, rs1 = 0.0f;
-    Frag a0, b0, a1, b1;
-    if (nk > 0) {
-        frag_load<AKC>(a0, A, lda, am, k_begin, lane);
-        frag_load<BKC>(b0, B, ldb, bn, k_begin, lane);
-        int kt = 0;
-        for (; kt + 2 <= nk; kt += 2) {
-            const int k1 = k_begin + (kt + 1) * BK;
-            frag_load<AKC>(a1, A, lda, am, k1, lane);
-            frag_load<BKC>(b1, B, ldb, bn, k1, lane);
-            if (do_rs) {
-#pragma unroll
-                for (int s = 0; s < 8; ++s) { rs0 += a0.v[0][s]; rs1 += a0.v[1][s]; }
-            }
-            frag_mma(acc, a0, b0);
-            const int k2 = min(k_begin + (kt + 2) * BK, k_end - BK);     // tail: harmless re-load
-            frag_load<AKC>(a0, A, lda, am, k2, lane);
-            frag_load<BKC>(b0, B, ldb, bn, k2, lane);
-            if (do_rs) {
-#pragma unroll
-                for (int s = 0; s < 8; ++s) { rs0 += a1.v[0][s]; rs1 += a1.v[1][s]; }
-            }
-            frag_mma(acc, a1, b1);
-        }
-        if (kt < nk) {
-            if (do_rs) {
-#pragma unroll
-                for (int s = 0; s < 8; ++s) { rs0 += a0.v[0][s]; rs1 += a0.v[1][s]; }
-            }
-            frag_mma(acc, a0, b0);
-        }
-    }
-    if (do_rs) {      // halves h = 0, 1 hold k = 0..7 / 8..15 of every tile: add them, lane x writes
-        rs0 += __shfl_xor(rs0, 32, 64);
-        rs1 += __shfl_xor(rs1, 32, 64);
-        if (lane < 32) {
-            ep.rowsum[(int64_t)blockIdx.z * M + am + lane] = rs0;
-            ep.rowsum[(int64_t)blockIdx.z * M + am + 32 + lane] = rs1;
-        }
-    }
     gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, slabs);
 }
 
@@ -525,6 +418,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(const float* __restri
 using namespace qarig;
 
 extern "C" size_t qarig_gemm_workspace_bytes(int M, int N, int splitk) {
+    if (M < 1 || N < 1 || splitk > (1 << 16)) return 0;
     // split-K slabs + (always) room for the per-split A row sums
     const size_t sk = splitk > 1 ? splitk : 1;
     return (splitk > 1 ? sk * M * N * sizeof(float) : 0) + sk * M * sizeof(float);
@@ -554,6 +448,10 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
                          void* workspace, size_t ws_bytes, void* stream) {
     QARIG_CHECK_ARG(A && B && C, "gemm: null operand");
     QARIG_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad extents M=%d N=%d K=%d", M, N, K);
+    QARIG_CHECK_DIMS("gemm", M, N);
+    QARIG_CHECK_DIMS("gemm", M, K);
+    QARIG_CHECK_DIMS("gemm", N, K);
+    QARIG_CHECK_ARG(splitk <= 4096, "gemm: splitk %d too large", splitk);
     QARIG_CHECK_ARG(act >= 0 && act <= 3 && gact >= 0 && gact <= 3, "gemm: bad activation id");
     if (splitk < 1) splitk = 1;
     if (accumulate) {
@@ -605,31 +503,25 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     const char* stagger_e = getenv("QARIG_GEMM_STAGGER");
     const int stagger_env = stagger_e ? atoi(stagger_e) : -1;
     const int stagger = (long)grid.x * grid.z >= 1024 ? (stagger_env >= 0 ? stagger_env : 2) : 0;
-    const char* direct_e = getenv("QARIG_GEMM_DIRECT");
-    const bool direct = direct_e && direct_e[0] == '1';
-    if (direct && fast && vec_epi && !(a_rowsum && a_kcontig)) {
-        if (a_kcontig && b_kcontig)
-            hipLaunchKernelGGL((gemm_direct_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
-                               N, K, tiles_n, splitk, slabs);
-        else if (a_kcontig)
-            hipLaunchKernelGGL((gemm_direct_kernel<true, false>), grid, block, 0, st, A, lda, B, ldb, ep, M,
-                               N, K, tiles_n, splitk, slabs);
-        else if (b_kcontig)
-            hipLaunchKernelGGL((gemm_direct_kernel<false, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
-                               N, K, tiles_n, splitk, slabs);
-        else
-            hipLaunchKernelGGL((gemm_direct_kernel<false, false>), grid, block, 0, st, A, lda, B, ldb, ep,
-                               M, N, K, tiles_n, splitk, slabs);
-    } else if (dma_on && dma_shape && fast && vec_epi && !(a_rowsum && a_kcontig) &&
+    // ring depth: 3 stages where the grid leaves at most three workgroups per CU anyway (the
+    // split-K weight gradients and the N = 512 outputs: 512 workgroups); QARIG_GEMM_STAGES overrides
+    const char* stages_e = getenv("QARIG_GEMM_STAGES");
+    const int stages = stages_e ? atoi(stages_e) : ((long)grid.x * grid.z <= 768 ? 3 : 2);
+#define QARIG_LAUNCH_DMA(AK, BK_, ...)                                                        \
+    do {                                                                                      \
+        if (stages == 3) hipLaunchKernelGGL((gemm_dma_kernel<AK, BK_, 3>), __VA_ARGS__);      \
+        else hipLaunchKernelGGL((gemm_dma_kernel<AK, BK_, 2>), __VA_ARGS__);                  \
+    } while (0)
+    if (dma_on && dma_shape && fast && vec_epi && !(a_rowsum && a_kcontig) &&
         !(!a_kcontig && b_kcontig)) {
         if (a_kcontig && b_kcontig)
-            hipLaunchKernelGGL((gemm_dma_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
+            QARIG_LAUNCH_DMA(true, true, grid, block, 0, st, A, lda, B, ldb, ep, M,
                                N, K, tiles_n, splitk, slabs, stagger);
         else if (a_kcontig)
-            hipLaunchKernelGGL((gemm_dma_kernel<true, false>), grid, block, 0, st, A, lda, B, ldb, ep, M,
+            QARIG_LAUNCH_DMA(true, false, grid, block, 0, st, A, lda, B, ldb, ep, M,
                                N, K, tiles_n, splitk, slabs, stagger);
         else
-            hipLaunchKernelGGL((gemm_dma_kernel<false, false>), grid, block, 0, st, A, lda, B, ldb, ep,
+            QARIG_LAUNCH_DMA(false, false, grid, block, 0, st, A, lda, B, ldb, ep,
                                M, N, K, tiles_n, splitk, slabs, stagger);
     } else {
 #define QARIG_LAUNCH_GEMM(TA, TB)                                                              \
@@ -683,6 +575,7 @@ extern "C" int qarig_slab_reduce_f32(const float* slabs, float* out, int64_t ldc
 }
 
 extern "C" size_t qarig_colsum_workspace_bytes(int M, int N) {
+    if (M < 1 || N < 1 || M > (1 << 30)) return 0;
     const int chunks = (M + COLSUM_ROWS - 1) / COLSUM_ROWS;
     return (size_t)chunks * N * sizeof(float);
 }
@@ -691,6 +584,7 @@ extern "C" size_t qarig_colsum_workspace_bytes(int M, int N) {
 extern "C" int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out,
                                 int accumulate, void* workspace, size_t ws_bytes, void* stream) {
     QARIG_CHECK_ARG(X && out && M > 0 && N > 0, "colsum: bad arguments");
+    QARIG_CHECK_DIMS("colsum", M, N);
     if (!workspace || ws_bytes < qarig_colsum_workspace_bytes(M, N)) {
         qarig_set_error("colsum: workspace too small");
         return QARIG_ERR_WORKSPACE;

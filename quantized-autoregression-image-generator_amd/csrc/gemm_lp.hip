@@ -201,7 +201,7 @@ extern "C" int qarig_slab_reduce_f32(const float* slabs, float* out, int64_t ldc
 // fp32 -> bf16 (round to nearest even) of n contiguous elements; dst holds n 16-bit values.
 // New entry (no reference counterpart): the operand conversion of the reduced-precision mode.
 extern "C" int qarig_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
-    QARIG_CHECK_ARG(src && dst && n > 0, "cast_bf16: bad arguments");
+    QARIG_CHECK_ARG(src && dst && n > 0 && n <= (1LL << 40), "cast_bf16: bad arguments");
     QARIG_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "cast_bf16: 16-B aligned buffers");
     const int64_t n8 = n / 8;
     if (n8 > 0) {
@@ -221,6 +221,7 @@ extern "C" int qarig_cast_bf16(const float* src, void* dst, int64_t n, void* str
 extern "C" int qarig_cast_transpose_bf16(const float* src, int64_t ld, int R, int C, void* dst,
                                          void* stream) {
     QARIG_CHECK_ARG(src && dst && R > 0 && C > 0 && ld >= C, "cast_transpose_bf16: bad arguments");
+    QARIG_CHECK_DIMS("cast_transpose_bf16", R, C);
     QARIG_CHECK_ARG(((uintptr_t)dst & 3) == 0, "cast_transpose_bf16: 4-B aligned destination");
     hipLaunchKernelGGL(cast_transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0,
                        (hipStream_t)stream, src, ld, R, C, (bf16_t*)dst);
@@ -229,12 +230,14 @@ extern "C" int qarig_cast_transpose_bf16(const float* src, int64_t ld, int R, in
 }
 
 extern "C" size_t qarig_gemm_lp_workspace_bytes(int M, int N, int splitk) {
+    if (M < 1 || N < 1 || splitk > (1 << 16)) return 0;
     return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0;
 }
 
 // 1 when the shape can run on the reduced-precision kernel (else the caller uses qarig_gemm_f32).
 extern "C" int qarig_gemm_lp_supported(int M, int N, int K, int splitk) {
     if (splitk < 1) splitk = 1;
+    if (!qarig_dims_ok({M, N}) || !qarig_dims_ok({M, K}) || !qarig_dims_ok({N, K}) || splitk > 4096) return 0;
     return M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % splitk == 0 &&
            (K / splitk) % LBK == 0;
 }

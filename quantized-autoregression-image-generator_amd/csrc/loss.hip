@@ -85,7 +85,7 @@ extern "C" size_t qarig_mse_workspace_bytes(void) { return MSE_BLOCKS * sizeof(f
 // dpred (n floats or NULL).  part_ws: qarig_mse_workspace_bytes().
 extern "C" int qarig_mse_fwd(const float* pred, const float* target, int64_t n, float* loss,
                              float* dpred, float* part_ws, void* stream) {
-    QARIG_CHECK_ARG(pred && target && loss && part_ws && n > 0, "mse: bad arguments");
+    QARIG_CHECK_ARG(pred && target && loss && part_ws && n > 0 && n <= (1LL << 40), "mse: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const float inv_n = 1.0f / (float)n;
     hipLaunchKernelGGL(mse_partial_kernel, dim3(MSE_BLOCKS), dim3(256), 0, st, pred, target, n,
@@ -104,6 +104,7 @@ extern "C" int qarig_cross_entropy_fwd(const float* logits, const int64_t* targe
                                        void* stream) {
     QARIG_CHECK_ARG(logits && target && loss && row_ws && bad_flag && M > 0 && C > 0,
                     "cross_entropy: bad arguments");
+    QARIG_CHECK_DIMS("cross_entropy", M, C);
     hipStream_t st = (hipStream_t)stream;
     const float inv_m = 1.0f / (float)M;
     hipLaunchKernelGGL(ce_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, logits, target, M, C,

@@ -164,6 +164,7 @@ extern "C" int qarig_layernorm_fwd(const float* x, int M, int D, float eps, cons
                                    void* stream) {
     QARIG_CHECK_ARG(!mod_idx || scale, "layernorm_fwd: mod_idx needs scale/shift tables");
     QARIG_CHECK_ARG(x && y && mean && rstd && M > 0 && D > 0, "layernorm_fwd: bad arguments");
+    QARIG_CHECK_DIMS("layernorm_fwd", M, D);
     QARIG_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "layernorm_fwd: gamma/beta pair");
     QARIG_CHECK_ARG((scale == nullptr) == (shift == nullptr), "layernorm_fwd: scale/shift pair");
     QARIG_CHECK_ARG(!(gamma && scale), "layernorm_fwd: affine and AdaLN forms are exclusive");
@@ -191,6 +192,7 @@ extern "C" int qarig_layernorm_bwd(const float* dy, const float* x, const float*
                                    const int* mod_idx, int M, int D, float* dx, float* dy_xhat,
                                    void* stream) {
     QARIG_CHECK_ARG(dy && x && mean && rstd && dx && M > 0 && D > 0, "layernorm_bwd: bad arguments");
+    QARIG_CHECK_DIMS("layernorm_bwd", M, D);
     QARIG_CHECK_ARG(!(gamma && scale), "layernorm_bwd: affine and AdaLN forms are exclusive");
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     const bool vec = D % 256 == 0 && al16(dy) && al16(x) && al16(gamma) && al16(scale) && al16(dx) &&

@@ -43,7 +43,7 @@ using namespace qarig;
 extern "C" int qarig_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
                                float beta2, float eps, float step_size, float bc2_sqrt,
                                float grad_scale, const float* dev_step, void* stream) {
-    QARIG_CHECK_ARG(p && g && m && v && n > 0, "adam: bad arguments");
+    QARIG_CHECK_ARG(p && g && m && v && n > 0 && n <= (1LL << 40), "adam: bad arguments");
     int64_t b = (n + 255) / 256;
     if (b > 8192) b = 8192;
     hipLaunchKernelGGL(adam_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,

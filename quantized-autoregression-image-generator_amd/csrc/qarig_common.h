@@ -34,6 +34,25 @@ extern "C" void qarig_set_error(const char* fmt, ...);
         }                                                                     \
     } while (0)
 
+// Extents an entry point accepts: every one positive and at most `max_each`, their product at
+// most `max_prod` -- after this check the host-side index / grid / byte arithmetic derived from
+// them cannot overflow (tests/test_sanitizers.py drives every entry point under UBSan with
+// INT_MAX-sized arguments).
+#include <initializer_list>
+static inline bool qarig_dims_ok(std::initializer_list<long long> dims, long long max_each = 1LL << 24,
+                                 long long max_prod = 1LL << 40) {
+    long long p = 1;
+    for (long long d : dims) {
+        if (d < 1 || d > max_each) return false;
+        if (p > max_prod / d) return false;
+        p *= d;
+    }
+    return true;
+}
+#define QARIG_CHECK_DIMS(what, ...)                                                             \
+    QARIG_CHECK_ARG(qarig_dims_ok({__VA_ARGS__}),                                               \
+                    what ": extents must be positive, at most 2^24 each, product at most 2^40")
+
 namespace qarig {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -309,8 +309,13 @@ def pick_splitk(M, N, K):
         while s > 1 and (K % s or (K // s) % 16 or s * tiles > 512):
             s -= 1
         return max(1, s)
-    s = min(max(1, 512 // tiles), K // 512)
-    return max(1, min(s, 32))
+    s = max(1, min(max(1, 512 // tiles), K // 512, 32))
+    # slices that divide K into whole 16-deep tiles keep the launch on the interior kernels
+    # (the padded classifier's 640 x 2048 output over K = 16384 asked for 6: 2736-deep slices
+    # sent it to the guarded kernel at half the rate)
+    while s > 1 and (K % s or (K // s) % 16):
+        s -= 1
+    return s
 
 
 # ------------------------------------------------------------ shared small helpers
