@@ -294,8 +294,7 @@ def main():
         rand = parallel.shard(torch.randint(0, nwin, (N * world,), generator=rng))
         if graphed is not None:
             return graphed(z, rand)
-        hr_in, lr_in, hr_tg = pipeline.tokenize(z, lr_cb, hr_cb, train_base_model=cfg["base"])
-        hr_in, hr_tg, pos = pipeline.slide(hr_in, hr_tg, cfg["window"], rand)
+        hr_in, lr_in, hr_tg, pos = pipeline.tokenize_window(z, lr_cb, hr_cb, cfg["base"], cfg["window"], rand)
         return pipeline.train_step(model, optim, hr_in, lr_in, hr_tg, pos, pos_bound=seq)
 
     def fence():

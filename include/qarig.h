@@ -86,15 +86,21 @@ int qarig_gemm_lp_supported(int M, int N, int K, int splitk);
 size_t qarig_gemm_lp_workspace_bytes(int M, int N, int splitk);
 int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t ldb, int layout, float* C,
                   int64_t ldc, int M, int N, int K, const float* bias, const float* residual,
-                  int64_t ldr, float* preact, int64_t ldp, int act, const float* gradz, int64_t ldz,
-                  int gact, int splitk, int accumulate, void* Cb, int64_t ldcb, void* Pb,
-                  int64_t ldpb, void* workspace, size_t ws_bytes, void* stream);
+                  int64_t ldr, float* preact, int64_t ldp, int act, const void* gradz, int64_t ldz,
+                  int gradz_is_bf16, int gact, int splitk, int accumulate, void* Cb, int64_t ldcb,
+                  void* Pb, int64_t ldpb, void* workspace, size_t ws_bytes, void* stream);
 
 /* Operand conversion of the reduced-precision mode (no reference counterpart): fp32 -> bf16,
  * round to nearest even; n contiguous elements, or the transpose (C, R) of a (R, C) matrix
  * with row stride ld (the W^T shadow of an nn.Linear weight). */
 int qarig_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 int qarig_cast_transpose_bf16(const float* src, int64_t ld, int R, int C, void* dst, void* stream);
+/* colsum[n] (+)= sum_m src[m][n] in a fixed order -- the bias gradient of nn.Linear
+ * (models/layers.py:243-250) -- and, when dst is given, dst = bf16(src) in the same pass over
+ * src (fp32, or bf16 with src_is_bf16 = 1 and dst NULL). */
+size_t qarig_cast_colsum_workspace_bytes(int M, int N);
+int qarig_cast_colsum(const void* src, int64_t ld, int src_is_bf16, int M, int N, void* dst,
+                      float* colsum, int accumulate, void* workspace, size_t ws_bytes, void* stream);
 
 /* `groups` independent skinny products in one launch, C_g = act(A_g W_g^T + bias_g) with
  * X_g = X + g * x_gs (a_gs == 0 shares the activations).  Decode steps use it for the q/k/v
@@ -146,6 +152,14 @@ int qarig_index_histogram(const int64_t* ids, int64_t n, int K, int64_t* counts,
 /* get_positional_embeddings -- models/layers.py:83-96.  pos fp32 (R,), freq (D/2,)
  * (host-computed exactly as the reference does), out (R,D) = [sin | cos]. */
 int qarig_posemb_fwd(const float* pos, int R, int D, const float* freq, float* out, void* stream);
+
+/* Token assembly of the training hot loop (train_quantized_transformer.py:423-484) in one launch:
+ * from the LR / HR BMU indices to the windowed decoder input, target and absolute positions
+ * (base: [lr | hr + k_lr] / enc-dec: [<start> | hr]; target [hr | <end>]; window of W tokens
+ * starting at offs[n]; pos = offs[n] + w).  Replaces cat + unfold + gather + arange on the host. */
+int qarig_assemble_tokens(const int64_t* lr, int S_lr, const int64_t* hr, int S_hr, int N, int base,
+                          int k_lr, int k_hr, const int64_t* offs, int W, int64_t* hr_in,
+                          int64_t* hr_tg, int64_t* pos, void* stream);
 
 /* nn.Embedding + additive position table -- models/Transformer.py:127-139,154-167.
  * ids int64 (M = N*S); pe (S,D) or NULL; out (M,D). */

@@ -41,6 +41,34 @@ __global__ void embedding_fwd_kernel(const int64_t* __restrict__ ids, int M, int
     }
 }
 
+// Token assembly of the training loop (reference train_quantized_transformer.py:423-484) in one
+// launch: the decoder input / target sequences
+//   base   : input = [lr tokens | hr + k_lr],  target = [hr | <end> = k_hr]
+//   enc-dec: input = [<start> = k_hr | hr],    target = [hr | <end>]
+// are never materialised; window w of sample n starts at offs[n] and the kernel writes
+// hr_in (N,W), hr_tg (N,W) and the absolute positions pos (N,W) = offs[n] + w directly.
+// window == 0: no sliding window, the whole sequences (W = S_in) and no positions.
+__global__ void assemble_tokens_kernel(const int64_t* __restrict__ lr, int S_lr,
+                                       const int64_t* __restrict__ hr, int S_hr, int N, int base,
+                                       int k_lr, int k_hr, const int64_t* __restrict__ offs, int W,
+                                       int64_t* __restrict__ hr_in, int64_t* __restrict__ hr_tg,
+                                       int64_t* __restrict__ pos) {
+    const int lead = base ? S_lr : 1;          // tokens in front of the HR tokens of the input
+    const int64_t total = (int64_t)N * W;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / W), w = (int)(idx - (int64_t)n * W);
+        const int64_t o = offs ? offs[n] : 0;
+        const int64_t j = o + w;                                   // index in the full sequences
+        int64_t vin;
+        if (j < lead) vin = base ? lr[(int64_t)n * S_lr + j] : (int64_t)k_hr;
+        else vin = hr[(int64_t)n * S_hr + (j - lead)] + (base ? k_lr : 0);
+        hr_in[idx] = vin;
+        hr_tg[idx] = j < S_hr ? hr[(int64_t)n * S_hr + j] : (int64_t)k_hr;
+        if (pos) pos[idx] = j;
+    }
+}
+
 // dtable[v][:] = sum over m with ids[m]==v of dy[m][:], m ascending (deterministic, no
 // atomics).  One block per vocabulary row; every wave scans the id stream 64 ids at a
 // time (coalesced) and walks only the set bits of the match ballot.
@@ -110,5 +138,31 @@ extern "C" int qarig_embedding_bwd(const int64_t* ids, int M, int D, int V, cons
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, M, D,
                        dy, dtable);
     QARIG_CHECK_LAUNCH("embedding_bwd");
+    return QARIG_OK;
+}
+
+// hr_in / hr_tg / pos (N,W) int64 from the BMU indices (see assemble_tokens_kernel).  lr (N,S_lr)
+// is read by the base model only; offs (N) int64 window starts or NULL (then W must be the
+// input length S_lr + S_hr (base) / 1 + S_hr and pos may be NULL).  Offsets are trusted to lie in
+// [0, S_in - W] (the host draws them with randint(0, S_in - W + 1)).
+extern "C" int qarig_assemble_tokens(const int64_t* lr, int S_lr, const int64_t* hr, int S_hr, int N,
+                                     int base, int k_lr, int k_hr, const int64_t* offs, int W,
+                                     int64_t* hr_in, int64_t* hr_tg, int64_t* pos, void* stream) {
+    QARIG_CHECK_ARG(hr && hr_in && hr_tg && (lr || !base), "assemble_tokens: null pointer");
+    QARIG_CHECK_ARG(N > 0 && S_hr > 0 && W > 0 && (!base || S_lr > 0), "assemble_tokens: bad extents");
+    QARIG_CHECK_DIMS("assemble_tokens", N, S_hr);
+    QARIG_CHECK_DIMS("assemble_tokens", N, W);
+    const int s_in = (base ? S_lr : 1) + S_hr;
+    QARIG_CHECK_ARG(W <= s_in && (offs || W == s_in), "assemble_tokens: window %d vs sequence %d", W, s_in);
+    QARIG_CHECK_ARG(base ? (S_lr <= (1 << 24)) : 1, "assemble_tokens: bad extents");
+    // the target has S_hr + 1 entries; with the base model's S_lr leading tokens logits and
+    // targets line up only for S_lr == 1 -- as in the reference, longer LR
+    // sequences simply run out of target (guarded: <end> is written past it)
+    const int64_t total = (int64_t)N * W;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, lr, S_lr,
+                       hr, S_hr, N, base, k_lr, k_hr, offs, W, hr_in, hr_tg, pos);
+    QARIG_CHECK_LAUNCH("assemble_tokens");
     return QARIG_OK;
 }

@@ -37,6 +37,13 @@ struct RowSumHook {
 // before its first load, first round only; the epilogue of one workgroup then runs under the
 // MFMAs of the other three for the rest of the launch.  Placement only changes speed.
 __device__ __forceinline__ void stagger_first_round(int units) {
+    if (units < 0) {     // experiment: static issue priority by SIMD wave slot instead of a delay
+        const int slot = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3);
+        if (slot == 1) __builtin_amdgcn_s_setprio(1);
+        else if (slot == 2) __builtin_amdgcn_s_setprio(2);
+        else if (slot == 3) __builtin_amdgcn_s_setprio(3);
+        return;
+    }
     if (units <= 0 || blockIdx.x >= 1024u) return;
     const int slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15;   // HW_REG_HW_ID[3:0]
     for (int i = 0; i < slot * units; ++i) __builtin_amdgcn_s_sleep(127);
@@ -258,6 +265,126 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const float* __re
             }
             st = st + 1 == STAGES ? 0 : st + 1;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (do_rs) ep.rowsum[(int64_t)blockIdx.z * M + m0 + tid] = rs;
+    __syncthreads();                      // ring no longer in use: the epilogue stages through it
+    gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, slabs);
+}
+
+// The same ring (3 stages) with the fragments of tile t+1 read from LDS into a second register
+// set WHILE tile t's 32 MFMAs issue: the LDS round trip (8 x ds_read_b128 + latency behind the
+// other waves' LDS traffic) leaves the k-loop's critical path; what remains between two MFMA
+// slabs is the barrier and the issue of 4 DMAs and 8 reads.  (Counters on the 2-stage kernel:
+// waves spend 19 % of their cycles in s_waitcnt / s_barrier and the matrix pipe idles 24 %.)
+struct Frags8 {
+    f32x4 a0l, a0h, a1l, a1h, b0l, b0h, b1l, b1h;
+};
+template <bool AKC, bool BKC>
+__device__ __forceinline__ void frags_read(Frags8& f, const float* ta, const float* tb, int wm, int wn,
+                                           int x, int h) {
+    frag_read<AKC>(ta, wm * 64 + x, h, f.a0l, f.a0h);
+    frag_read<BKC>(tb, wn * 64 + x, h, f.b0l, f.b0h);
+    frag_read<AKC>(ta, wm * 64 + 32 + x, h, f.a1l, f.a1h);
+    frag_read<BKC>(tb, wn * 64 + 32 + x, h, f.b1l, f.b1h);
+}
+__device__ __forceinline__ void frags_mma(Acc& acc, const Frags8& f) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float a0 = s < 4 ? f.a0l[s & 3] : f.a0h[s & 3];
+        const float a1 = s < 4 ? f.a1l[s & 3] : f.a1h[s & 3];
+        const float b0 = s < 4 ? f.b0l[s & 3] : f.b0h[s & 3];
+        const float b1 = s < 4 ? f.b1l[s & 3] : f.b1h[s & 3];
+        acc.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc.t[0][0], 0, 0, 0);
+        acc.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc.t[0][1], 0, 0, 0);
+        acc.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc.t[1][0], 0, 0, 0);
+        acc.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc.t[1][1], 0, 0, 0);
+    }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_pf_kernel(const float* __restrict__ A, int64_t lda,
+                                                                  const float* __restrict__ B, int64_t ldb,
+                                                                  GemmEpilogue ep, int M, int N, int K,
+                                                                  int tiles_n, int splitk, float* slabs) {
+    constexpr int ST = 3;
+    __shared__ __attribute__((aligned(16))) float lds[ST * DMA_STAGE_FLOATS];   // 48 KB
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    int k_begin = 0, k_end = K;
+    if (splitk > 1) {
+        const int per = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
+        k_begin = blockIdx.z * per;
+        k_end = min(K, k_begin + per);
+    }
+    const int nk = (k_end - k_begin) / BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int x = lane & 31, h = lane >> 5;
+    const int last = k_begin + (nk - 1) * BK;
+
+    Acc acc;
+    acc_zero(acc);
+    float rs = 0.0f;
+    const bool do_rs = !AKC && ep.rowsum != nullptr && tn == 0 && tid < 128;
+    auto stage_of = [](int t) { return t % ST; };
+    auto issue = [&](int t) {            // DMA of tile t (clamped: a harmless re-load past the end)
+        const int k = min(k_begin + t * BK, last);
+        float* dst = lds + stage_of(t) * DMA_STAGE_FLOATS;
+        dma_tile<AKC>(A, lda, m0, k, dst, wave, lane);
+        dma_tile<BKC>(B, ldb, n0, k, dst + DMA_OP_FLOATS, wave, lane);
+    };
+    auto rowsum_tile = [&](int t) {      // sum_k A(m0 + tid, k) of tile t, k ascending
+        f32x4 r0, r1, r2, r3;
+        const float* ta = lds + stage_of(t) * DMA_STAGE_FLOATS;
+        frag_read<false>(ta, tid, 0, r0, r1);
+        frag_read<false>(ta, tid, 1, r2, r3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rs += r0[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rs += r1[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rs += r2[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rs += r3[q];
+    };
+    if (nk > 0) {
+        issue(0);
+        issue(1);
+        issue(2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // tile 0 landed (1, 2 in flight)
+        __builtin_amdgcn_s_barrier();
+        Frags8 P, Q;
+        frags_read<AKC, BKC>(P, lds, lds + DMA_OP_FLOATS, wm, wn, x, h);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_rs) rowsum_tile(0);
+        int t = 0;
+        // body for tile t with its fragments in CUR; leaves tile t+1's in NXT
+#define QARIG_PF_BODY(CUR, NXT)                                                                   \
+        {                                                                                         \
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   /* tile t+1 landed, t+2 in flight */ \
+            __builtin_amdgcn_s_barrier();      /* ... for everyone; all reads of tile t retired */  \
+            issue(t + 3);                      /* into the stage tile t has just vacated */        \
+            const float* na = lds + stage_of(t + 1) * DMA_STAGE_FLOATS;                           \
+            frags_read<AKC, BKC>(NXT, na, na + DMA_OP_FLOATS, wm, wn, x, h);                      \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            frags_mma(acc, CUR);                                                                  \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            if (do_rs && t + 1 < nk) rowsum_tile(t + 1);                                          \
+            ++t;                                                                                  \
+        }
+        while (t + 2 <= nk) {
+            QARIG_PF_BODY(P, Q)
+            QARIG_PF_BODY(Q, P)
+        }
+        if (t < nk) QARIG_PF_BODY(P, Q)
+#undef QARIG_PF_BODY
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (do_rs) ep.rowsum[(int64_t)blockIdx.z * M + m0 + tid] = rs;
@@ -501,8 +628,10 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     // stagger (units of 8128-cycle sleeps per wave slot) only where the grid spans more than
     // one dispatch round of ~4 workgroups per CU; QARIG_GEMM_STAGGER overrides (0 = off)
     const char* stagger_e = getenv("QARIG_GEMM_STAGGER");
-    const int stagger_env = stagger_e ? atoi(stagger_e) : -1;
-    const int stagger = (long)grid.x * grid.z >= 1024 ? (stagger_env >= 0 ? stagger_env : 2) : 0;
+    const int stagger_env = stagger_e ? atoi(stagger_e) : 0;
+    // measured: the delay is worth nothing (+-1 %: profiles/README.md), so it is off by default;
+    // QARIG_GEMM_STAGGER = -1 selects the static-priority experiment
+    const int stagger = stagger_env == -2 ? -1 : ((long)grid.x * grid.z >= 1024 && stagger_env > 0 ? stagger_env : 0);
     // ring depth: 3 stages where the grid leaves at most three workgroups per CU anyway (the
     // split-K weight gradients and the N = 512 outputs: 512 workgroups); QARIG_GEMM_STAGES overrides
     const char* stages_e = getenv("QARIG_GEMM_STAGES");
@@ -512,7 +641,22 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
         if (stages == 3) hipLaunchKernelGGL((gemm_dma_kernel<AK, BK_, 3>), __VA_ARGS__);      \
         else hipLaunchKernelGGL((gemm_dma_kernel<AK, BK_, 2>), __VA_ARGS__);                  \
     } while (0)
-    if (dma_on && dma_shape && fast && vec_epi && !(a_rowsum && a_kcontig) &&
+    // fragment-prefetch form of the ring on the shapes the DMA kernel serves (+2..5 % there,
+    // -4..-13 % on K = 512 x N = 2048, which stays on the register-staged kernel);
+    // QARIG_GEMM_PF=0 restores the 2-stage kernel, =1 forces the prefetch form on every shape
+    const char* pf_e = getenv("QARIG_GEMM_PF");
+    const bool pf = pf_e ? pf_e[0] == '1' || (pf_e[0] != '0' && dma_shape) : (dma_on && dma_shape);
+    if (pf && fast && vec_epi && !(a_rowsum && a_kcontig) && !(!a_kcontig && b_kcontig)) {
+        if (a_kcontig && b_kcontig)
+            hipLaunchKernelGGL((gemm_dma_pf_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
+                               N, K, tiles_n, splitk, slabs);
+        else if (a_kcontig)
+            hipLaunchKernelGGL((gemm_dma_pf_kernel<true, false>), grid, block, 0, st, A, lda, B, ldb, ep, M,
+                               N, K, tiles_n, splitk, slabs);
+        else
+            hipLaunchKernelGGL((gemm_dma_pf_kernel<false, false>), grid, block, 0, st, A, lda, B, ldb, ep,
+                               M, N, K, tiles_n, splitk, slabs);
+    } else if (dma_on && dma_shape && fast && vec_epi && !(a_rowsum && a_kcontig) &&
         !(!a_kcontig && b_kcontig)) {
         if (a_kcontig && b_kcontig)
             QARIG_LAUNCH_DMA(true, true, grid, block, 0, st, A, lda, B, ldb, ep, M,

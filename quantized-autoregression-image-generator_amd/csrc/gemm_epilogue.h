@@ -18,7 +18,10 @@ struct GemmEpilogue {
     float* rowsum;                        // [splitk][M]: sum_k A(m,k) per K split, or null
     unsigned short* Cb; int64_t ldcb;     // optional bf16 copy of what goes to C (consumer GEMMs), or null
     unsigned short* Pb; int64_t ldpb;     // optional bf16 copy of the saved pre-activation, or null
+    const unsigned short* gradzb; int64_t ldzb;   // gradz given in bf16 (reduced-precision mode), or null
 };
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned int hi16) { return __uint_as_float(hi16 << 16); }
 
 // two fp32 -> one dword of two bf16 (round to nearest even, v_cvt_pk_bf16_f32)
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
@@ -79,6 +82,12 @@ __device__ __forceinline__ void gemm_epilogue_wide(const Acc& acc, const GemmEpi
                 const float4 z = *reinterpret_cast<const float4*>(ep.gradz + row * ep.ldz + gc);
                 y.x *= act_grad(z.x, ep.gact); y.y *= act_grad(z.y, ep.gact);
                 y.z *= act_grad(z.z, ep.gact); y.w *= act_grad(z.w, ep.gact);
+            } else if (ep.gradzb) {
+                const uint2 zb = *reinterpret_cast<const uint2*>(ep.gradzb + row * ep.ldzb + gc);
+                y.x *= act_grad(bf16_bits_to_f32(zb.x & 0xffffu), ep.gact);
+                y.y *= act_grad(bf16_bits_to_f32(zb.x >> 16), ep.gact);
+                y.z *= act_grad(bf16_bits_to_f32(zb.y & 0xffffu), ep.gact);
+                y.w *= act_grad(bf16_bits_to_f32(zb.y >> 16), ep.gact);
             }
             if (ep.C) *reinterpret_cast<float4*>(ep.C + row * ep.ldc + gc) = y;
             if (ep.Cb)

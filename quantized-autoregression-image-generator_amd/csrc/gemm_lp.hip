@@ -166,6 +166,42 @@ __global__ void cast_bf16_tail_kernel(const float* __restrict__ src, bf16_t* __r
     if (i < n) dst[i] = (bf16_t)(pack_bf16x2(src[i], 0.0f) & 0xffffu);
 }
 
+// Cast with the column sums riding along: dst = bf16(src) for src (M, N) fp32 and
+// part[blockIdx.y][n] = sum of the block's CS_ROWS rows of column n (fixed order).  The bias
+// gradient of a Linear layer is the column sum of the same dT that the weight-gradient GEMM
+// needs in bf16, so one pass over dT yields both.
+constexpr int CS_ROWS = 64;
+__global__ __launch_bounds__(128) void cast_colsum_kernel(const float* __restrict__ src, int64_t ld,
+                                                          int M, int N, bf16_t* __restrict__ dst,
+                                                          float* __restrict__ part) {
+    const int c = (blockIdx.x * 128 + threadIdx.x) * 4;
+    if (c >= N) return;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0; r < r1; ++r) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + c);
+        if (dst)
+            *reinterpret_cast<uint2*>(dst + (int64_t)r * N + c) =
+                make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * N + c) = s;
+}
+// the same sums from a bf16 tensor (dT1 of an MLP exists only in bf16 in this mode)
+__global__ __launch_bounds__(128) void colsum_bf16_kernel(const bf16_t* __restrict__ src, int64_t ld,
+                                                          int M, int N, float* __restrict__ part) {
+    const int c = (blockIdx.x * 128 + threadIdx.x) * 4;
+    if (c >= N) return;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0; r < r1; ++r) {
+        const uint2 v = *reinterpret_cast<const uint2*>(src + (int64_t)r * ld + c);
+        s.x += bf16_bits_to_f32(v.x & 0xffffu); s.y += bf16_bits_to_f32(v.x >> 16);
+        s.z += bf16_bits_to_f32(v.y & 0xffffu); s.w += bf16_bits_to_f32(v.y >> 16);
+    }
+    *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * N + c) = s;
+}
+
 // dst[c][r] = bf16(src[r][c]) for src (R, C) row-major with leading dimension lds_: the W^T
 // shadow of a Linear weight.  64 x 64 tiles through LDS, coalesced on both sides.
 __global__ __launch_bounds__(256) void cast_transpose_bf16_kernel(const float* __restrict__ src,
@@ -229,6 +265,39 @@ extern "C" int qarig_cast_transpose_bf16(const float* src, int64_t ld, int R, in
     return QARIG_OK;
 }
 
+extern "C" size_t qarig_cast_colsum_workspace_bytes(int M, int N) {
+    if (M < 1 || N < 1 || M > (1 << 24) || N > (1 << 24)) return 0;
+    return (size_t)((M + CS_ROWS - 1) / CS_ROWS) * N * sizeof(float);
+}
+
+// colsum[n] (+)= sum_m src[m][n], and (dst != NULL) dst = bf16(src); src fp32 (src_is_bf16 = 0) or
+// bf16 (1; dst must be NULL).  N % 4 == 0, rows 16-B (8-B for bf16) aligned.  The bias gradient
+// of nn.Linear (models/layers.py:243-250) in the reduced-precision mode.
+extern "C" int qarig_cast_colsum(const void* src, int64_t ld, int src_is_bf16, int M, int N, void* dst,
+                                 float* colsum, int accumulate, void* workspace, size_t ws_bytes,
+                                 void* stream) {
+    QARIG_CHECK_ARG(src && colsum && M > 0 && N > 0 && N % 4 == 0 && ld >= N && ld % 4 == 0,
+                    "cast_colsum: bad arguments");
+    QARIG_CHECK_DIMS("cast_colsum", M, N);
+    QARIG_CHECK_ARG(!(src_is_bf16 && dst), "cast_colsum: a bf16 source is not re-cast");
+    QARIG_CHECK_ARG(((uintptr_t)src & (src_is_bf16 ? 7 : 15)) == 0 && (!dst || ((uintptr_t)dst & 7) == 0),
+                    "cast_colsum: misaligned buffers");
+    if (!workspace || ws_bytes < qarig_cast_colsum_workspace_bytes(M, N)) {
+        qarig_set_error("cast_colsum: workspace too small");
+        return QARIG_ERR_WORKSPACE;
+    }
+    const int chunks = (M + CS_ROWS - 1) / CS_ROWS;
+    dim3 grid((N / 4 + 127) / 128, chunks), block(128);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_is_bf16)
+        hipLaunchKernelGGL(colsum_bf16_kernel, grid, block, 0, st, (const bf16_t*)src, ld, M, N, (float*)workspace);
+    else
+        hipLaunchKernelGGL(cast_colsum_kernel, grid, block, 0, st, (const float*)src, ld, M, N, (bf16_t*)dst,
+                           (float*)workspace);
+    QARIG_CHECK_LAUNCH("cast_colsum");
+    return qarig_slab_reduce_f32((const float*)workspace, colsum, N, 1, N, chunks, accumulate, stream);
+}
+
 extern "C" size_t qarig_gemm_lp_workspace_bytes(int M, int N, int splitk) {
     if (M < 1 || N < 1 || splitk > (1 << 16)) return 0;
     return splitk > 1 ? (size_t)splitk * M * N * sizeof(float) : 0;
@@ -249,9 +318,9 @@ extern "C" int qarig_gemm_lp_supported(int M, int N, int K, int splitk) {
 extern "C" int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t ldb, int layout,
                              float* C, int64_t ldc, int M, int N, int K, const float* bias,
                              const float* residual, int64_t ldr, float* preact, int64_t ldp, int act,
-                             const float* gradz, int64_t ldz, int gact, int splitk, int accumulate,
-                             void* Cb, int64_t ldcb, void* Pb, int64_t ldpb, void* workspace,
-                             size_t ws_bytes, void* stream) {
+                             const void* gradz, int64_t ldz, int gradz_is_bf16, int gact, int splitk,
+                             int accumulate, void* Cb, int64_t ldcb, void* Pb, int64_t ldpb,
+                             void* workspace, size_t ws_bytes, void* stream) {
     QARIG_CHECK_ARG(A && B && (C || Cb), "gemm_lp: null operand");
     QARIG_CHECK_ARG(layout == 0 || layout == 1, "gemm_lp: layout must be 0 (NT) or 1 (TN)");
     QARIG_CHECK_ARG(act >= 0 && act <= 3 && gact >= 0 && gact <= 3, "gemm_lp: bad activation id");
@@ -262,7 +331,8 @@ extern "C" int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t 
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     QARIG_CHECK_ARG(al16(A) && al16(B) && lda % 8 == 0 && ldb % 8 == 0, "gemm_lp: operands 16-B aligned, ld %% 8");
     auto ok4 = [&](const void* p, int64_t ld) { return !p || (al16(p) && ld % 4 == 0); };
-    QARIG_CHECK_ARG(ok4(C, ldc) && ok4(bias, 4) && ok4(residual, ldr) && ok4(preact, ldp) && ok4(gradz, ldz),
+    QARIG_CHECK_ARG(ok4(C, ldc) && ok4(bias, 4) && ok4(residual, ldr) && ok4(preact, ldp) &&
+                        (gradz_is_bf16 ? (!gradz || (((uintptr_t)gradz & 7) == 0 && ldz % 4 == 0)) : ok4(gradz, ldz)),
                     "gemm_lp: fp32 epilogue tensors 16-B aligned, ld %% 4");
     QARIG_CHECK_ARG((!Cb || (((uintptr_t)Cb & 7) == 0 && ldcb % 4 == 0)) &&
                         (!Pb || (((uintptr_t)Pb & 7) == 0 && ldpb % 4 == 0)),
@@ -282,8 +352,10 @@ extern "C" int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t 
     }
     const int tiles_m = M / BM, tiles_n = N / BN;
     dim3 grid(tiles_m * tiles_n, 1, splitk), block(NTHREADS);
-    GemmEpilogue ep{C, ldc, bias, residual, ldr, preact, ldp, act, gradz, ldz, gact, nullptr,
-                    (unsigned short*)Cb, ldcb, (unsigned short*)Pb, ldpb};
+    GemmEpilogue ep{C, ldc, bias, residual, ldr, preact, ldp, act,
+                    gradz_is_bf16 ? nullptr : (const float*)gradz, ldz, gact, nullptr,
+                    (unsigned short*)Cb, ldcb, (unsigned short*)Pb, ldpb,
+                    gradz_is_bf16 ? (const unsigned short*)gradz : nullptr, ldz};
     hipStream_t st = (hipStream_t)stream;
     if (layout == 0)
         hipLaunchKernelGGL((gemm_lp_kernel<false>), grid, block, 0, st, (const bf16_t*)A, lda,

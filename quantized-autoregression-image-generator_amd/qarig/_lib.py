@@ -32,8 +32,10 @@ SIGNATURES = {
                            P]),
     "qarig_gemm_lp_supported": (I, [I, I, I, I]),
     "qarig_gemm_lp_workspace_bytes": (Z, [I, I, I]),
-    "qarig_gemm_lp": (I, [P, L, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, I, P, L, P, L, P, Z,
+    "qarig_gemm_lp": (I, [P, L, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, I, I, P, L, P, L, P, Z,
                           P]),
+    "qarig_cast_colsum_workspace_bytes": (Z, [I, I]),
+    "qarig_cast_colsum": (I, [P, L, I, I, I, P, P, I, P, Z, P]),
     "qarig_cast_bf16": (I, [P, P, L, P]),
     "qarig_cast_transpose_bf16": (I, [P, L, I, I, P, P]),
     "qarig_colsum_workspace_bytes": (Z, [I, I]),
@@ -45,6 +47,7 @@ SIGNATURES = {
     "qarig_som_weights_fwd": (I, [P, L, I, F, P, P]),
     "qarig_index_histogram": (I, [P, L, I, P, P, P]),
     "qarig_posemb_fwd": (I, [P, I, I, P, P, P]),
+    "qarig_assemble_tokens": (I, [P, I, P, I, I, I, I, I, P, I, P, P, P, P]),
     "qarig_embedding_fwd": (I, [P, I, I, I, I, P, P, P, P, P]),
     "qarig_embedding_bwd": (I, [P, I, I, I, P, P, P]),
     "qarig_layernorm_fwd": (I, [P, I, I, F, P, P, P, P, P, P, P, P, P]),

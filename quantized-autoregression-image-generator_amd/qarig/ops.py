@@ -167,6 +167,20 @@ def cast_transpose_bf16(x, cache=False):
     return out
 
 
+def cast_colsum(x, colsum_out, accumulate=False, want_cast=True):
+    """One pass over x (M,N) (fp32, or bf16 with want_cast False): column sums (+)= into
+    colsum_out (fp32 (N,)) -- the bias gradient -- and, for fp32 input, the bf16 copy of x."""
+    M, N = x.shape
+    assert x.stride(1) == 1 and colsum_out.shape == (N,) and colsum_out.is_contiguous()
+    is_bf = x.dtype == torch.bfloat16
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if (want_cast and not is_bf) else None
+    lib = _lib.load()
+    ws = workspace(lib.qarig_cast_colsum_workspace_bytes(M, N), x.device, "colsum")
+    check(lib.qarig_cast_colsum(ptr(x), x.stride(0), int(is_bf), M, N, ptr(out), ptr(colsum_out),
+                                int(accumulate), ptr(ws), ws.numel(), stream()), "qarig_cast_colsum")
+    return out
+
+
 def _is_param_like(t):
     """Weights (cached shadows) vs activations (cast per call)."""
     return isinstance(t, torch.nn.Parameter) or getattr(t, "_qarig_weight", False)
@@ -189,7 +203,8 @@ def gemm_lp(A_bf, B_bf, layout, M, N, K, C=None, bias=None, residual=None, preac
         ptr(C), C.stride(0) if C is not None else 0, M, N, K, ptr(bias),
         ptr(residual), residual.stride(0) if residual is not None else 0,
         ptr(preact), preact.stride(0) if preact is not None else 0, act,
-        ptr(gradz), gradz.stride(0) if gradz is not None else 0, gact, splitk, int(accumulate),
+        ptr(gradz), gradz.stride(0) if gradz is not None else 0,
+        int(gradz is not None and gradz.dtype == torch.bfloat16), gact, splitk, int(accumulate),
         ptr(Cb), Cb.stride(0) if Cb is not None else 0, ptr(Pb), Pb.stride(0) if Pb is not None else 0,
         ptr(ws), nws, stream()), "qarig_gemm_lp")
     if GEMM_EVENTS is not None:
@@ -444,6 +459,32 @@ def posemb(pos, D):
     check(_lib.load().qarig_posemb_fwd(ptr(pos), pos.numel(), D, ptr(pos_frequencies(D, pos.device)),
                                        ptr(out), stream()), "qarig_posemb_fwd")
     return out
+
+
+def assemble_tokens(lr_idx, hr_idx, base, k_lr, k_hr, offs=None, window=None):
+    """(hr_in, hr_tg, pos) int64 (N,W) from the BMU indices: token assembly + window slicing of
+    the training loop (reference train_quantized_transformer.py:423-484) in one launch.
+    offs: int64 (N,) window starts on the device, or None for the whole sequence (pos None)."""
+    require_cuda(hr_idx, lr_idx, offs)
+    hr_idx = _i64c(hr_idx)
+    N, S_hr = hr_idx.shape
+    S_lr = 0
+    if base:
+        lr_idx = _i64c(lr_idx)
+        S_lr = lr_idx.shape[1]
+    s_in = (S_lr if base else 1) + S_hr
+    W = s_in if offs is None else int(window)
+    dev = hr_idx.device
+    hr_in = torch.empty((N, W), dtype=torch.int64, device=dev)
+    hr_tg = torch.empty((N, W), dtype=torch.int64, device=dev)
+    pos = torch.empty((N, W), dtype=torch.int64, device=dev) if offs is not None else None
+    if offs is not None:
+        offs = _i64c(offs)
+        assert offs.shape == (N,)
+    check(_lib.load().qarig_assemble_tokens(ptr(lr_idx) if base else None, S_lr, ptr(hr_idx), S_hr, N,
+                                            int(base), int(k_lr), int(k_hr), ptr(offs), W, ptr(hr_in),
+                                            ptr(hr_tg), ptr(pos), stream()), "qarig_assemble_tokens")
+    return hr_in, hr_tg, pos
 
 
 def embedding_fwd(ids, table, pe=None):

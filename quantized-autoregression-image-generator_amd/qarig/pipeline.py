@@ -37,6 +37,19 @@ def slide(hr_input, hr_target, window, rand_indices):
     return hr_input.gather(1, offs), hr_target.gather(1, offs), offs
 
 
+def tokenize_window(feature_map, lr_codebook, hr_codebook, train_base_model, window, rand_indices):
+    """tokenize + slide fused: BMU indices -> (hr_input, lr_input, hr_target, pos) of ONE window
+    per sample, assembled by one kernel (no cat / full / gather / arange launches and no
+    full-length sequences in HBM).  rand_indices None: no sliding window (pos None)."""
+    from . import ops
+    lr_idx = lr_codebook.get_patches_bmu(feature_map, reshape=True)
+    hr_idx = hr_codebook.get_patches_bmu(feature_map, reshape=True)
+    offs = None if rand_indices is None else rand_indices.to(feature_map.device)
+    hr_in, hr_tg, pos = ops.assemble_tokens(lr_idx, hr_idx, train_base_model, lr_codebook.num_embeddings,
+                                            hr_codebook.num_embeddings, offs, window)
+    return hr_in, (None if train_base_model else lr_idx), hr_tg, pos
+
+
 def num_windows(seq_len, window):
     return seq_len - window + 1
 
@@ -85,11 +98,11 @@ class GraphedTrainStep:
         self.graph = None
 
     def _body(self, z, rand, captured):
-        hr_in, lr_in, hr_tg = tokenize(z, self.lr_cb, self.hr_cb, self.base)
-        seq = hr_in.shape[1]
-        pos = None
-        if self.window is not None:
-            hr_in, hr_tg, pos = slide(hr_in, hr_tg, self.window, rand)
+        hr_in, lr_in, hr_tg, pos = tokenize_window(z, self.lr_cb, self.hr_cb, self.base, self.window,
+                                                   rand if self.window is not None else None)
+        lr_seq = (z.shape[2] // self.lr_cb.patch_dim[0]) * (z.shape[3] // self.lr_cb.patch_dim[1])
+        seq = (z.shape[2] // self.hr_cb.patch_dim[0]) * (z.shape[3] // self.hr_cb.patch_dim[1]) + \
+            (lr_seq if self.base else 1)
         self.optim.zero_grad()
         logits = self.model(x_dec=hr_in, x_enc=lr_in, pos_cond=pos, pos_bound=seq)
         loss = QF.cross_entropy(logits.view(-1, logits.shape[-1]), hr_tg.flatten())

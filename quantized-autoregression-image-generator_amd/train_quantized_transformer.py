@@ -252,15 +252,15 @@ def main():
                                          size=(N,))                     # CPU global RNG
                 loss = graphed(feature_map, rand)
             else:
-                hr_in, lr_in, hr_tg = pipeline.tokenize(feature_map, lr_codebook, hr_codebook,
-                                                        train_base_model)
-                pos_idx = None
-                seq_total = hr_in.shape[1]
+                seq_total = graphed_seq
+                rand = None
                 if use_sliding_window:
-                    nwin = pipeline.num_windows(hr_in.shape[1], sliding_window)
+                    nwin = pipeline.num_windows(seq_total, sliding_window)
                     rand = torch.randint(low=0, high=nwin, size=(N * world,))   # CPU global RNG
                     rand = parallel.shard(parallel.broadcast_host_tensor(rand))
-                    hr_in, hr_tg, pos_idx = pipeline.slide(hr_in, hr_tg, sliding_window, rand)
+                hr_in, lr_in, hr_tg, pos_idx = pipeline.tokenize_window(
+                    feature_map, lr_codebook, hr_codebook, train_base_model,
+                    sliding_window if use_sliding_window else None, rand)
                 loss = pipeline.train_step(model, optim, hr_in, lr_in, hr_tg, pos_idx,
                                            pos_bound=seq_total)
             loss_val = loss.item()                                   # the reference's per-step sync

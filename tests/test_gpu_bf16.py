@@ -155,6 +155,71 @@ def test_bf16_mode_falls_back_to_fp32_kernels_off_the_interior(bf16_mode):
         ops.gemm(A, W)
 
 
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a * b).sum() / (a.norm() * b.norm()))
+
+
+@pytest.mark.parametrize("N_out,act2", [(512, 0), (512, 1), (513, 0)])
+def test_lp_mlp_nodes_track_fp32_nodes(bf16_mode, N_out, act2):
+    """The bf16-storage MLP node (h, t1, dT1 exist only in bf16; bias gradients from the fused
+    cast + column-sum pass; padded ragged output width) against the fp32 node from the same
+    weights: outputs and every gradient within the bf16 rounding budget (relative error of
+    the tensor < 1e-2, cosine > 0.9999)."""
+    ops = bf16_mode
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(7)
+    M, K, H = 2048, 512, 2048
+    x = torch.randn((4, M // 4, K), generator=g).cuda()
+    w1, b1 = (torch.randn((H, K), generator=g) * 0.04).cuda(), (torch.randn(H, generator=g) * 0.1).cuda()
+    w2, b2 = (torch.randn((N_out, H), generator=g) * 0.02).cuda(), (torch.randn(N_out, generator=g) * 0.1).cuda()
+    dy = torch.randn((4, M // 4, N_out), generator=g).cuda()
+    res = {}
+    for mode in ("f32", "bf16"):
+        ops.PRECISION = mode
+        leaves = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        y = QF.mlp2(*leaves, 1, act2)
+        if mode == "bf16":
+            assert type(y.grad_fn).__name__ == "_MLP2LPBackward"
+        (y * dy).sum().backward()
+        res[mode] = [y.detach()] + [t.grad for t in leaves]
+    ops.PRECISION = "bf16"
+    for a, b in zip(res["bf16"], res["f32"]):
+        assert rel_err(a, b) < 1.5e-2 and _cos(a, b) > 0.9999
+
+
+def test_lp_qkv_and_residual_nodes_track_fp32_nodes(bf16_mode):
+    ops = bf16_mode
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(8)
+    M, K, H = 2048, 512, 1024
+    x = torch.randn((2, M // 2, K), generator=g).cuda()
+    params = []
+    for _ in range(3):
+        params.append(((torch.randn((H, K), generator=g) * 0.04).cuda(), (torch.randn(H, generator=g) * 0.1).cuda(),
+                       (torch.randn((K, H), generator=g) * 0.03).cuda(), (torch.randn(K, generator=g) * 0.1).cuda()))
+    dys = [torch.randn((2, M // 2, K), generator=g).cuda() for _ in range(3)]
+    wr, br = (torch.randn((K, K), generator=g) * 0.04).cuda(), (torch.randn(K, generator=g) * 0.1).cuda()
+    skip = torch.randn((2, M // 2, K), generator=g).cuda()
+    res = {}
+    for mode in ("f32", "bf16"):
+        ops.PRECISION = mode
+        xl = x.clone().requires_grad_(True)
+        pl = [tuple(t.clone().requires_grad_(True) for t in p) for p in params]
+        q, k, v = QF.mlp2x3(xl, pl, 1, 0)
+        (q * dys[0] + k * dys[1] + v * dys[2]).sum().backward()
+        out = [q.detach(), k.detach(), v.detach(), xl.grad] + [t.grad for p in pl for t in p]
+        xr, sl = x.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+        wl, bl = wr.clone().requires_grad_(True), br.clone().requires_grad_(True)
+        z = QF.linear_act(xr, wl, bl, residual=sl, act=1)
+        (z * dys[0]).sum().backward()
+        out += [z.detach(), xr.grad, sl.grad, wl.grad, bl.grad]
+        res[mode] = out
+    ops.PRECISION = "bf16"
+    for a, b in zip(res["bf16"], res["f32"]):
+        assert rel_err(a, b) < 1.5e-2 and _cos(a, b) > 0.9999
+
+
 def test_bf16_train_step_tracks_fp32_step():
     """One README-shaped (narrower/shallower) training step in both modes from the same
     weights: loss within 2e-3 relative, flat gradient cosine similarity > 0.999."""

@@ -55,6 +55,13 @@ def test_train_step_matches_reference_step(tag, table):
     w_in, w_tg, pos = pipeline.slide(hr_in, hr_tg, window, g["rand_indices"])
     assert torch.equal(w_in.cpu(), g["hr_input"]) and torch.equal(w_tg.cpu(), g["hr_target"])
     assert torch.equal(pos.cpu(), g["pos"])
+    # the fused form (one kernel from the BMU indices to the window) gives the same tensors
+    f_in, f_lr, f_tg, f_pos = pipeline.tokenize_window(g["fmap"].cuda(), lr_cb, hr_cb, base, window,
+                                                       g["rand_indices"])
+    assert torch.equal(f_in, w_in) and torch.equal(f_tg, w_tg) and torch.equal(f_pos, pos)
+    assert (f_lr is None) if base else torch.equal(f_lr, lr_in)
+    n_in, _, n_tg, n_pos = pipeline.tokenize_window(g["fmap"].cuda(), lr_cb, hr_cb, base, None, None)
+    assert torch.equal(n_in, hr_in) and torch.equal(n_tg, hr_tg) and n_pos is None
     opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
     old = (QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO)
     try:
