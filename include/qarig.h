@@ -79,7 +79,9 @@ int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const float* B, i
  * fp32 epilogue as qarig_gemm_f32.  layout 0 = NT: A (M,K), B (N,K), reduction-contiguous
  * (forward x W^T; input gradient dT W with the W^T shadow as B); layout 1 = TN: A (K,M), B (K,N),
  * reduction-major (weight gradient dT^T x from the row-major activations, transposed on the LDS
- * read by ds_read_b64_tr_b16).  A, B: bf16 (16-bit) elements, lda / ldb in elements.
+ * read by ds_read_b64_tr_b16); layout 2 = NN: A (M,K) reduction-contiguous, B (K,N)
+ * reduction-major (input gradient dT W on the weight shadow exactly as stored: no W^T copy).
+ * A, B: bf16 (16-bit) elements, lda / ldb in elements.
  * C: fp32 output (may be NULL when Cb is given); Cb / Pb: optional bf16 copies of the output /
  * of the saved pre-activation for a consumer GEMM.  Shapes: qarig_gemm_lp_supported. */
 int qarig_gemm_lp_supported(int M, int N, int K, int splitk);

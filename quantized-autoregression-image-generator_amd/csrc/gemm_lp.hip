@@ -8,6 +8,8 @@
 //        (forward  x W^T;  input gradient  dT W  with the W^T shadow as B)
 //   TN:  C[M,N] = sum_k A[k][m] * B[k][n]      A (K,M), B (K,N) bf16, reduction-major
 //        (weight gradient  dT^T x: both operands are the row-major activations as they lie)
+//   NN:  C[M,N] = sum_k A[m][k] * B[k][n]      A (M,K) reduction-contiguous, B (K,N) reduction-major
+//        (input gradient  dT W  on the weight shadow AS STORED (N_out,K_in): no W^T copy)
 //
 // Tile 128 x 128 x 64, 4 waves (2x2), each wave 2x2 accumulators of 32x32; the operand tiles
 // go global -> LDS by global_load_lds_dwordx4 (no VGPR staging) into a 2-stage ring, one
@@ -87,7 +89,7 @@ __device__ __forceinline__ void lp_frag(const bf16_t* tile, int x0, int ks, int 
     }
 }
 
-template <bool TN>
+template <bool TNA, bool TNB>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_lp_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                               const bf16_t* __restrict__ B, int64_t ldb,
                                                               GemmEpilogue ep, int M, int N, int K,
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_lp_kernel(const bf16_t* __re
     Acc acc;
     acc_zero(acc);
     if (nk > 0) {
-        lp_stage<TN>(A, lda, m0, k_begin, lds, wave, lane);
-        lp_stage<TN>(B, ldb, n0, k_begin, lds + LP_OP, wave, lane);
+        lp_stage<TNA>(A, lda, m0, k_begin, lds, wave, lane);
+        lp_stage<TNB>(B, ldb, n0, k_begin, lds + LP_OP, wave, lane);
         for (int kt = 0; kt < nk; ++kt) {
             // this wave's DMAs of tile kt have landed, then (barrier) everybody's; the same barrier
             // retires all reads of tile kt-1, whose stage is refilled right after it
@@ -120,8 +122,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_lp_kernel(const bf16_t* __re
             const int st = kt & 1;
             if (kt + 1 < nk) {
                 const int kn = k_begin + (kt + 1) * LBK;
-                lp_stage<TN>(A, lda, m0, kn, lds + (st ^ 1) * LP_STAGE, wave, lane);
-                lp_stage<TN>(B, ldb, n0, kn, lds + (st ^ 1) * LP_STAGE + LP_OP, wave, lane);
+                lp_stage<TNA>(A, lda, m0, kn, lds + (st ^ 1) * LP_STAGE, wave, lane);
+                lp_stage<TNB>(B, ldb, n0, kn, lds + (st ^ 1) * LP_STAGE + LP_OP, wave, lane);
             }
             const bf16_t* ta = lds + st * LP_STAGE;
             const bf16_t* tb = ta + LP_OP;
@@ -130,8 +132,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_lp_kernel(const bf16_t* __re
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    lp_frag<TN>(ta, wm * 64 + i * 32, ks, lane, fa[ks][i]);
-                    lp_frag<TN>(tb, wn * 64 + i * 32, ks, lane, fb[ks][i]);
+                    lp_frag<TNA>(ta, wm * 64 + i * 32, ks, lane, fa[ks][i]);
+                    lp_frag<TNB>(tb, wn * 64 + i * 32, ks, lane, fb[ks][i]);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -170,36 +172,78 @@ __global__ void cast_bf16_tail_kernel(const float* __restrict__ src, bf16_t* __r
 // part[blockIdx.y][n] = sum of the block's CS_ROWS rows of column n (fixed order).  The bias
 // gradient of a Linear layer is the column sum of the same dT that the weight-gradient GEMM
 // needs in bf16, so one pass over dT yields both.
-constexpr int CS_ROWS = 64;
-__global__ __launch_bounds__(128) void cast_colsum_kernel(const float* __restrict__ src, int64_t ld,
+constexpr int CS_ROWS = 64;     // rows per block: 4 row groups of 16, combined in group order
+__global__ __launch_bounds__(512) void cast_colsum_kernel(const float* __restrict__ src, int64_t ld,
                                                           int M, int N, bf16_t* __restrict__ dst,
                                                           float* __restrict__ part) {
-    const int c = (blockIdx.x * 128 + threadIdx.x) * 4;
-    if (c >= N) return;
-    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    __shared__ float4 red[3][128];
+    const int ct = threadIdx.x & 127, rg = threadIdx.x >> 7;
+    const int c = (blockIdx.x * 128 + ct) * 4;
+    const bool in = c < N;
+    const int r0 = blockIdx.y * CS_ROWS + rg * 16, r1 = min(M, r0 + 16);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = r0; r < r1; ++r) {
-        const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + c);
-        if (dst)
-            *reinterpret_cast<uint2*>(dst + (int64_t)r * N + c) =
-                make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    if (in)
+        for (int r = r0; r < r1; ++r) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + c);
+            if (dst)
+                *reinterpret_cast<uint2*>(dst + (int64_t)r * N + c) =
+                    make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    if (rg > 0) red[rg - 1][ct] = s;
+    __syncthreads();
+    if (rg == 0 && in) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float4 t = red[g][ct];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * N + c) = s;
     }
-    *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * N + c) = s;
 }
 // the same sums from a bf16 tensor (dT1 of an MLP exists only in bf16 in this mode)
-__global__ __launch_bounds__(128) void colsum_bf16_kernel(const bf16_t* __restrict__ src, int64_t ld,
+__global__ __launch_bounds__(512) void colsum_bf16_kernel(const bf16_t* __restrict__ src, int64_t ld,
                                                           int M, int N, float* __restrict__ part) {
-    const int c = (blockIdx.x * 128 + threadIdx.x) * 4;
-    if (c >= N) return;
-    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    __shared__ float4 red[3][128];
+    const int ct = threadIdx.x & 127, rg = threadIdx.x >> 7;
+    const int c = (blockIdx.x * 128 + ct) * 4;
+    const bool in = c < N;
+    const int r0 = blockIdx.y * CS_ROWS + rg * 16, r1 = min(M, r0 + 16);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = r0; r < r1; ++r) {
-        const uint2 v = *reinterpret_cast<const uint2*>(src + (int64_t)r * ld + c);
-        s.x += bf16_bits_to_f32(v.x & 0xffffu); s.y += bf16_bits_to_f32(v.x >> 16);
-        s.z += bf16_bits_to_f32(v.y & 0xffffu); s.w += bf16_bits_to_f32(v.y >> 16);
+    if (in)
+        for (int r = r0; r < r1; ++r) {
+            const uint2 v = *reinterpret_cast<const uint2*>(src + (int64_t)r * ld + c);
+            s.x += bf16_bits_to_f32(v.x & 0xffffu); s.y += bf16_bits_to_f32(v.x >> 16);
+            s.z += bf16_bits_to_f32(v.y & 0xffffu); s.w += bf16_bits_to_f32(v.y >> 16);
+        }
+    if (rg > 0) red[rg - 1][ct] = s;
+    __syncthreads();
+    if (rg == 0 && in) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float4 t = red[g][ct];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * N + c) = s;
     }
-    *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * N + c) = s;
+}
+// out[n] (+)= sum over the `chunks` partial rows, in a fixed order: 4 interleaved chunk groups per
+// column summed in parallel, then combined in group order (a serial walk over 128+ chunks is
+// latency-bound: 15 us per bias gradient)
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int chunks,
+                                                            int N, float* __restrict__ out, int accumulate) {
+    __shared__ float red[3][64];
+    const int ct = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + ct;
+    float s = 0.0f;
+    if (c < N)
+        for (int z = g; z < chunks; z += 4) s += part[(int64_t)z * N + c];
+    if (g > 0) red[g - 1][ct] = s;
+    __syncthreads();
+    if (g == 0 && c < N) {
+        s = ((s + red[0][ct]) + red[1][ct]) + red[2][ct];
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 // dst[c][r] = bf16(src[r][c]) for src (R, C) row-major with leading dimension lds_: the W^T
@@ -287,7 +331,7 @@ extern "C" int qarig_cast_colsum(const void* src, int64_t ld, int src_is_bf16, i
         return QARIG_ERR_WORKSPACE;
     }
     const int chunks = (M + CS_ROWS - 1) / CS_ROWS;
-    dim3 grid((N / 4 + 127) / 128, chunks), block(128);
+    dim3 grid((N / 4 + 127) / 128, chunks), block(512);
     hipStream_t st = (hipStream_t)stream;
     if (src_is_bf16)
         hipLaunchKernelGGL(colsum_bf16_kernel, grid, block, 0, st, (const bf16_t*)src, ld, M, N, (float*)workspace);
@@ -295,7 +339,10 @@ extern "C" int qarig_cast_colsum(const void* src, int64_t ld, int src_is_bf16, i
         hipLaunchKernelGGL(cast_colsum_kernel, grid, block, 0, st, (const float*)src, ld, M, N, (bf16_t*)dst,
                            (float*)workspace);
     QARIG_CHECK_LAUNCH("cast_colsum");
-    return qarig_slab_reduce_f32((const float*)workspace, colsum, N, 1, N, chunks, accumulate, stream);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 63) / 64), dim3(256), 0, st, (const float*)workspace,
+                       chunks, N, colsum, accumulate);
+    QARIG_CHECK_LAUNCH("cast_colsum reduce");
+    return QARIG_OK;
 }
 
 extern "C" size_t qarig_gemm_lp_workspace_bytes(int M, int N, int splitk) {
@@ -322,7 +369,7 @@ extern "C" int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t 
                              int accumulate, void* Cb, int64_t ldcb, void* Pb, int64_t ldpb,
                              void* workspace, size_t ws_bytes, void* stream) {
     QARIG_CHECK_ARG(A && B && (C || Cb), "gemm_lp: null operand");
-    QARIG_CHECK_ARG(layout == 0 || layout == 1, "gemm_lp: layout must be 0 (NT) or 1 (TN)");
+    QARIG_CHECK_ARG(layout >= 0 && layout <= 2, "gemm_lp: layout must be 0 (NT), 1 (TN) or 2 (NN)");
     QARIG_CHECK_ARG(act >= 0 && act <= 3 && gact >= 0 && gact <= 3, "gemm_lp: bad activation id");
     if (splitk < 1) splitk = 1;
     QARIG_CHECK_ARG(qarig_gemm_lp_supported(M, N, K, splitk),
@@ -358,10 +405,13 @@ extern "C" int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t 
                     gradz_is_bf16 ? (const unsigned short*)gradz : nullptr, ldz};
     hipStream_t st = (hipStream_t)stream;
     if (layout == 0)
-        hipLaunchKernelGGL((gemm_lp_kernel<false>), grid, block, 0, st, (const bf16_t*)A, lda,
+        hipLaunchKernelGGL((gemm_lp_kernel<false, false>), grid, block, 0, st, (const bf16_t*)A, lda,
+                           (const bf16_t*)B, ldb, ep, M, N, K, tiles_n, splitk, (float*)workspace);
+    else if (layout == 1)
+        hipLaunchKernelGGL((gemm_lp_kernel<true, true>), grid, block, 0, st, (const bf16_t*)A, lda,
                            (const bf16_t*)B, ldb, ep, M, N, K, tiles_n, splitk, (float*)workspace);
     else
-        hipLaunchKernelGGL((gemm_lp_kernel<true>), grid, block, 0, st, (const bf16_t*)A, lda,
+        hipLaunchKernelGGL((gemm_lp_kernel<false, true>), grid, block, 0, st, (const bf16_t*)A, lda,
                            (const bf16_t*)B, ldb, ep, M, N, K, tiles_n, splitk, (float*)workspace);
     QARIG_CHECK_LAUNCH("gemm_lp");
     if (splitk > 1)

@@ -11,8 +11,9 @@ up to bf16 rounding of the GEMM operands):
  * the narrow (512-wide) GEMM inputs that other kernels produce in fp32 (LayerNorm output,
    attention output, incoming gradients) are cast once per node; the cast of an incoming gradient
    also yields the bias gradient (column sums ride on the same pass: qarig_cast_colsum);
- * weights keep fp32 masters (Adam is unchanged); bf16 shadows in both layouts (W for forward,
-   W^T for the input gradient) are refreshed once per optimiser step (qarig.ops cache);
+ * weights keep fp32 masters (Adam is unchanged); ONE bf16 shadow per weight, as stored (N,K), is
+   refreshed once per optimiser step (qarig.ops cache): the forward reads it reduction-contiguous,
+   the input gradient reduction-major (transposed on the LDS read), so no W^T copy exists;
  * weight gradients are TN products of the row-major bf16 activations as they lie (transposed on
    the LDS read), accumulated in fp32 straight into the parameter's .grad.
 """
@@ -143,14 +144,14 @@ class _MLP2LP(torch.autograd.Function):
         dT2 = ops.act_bwd(dy2, t2, act2) if act2 else dy2
         db2, dT2b = _bias_grad(dT2, b2 if ctx.needs_input_grad[4] else None, N, True)
         dT1b = torch.empty((M, H), dtype=torch.bfloat16, device=dy2.device)
-        ops.gemm_lp(dT2b, _shadow(w2, transpose=True, pad_rows=Np), 0, M, H, Np,
+        ops.gemm_lp(dT2b, _shadow(w2, pad_rows=Np), 2, M, H, Np,
                     gradz=t1b if act1 else None, gact=act1, Cb=dT1b)
         dw2 = _wgrad(dT2b, hb, w2, N) if ctx.needs_input_grad[3] else None
         db1, _ = _bias_grad(dT1b, b1 if ctx.needs_input_grad[2] else None, H, False)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
-            ops.gemm_lp(dT1b, _shadow(w1, transpose=True), 0, M, K, H, C=dx)
+            ops.gemm_lp(dT1b, _shadow(w1), 2, M, K, H, C=dx)
             dx = dx.reshape(shp)
         dw1 = _wgrad(dT1b, xb, w1, H) if ctx.needs_input_grad[1] else None
         return dx, dw1, db1, dw2, db2, None, None
@@ -201,16 +202,16 @@ class _MLP2x3LP(torch.autograd.Function):
             dT2 = ops.act_bwd(dy2, t2, act2) if act2 else dy2
             db2, dT2b = _bias_grad(dT2, b2 if ctx.needs_input_grad[ni + 3] else None, N, True)
             dT1b = torch.empty((M, H), dtype=torch.bfloat16, device=dy2.device)
-            ops.gemm_lp(dT2b, _shadow(w2, transpose=True), 0, M, H, N, gradz=t1b if act1 else None,
+            ops.gemm_lp(dT2b, _shadow(w2), 2, M, H, N, gradz=t1b if act1 else None,
                         gact=act1, Cb=dT1b)
             dw2 = _wgrad(dT2b, hb, w2, N) if ctx.needs_input_grad[ni + 2] else None
             db1, _ = _bias_grad(dT1b, b1 if ctx.needs_input_grad[ni + 1] else None, H, False)
             if ctx.needs_input_grad[0]:
                 if dx is None:
                     dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
-                    ops.gemm_lp(dT1b, _shadow(w1, transpose=True), 0, M, K, H, C=dx)
+                    ops.gemm_lp(dT1b, _shadow(w1), 2, M, K, H, C=dx)
                 else:
-                    ops.gemm_lp(dT1b, _shadow(w1, transpose=True), 0, M, K, H, C=dx, accumulate=True)
+                    ops.gemm_lp(dT1b, _shadow(w1), 2, M, K, H, C=dx, accumulate=True)
             dw1 = _wgrad(dT1b, xb, w1, H) if ctx.needs_input_grad[ni] else None
             grads += [dw1, db1, dw2, db2]
         if dx is not None:
@@ -251,7 +252,7 @@ class _LinearActLP(torch.autograd.Function):
         dx = dw = dr = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
-            ops.gemm_lp(dTb, _shadow(weight, transpose=True), 0, M, K, N, C=dx)
+            ops.gemm_lp(dTb, _shadow(weight), 2, M, K, N, C=dx)
             dx = dx.reshape(shp)
         if ctx.needs_input_grad[1]:
             dw = _wgrad(dTb, xb, weight, N)

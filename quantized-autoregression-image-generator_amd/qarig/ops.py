@@ -220,7 +220,7 @@ def _gemm_lp(lib, A, B, a_kcontig, b_kcontig, C, pre, M, N, K, bias, residual, a
     multiplied by qarig_gemm_lp.  Returns False when the shape is not an interior one (the
     caller then runs the fp32 kernels).  The three Linear products map to
         forward   (kc, kc): NT on  x_bf (M,K)    and W_bf (N,K)
-        d-input   (kc, xc): NT on  dT_bf (M,N')  and the W^T shadow (K',N')
+        d-input   (kc, xc): NN on  dT_bf (M,N')  and the weight shadow as stored (N',K')
         d-weight  (xc, xc): TN on  dT_bf, x_bf as they lie (row-major, reduction-major)."""
     if a_kcontig == (not b_kcontig) and not a_kcontig:
         return False                       # (xc, kc) never occurs on the hot path
@@ -246,9 +246,11 @@ def _gemm_lp(lib, A, B, a_kcontig, b_kcontig, C, pre, M, N, K, bias, residual, a
         B_bf = cast_bf16(B if B.is_contiguous() else B.contiguous(), cache=_is_param_like(B))
         layout = 0
     elif a_kcontig:                        # d-input: B is (K_red, N_out) = the weight as stored
+        if B.stride(0) % 8 or not B.is_contiguous():
+            return False
         A_bf = cast_bf16(A if A.is_contiguous() else A.contiguous())
-        B_bf = cast_transpose_bf16(B, cache=_is_param_like(B))
-        layout = 0
+        B_bf = cast_bf16(B, cache=_is_param_like(B))
+        layout = 2
     else:                                  # d-weight
         A_bf = cast_bf16(A if A.is_contiguous() else A.contiguous())
         B_bf = cast_bf16(B if B.is_contiguous() else B.contiguous())

@@ -41,7 +41,7 @@ def test_cast_kernels_round_to_nearest_even():
     assert torch.equal(v, x[:, :128].bfloat16().t().contiguous())
 
 
-@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 def test_lp_fragment_maps_on_exact_integer_data(layout):
     """A = a permutation-like integer matrix, B asymmetric small integers: every product and sum
     is exact in bf16/fp32, so any wrong lane map, swizzle or transposed read shows as a wrong
@@ -54,10 +54,12 @@ def test_lp_fragment_maps_on_exact_integer_data(layout):
     A[torch.arange(M), torch.randint(0, K, (M,), generator=g)] += 2.0
     B = torch.randint(-8, 9, (N, K), generator=g).float() + torch.arange(N)[:, None] % 5
     ref = A.double() @ B.double().t()
-    if layout == 0:
+    if layout == 0:      # NT
         Ab, Bb = A.cuda().bfloat16(), B.cuda().bfloat16()
-    else:
+    elif layout == 1:    # TN
         Ab, Bb = A.t().contiguous().cuda().bfloat16(), B.t().contiguous().cuda().bfloat16()
+    else:                # NN: A reduction-contiguous, B reduction-major
+        Ab, Bb = A.cuda().bfloat16(), B.t().contiguous().cuda().bfloat16()
     C = torch.empty((M, N), device="cuda")
     Cb = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
     ops.gemm_lp(Ab, Bb, layout, M, N, K, C=C, Cb=Cb)
