@@ -654,8 +654,8 @@ static int attn_check(int N, int Sq, int Sk, int H, int d, int causal) {
 }
 
 // Launch geometry: a workgroup covers 4 adjacent heads x (W x 64) rows (queries; keys in the
-// dK/dV pass), W waves per head.  W = 4 reads a 256-token sequence's K/V exactly once; the
-// backward passes hold more LDS per chunk (three / four images), so they default to W = 2.
+// dK/dV pass), W waves per head.  W = 4 reads a 256-token sequence's K/V exactly once but leaves
+// one 16-wave workgroup per CU; all three passes default to W = 2.
 // QARIG_ATTN_QW / QARIG_ATTN_BW override (1, 2 or 4; tuning knob, any value is correct).
 static int attn_waves(int rows, int d, const char* env, int dflt, int wmax) {
     int w = dflt;
@@ -702,7 +702,10 @@ extern "C" int qarig_attention_fwd(const float* q, const float* k, const float* 
     QARIG_CHECK_ARG(q && k && v && o && lse, "attention_fwd: null pointer");
     if (int e = attn_check(N, Sq, Sk, H, d, causal)) return e;
     AttnDims a{N, Sq, Sk, H, causal, 1.4426950408889634f / sqrt_d, 1.0f / sqrt_d};
-    const int W = attn_waves(Sq, d, "QARIG_ATTN_QW", 4, d <= 16 ? 4 : 2);
+    // measured (tools/attn_bench.py, 64 x 256 tokens, 64 heads of 8): W = 1 / 2 / 4 -> 100 / 100 /
+    // 124 us; W = 2 reads K and V 1.5x (1.25x of the launch's algorithmic bytes in all) where
+    // W = 1 reads them 2.5x, and keeps two workgroups per CU to even out the causal imbalance
+    const int W = attn_waves(Sq, d, "QARIG_ATTN_QW", 2, d <= 16 ? 4 : 2);
     const int threads = 256 * W, rows = 64 * W;
     const size_t lds = attn_lds_bytes(threads, d, 1, 1, false);
     dim3 grid((unsigned)(N * ((H + HPB - 1) / HPB) * ((Sq + rows - 1) / rows))), block(threads);
