@@ -210,6 +210,16 @@ int qarig_attention_bwd(const float* q, const float* k, const float* v, const fl
                         int causal, float sqrt_d, float* dq, float* dk, float* dv, float* delta,
                         void* stream);
 
+/* The same attention (models/layers.py:433-474) with the QK^T / PV products and their backward
+ * counterparts on the bf16 MFMA (operands rounded to bf16; fp32 accumulation, softmax, LSE and
+ * tensors): BASELINE config 5's reduced-precision attention.  Opt-in; same arguments. */
+int qarig_attention_lp_fwd(const float* q, const float* k, const float* v, int N, int Sq, int Sk, int H,
+                           int d, int causal, float sqrt_d, float* o, float* lse, void* stream);
+int qarig_attention_lp_bwd(const float* q, const float* k, const float* v, const float* o,
+                           const float* dO, const float* lse, int N, int Sq, int Sk, int H, int d,
+                           int causal, float sqrt_d, float* dq, float* dk, float* dv, float* delta,
+                           void* stream);
+
 /* Single-token decode step against a KV cache.  The reference has no cache: it re-runs the
  * whole window for every sampled token (generate_images.py:283-307,
  * train_quantized_transformer.py:600-640); this computes the same attention row

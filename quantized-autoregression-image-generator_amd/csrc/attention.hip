@@ -54,13 +54,33 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
+// Precision of the two contractions.  LP = false: fp32 operands, v_mfma_f32_4x4x1_16B_f32 (the
+// parity mode: an exact fp32 fma chain).  LP = true (BASELINE config 5, opt-in): operands rounded
+// to bf16 on their way into LDS / registers, v_mfma_f32_4x4x4_16B_bf16 contracts four c's (S, dP)
+// or four keys / queries (PV, dQ, dK, dV) per instruction; accumulators, softmax, LSE and all
+// tensors in HBM stay fp32.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
+__device__ __forceinline__ s16x4 pack4_bf16(float a, float b, float c, float d) {
+    const uint2 u = make_uint2(pack2_bf16(a, b), pack2_bf16(c, d));
+    return __builtin_bit_cast(s16x4, u);
+}
+template <bool LP> struct Elem { typedef float T; };
+template <> struct Elem<true> { typedef unsigned short T; };
+
 // Geometry shared by the three kernels.  A chunk holds CH rows (keys, or queries in the dK/dV
 // pass) of the workgroup's 4 heads; every thread moves exactly one float4 per tensor per chunk.
-//   row image  R[row][4*HD + 4]   : fragment = 16-B reads of row (r0 + lane%4): conflict-free
-//   transposed T[4*HD][CH + 4]    : fragment = 16-B reads of column group (4g + lane%4)
+//   row image  R[row][4*HD + 4]   : fragment = reads of row (r0 + lane%4): conflict-free
+//   transposed T[4*HD][CH + 4]    : fragment = reads of column group (4g + lane%4)
+// (elements are fp32, or bf16 in the reduced-precision mode; strides in elements)
 template <int HD>
 struct Geo {
-    static constexpr int W = HPB * HD;       // floats per staged row
+    static constexpr int W = HPB * HD;       // elements per staged row
     static constexpr int V4 = W / 4;         // float4 per staged row
     static constexpr int RS = W + 4;         // row-image stride
     __device__ static int chunk_rows() { return blockDim.x / V4; }
@@ -78,28 +98,91 @@ __device__ __forceinline__ float4 chunk_load(const float* __restrict__ base, int
         v = *reinterpret_cast<const float4*>(base + (int64_t)(row0 + r) * D + c4 * 4);
     return v;
 }
-template <int HD>
-__device__ __forceinline__ void chunk_store_rows(float* R, float4 v) {
+template <int HD, typename T>
+__device__ __forceinline__ void chunk_store_rows(T* R, float4 v) {
     const int f = threadIdx.x;
     const int r = f / Geo<HD>::V4, c4 = f - r * Geo<HD>::V4;
-    *reinterpret_cast<float4*>(R + r * Geo<HD>::RS + c4 * 4) = v;
+    if constexpr (sizeof(T) == 4)
+        *reinterpret_cast<float4*>(R + r * Geo<HD>::RS + c4 * 4) = v;
+    else
+        *reinterpret_cast<uint2*>(R + r * Geo<HD>::RS + c4 * 4) =
+            make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
 }
-template <int HD>
-__device__ __forceinline__ void chunk_store_transposed(float* T, int ts, float4 v) {
+template <int HD, typename T>
+__device__ __forceinline__ void chunk_store_transposed(T* Tp, int ts, float4 v) {
     const int f = threadIdx.x;
     const int r = f / Geo<HD>::V4, c4 = f - r * Geo<HD>::V4;
-    float* t = T + (c4 * 4) * ts + r;
-    t[0] = v.x; t[ts] = v.y; t[2 * ts] = v.z; t[3 * ts] = v.w;
+    T* t = Tp + (c4 * 4) * ts + r;
+    if constexpr (sizeof(T) == 4) {
+        t[0] = v.x; t[ts] = v.y; t[2 * ts] = v.z; t[3 * ts] = v.w;
+    } else {
+        const uint32_t lo = pack2_bf16(v.x, v.y), hi = pack2_bf16(v.z, v.w);
+        t[0] = (T)(lo & 0xffffu); t[ts] = (T)(lo >> 16);
+        t[2 * ts] = (T)(hi & 0xffffu); t[3 * ts] = (T)(hi >> 16);
+    }
+}
+
+// The lane's own row (query, or key in the dK/dV pass): the B operand of the c-contractions.
+template <bool LP, int HD> struct Own { float f[HD]; };
+template <int HD> struct Own<true, HD> { s16x4 b[HD / 4]; };
+template <bool LP, int HD>
+__device__ __forceinline__ void own_load(Own<LP, HD>& o, const float* p, bool active) {
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) t = *reinterpret_cast<const float4*>(p + c);
+        if constexpr (LP) o.b[c / 4] = pack4_bf16(t.x, t.y, t.z, t.w);
+        else { o.f[c] = t.x; o.f[c + 1] = t.y; o.f[c + 2] = t.z; o.f[c + 3] = t.w; }
+    }
+}
+// s[i] += sum_c R[row i = lane%4 of the 4 staged rows][c] * own[c]   (c ascending)
+template <bool LP, int HD, typename T>
+__device__ __forceinline__ void dot_rows(f32x4& s, const T* rowp, const Own<LP, HD>& own) {
+#pragma unroll
+    for (int g = 0; g < HD / 4; ++g) {
+        if constexpr (LP) {
+            const s16x4 ka = *reinterpret_cast<const s16x4*>(rowp + 4 * g);
+            s = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ka, own.b[g], s, 0, 0, 0);
+        } else {
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(rowp + 4 * g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s = mfma4(ka[c], own.f[4 * g + c], s);
+        }
+    }
+}
+// Four per-lane values (probabilities / score gradients of 4 consecutive staged rows).
+template <bool LP> struct Vals { float v[4]; };
+template <> struct Vals<true> { s16x4 b; };
+template <bool LP>
+__device__ __forceinline__ Vals<LP> make_vals(float a, float b, float c, float d) {
+    Vals<LP> r;
+    if constexpr (LP) r.b = pack4_bf16(a, b, c, d);
+    else { r.v[0] = a; r.v[1] = b; r.v[2] = c; r.v[3] = d; }
+    return r;
+}
+// o[i] += sum over the 4 staged rows r of T[column 4g + i][r] * vals[r]   (r ascending)
+template <bool LP, typename T>
+__device__ __forceinline__ void acc_cols(f32x4& o, const T* trp, const Vals<LP>& x) {
+    if constexpr (LP) {
+        const s16x4 va = *reinterpret_cast<const s16x4*>(trp);
+        o = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(va, x.b, o, 0, 0, 0);
+    } else {
+        const f32x4 va = *reinterpret_cast<const f32x4*>(trp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o = mfma4(va[r], x.v[r], o);
+    }
 }
 
 // Forward.  Lane = query; wave = (head hh = wave % 4, query slice qq = wave / 4).
-template <int HD, int MAXT>
+template <int HD, int MAXT, bool LP>
 __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const float* __restrict__ q,
                                                         const float* __restrict__ k,
                                                         const float* __restrict__ v, AttnDims a,
                                                         float* __restrict__ o,
                                                         float* __restrict__ lse) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef typename Elem<LP>::T T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
     constexpr int G = HD / 4;
     const int CH = Geo<HD>::chunk_rows();
     const int TS = CH + 4;
@@ -129,16 +212,8 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const float* __restrict_
     const int BUF = CH * Geo<HD>::RS + Geo<HD>::W * TS;
     const int VOFF = CH * Geo<HD>::RS;
 
-    float qv[HD];
-    {
-        const float* qp = q + ((int64_t)n * a.Sq + (active ? i : 0)) * D + h * HD;
-#pragma unroll
-        for (int c = 0; c < HD; c += 4) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (active) t = *reinterpret_cast<const float4*>(qp + c);
-            qv[c] = t.x; qv[c + 1] = t.y; qv[c + 2] = t.z; qv[c + 3] = t.w;
-        }
-    }
+    Own<LP, HD> qv;
+    own_load<LP, HD>(qv, q + ((int64_t)n * a.Sq + (active ? i : 0)) * D + h * HD, active);
     f32x4 ov[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) ov[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -161,24 +236,16 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const float* __restrict_
             rk = chunk_load<HD>(kb, D, c0 + CH, a.Sk, cols_valid);
             rv = chunk_load<HD>(vb, D, c0 + CH, a.Sk, cols_valid);
         }
-        const float* Kc = smem + (t & 1) * BUF + hh * HD;
-        const float* Vc = smem + (t & 1) * BUF + VOFF + (hh * HD) * TS;
+        const T* Kc = smem + (t & 1) * BUF + hh * HD;
+        const T* Vc = smem + (t & 1) * BUF + VOFF + (hh * HD) * TS;
         const int jw = min(c0 + CH, jend);
         for (int j0 = c0; j0 < jw; j0 += 8) {
             const int jj = j0 - c0;
             // S^T for 8 keys: two accumulators (keys jj..jj+3, jj+4..jj+7), c ascending
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-            const float* kr = Kc + (jj + li) * Geo<HD>::RS;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const f32x4 ka = *reinterpret_cast<const f32x4*>(kr + 4 * g);
-                const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kr + 4 * Geo<HD>::RS + 4 * g);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    s0 = mfma4(ka[c], qv[4 * g + c], s0);
-                    s1 = mfma4(kb4[c], qv[4 * g + c], s1);
-                }
-            }
+            const T* kr = Kc + (jj + li) * Geo<HD>::RS;
+            dot_rows<LP, HD>(s0, kr, qv);
+            dot_rows<LP, HD>(s1, kr + 4 * Geo<HD>::RS, qv);
             float sc[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { sc[r] = s0[r] * a.c2; sc[4 + r] = s1[r] * a.c2; }
@@ -200,15 +267,13 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const float* __restrict_
             for (int r = 0; r < 8; ++r) { p[r] = exp2_fast(sc[r] - msafe); l += p[r]; }
             m = mn;
             // PV: keys ascending per output column group
+            const Vals<LP> pa = make_vals<LP>(p[0], p[1], p[2], p[3]);
+            const Vals<LP> pb = make_vals<LP>(p[4], p[5], p[6], p[7]);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const float* vr = Vc + (4 * g + li) * TS + jj;
-                const f32x4 va = *reinterpret_cast<const f32x4*>(vr);
-                const f32x4 vb4 = *reinterpret_cast<const f32x4*>(vr + 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ov[g] = mfma4(va[r], p[r], ov[g]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ov[g] = mfma4(vb4[r], p[4 + r], ov[g]);
+                const T* vr = Vc + (4 * g + li) * TS + jj;
+                acc_cols<LP>(ov[g], vr, pa);
+                acc_cols<LP>(ov[g], vr + 4, pb);
             }
         }
         if (t + 1 < nchunks) {
@@ -230,12 +295,14 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const float* __restrict_
 
 // dQ pass: lane = query; per chunk the K rows, V rows and K transposed.  Also emits
 // delta[i] = sum_c dO[i][c] * O[i][c].
-template <int HD, int MAXT>
+template <int HD, int MAXT, bool LP>
 __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ o, const float* __restrict__ dO, const float* __restrict__ lse,
     AttnDims a, float* __restrict__ dq, float* __restrict__ delta) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef typename Elem<LP>::T T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
     constexpr int G = HD / 4;
     const int CH = Geo<HD>::chunk_rows();
     const int TS = CH + 4;
@@ -263,18 +330,17 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(
     const int VOFF = CH * Geo<HD>::RS, TOFF = 2 * CH * Geo<HD>::RS;
 
     const int64_t roff = ((int64_t)n * a.Sq + (active ? i : 0)) * D + h * HD;
-    float qv[HD], dov[HD];
-    float dl = 0.0f;
+    Own<LP, HD> qv, dov;
+    own_load<LP, HD>(qv, q + roff, active);
+    own_load<LP, HD>(dov, dO + roff, active);
+    float dl = 0.0f;                     // delta from the fp32 tensors in both modes
 #pragma unroll
     for (int c = 0; c < HD; c += 4) {
-        float4 tq = make_float4(0.f, 0.f, 0.f, 0.f), tg = tq, to = tq;
+        float4 tg = make_float4(0.f, 0.f, 0.f, 0.f), to = tg;
         if (active) {
-            tq = *reinterpret_cast<const float4*>(q + roff + c);
             tg = *reinterpret_cast<const float4*>(dO + roff + c);
             to = *reinterpret_cast<const float4*>(o + roff + c);
         }
-        qv[c] = tq.x; qv[c + 1] = tq.y; qv[c + 2] = tq.z; qv[c + 3] = tq.w;
-        dov[c] = tg.x; dov[c + 1] = tg.y; dov[c + 2] = tg.z; dov[c + 3] = tg.w;
         dl = fmaf(tg.x, to.x, dl); dl = fmaf(tg.y, to.y, dl);
         dl = fmaf(tg.z, to.z, dl); dl = fmaf(tg.w, to.w, dl);
     }
@@ -301,29 +367,19 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(
             rk = chunk_load<HD>(kb, D, c0 + CH, a.Sk, cols_valid);
             rv = chunk_load<HD>(vb, D, c0 + CH, a.Sk, cols_valid);
         }
-        const float* Kc = smem + (t & 1) * BUF + hh * HD;
-        const float* Vc = smem + (t & 1) * BUF + VOFF + hh * HD;
-        const float* Tc = smem + (t & 1) * BUF + TOFF + (hh * HD) * TS;
+        const T* Kc = smem + (t & 1) * BUF + hh * HD;
+        const T* Vc = smem + (t & 1) * BUF + VOFF + hh * HD;
+        const T* Tc = smem + (t & 1) * BUF + TOFF + (hh * HD) * TS;
         const int jw = min(c0 + CH, jend);
         for (int j0 = c0; j0 < jw; j0 += 8) {
             const int jj = j0 - c0;
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
-            const float* kr = Kc + (jj + li) * Geo<HD>::RS;
-            const float* vr = Vc + (jj + li) * Geo<HD>::RS;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const f32x4 ka = *reinterpret_cast<const f32x4*>(kr + 4 * g);
-                const f32x4 kb4 = *reinterpret_cast<const f32x4*>(kr + 4 * Geo<HD>::RS + 4 * g);
-                const f32x4 va = *reinterpret_cast<const f32x4*>(vr + 4 * g);
-                const f32x4 vb4 = *reinterpret_cast<const f32x4*>(vr + 4 * Geo<HD>::RS + 4 * g);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    s0 = mfma4(ka[c], qv[4 * g + c], s0);
-                    s1 = mfma4(kb4[c], qv[4 * g + c], s1);
-                    d0 = mfma4(va[c], dov[4 * g + c], d0);
-                    d1 = mfma4(vb4[c], dov[4 * g + c], d1);
-                }
-            }
+            const T* kr = Kc + (jj + li) * Geo<HD>::RS;
+            const T* vr = Vc + (jj + li) * Geo<HD>::RS;
+            dot_rows<LP, HD>(s0, kr, qv);
+            dot_rows<LP, HD>(s1, kr + 4 * Geo<HD>::RS, qv);
+            dot_rows<LP, HD>(d0, vr, dov);
+            dot_rows<LP, HD>(d1, vr + 4 * Geo<HD>::RS, dov);
             float ds[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -335,19 +391,17 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(
                 for (int r = 0; r < 8; ++r)
                     if (j0 + r >= jw || (a.causal && j0 + r > i)) ds[r] = 0.0f;
             }
+            const Vals<LP> da = make_vals<LP>(ds[0], ds[1], ds[2], ds[3]);
+            const Vals<LP> db = make_vals<LP>(ds[4], ds[5], ds[6], ds[7]);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const float* tr = Tc + (4 * g + li) * TS + jj;
-                const f32x4 ta = *reinterpret_cast<const f32x4*>(tr);
-                const f32x4 tb = *reinterpret_cast<const f32x4*>(tr + 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[g] = mfma4(ta[r], ds[r], acc[g]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[g] = mfma4(tb[r], ds[4 + r], acc[g]);
+                const T* tr = Tc + (4 * g + li) * TS + jj;
+                acc_cols<LP>(acc[g], tr, da);
+                acc_cols<LP>(acc[g], tr + 4, db);
             }
         }
         if (t + 1 < nchunks) {
-            float* nb = smem + ((t + 1) & 1) * BUF;
+            T* nb = smem + ((t + 1) & 1) * BUF;
             chunk_store_rows<HD>(nb, rk);
             chunk_store_rows<HD>(nb + VOFF, rv);
             chunk_store_transposed<HD>(nb + TOFF, TS, rk);
@@ -365,24 +419,24 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(
 
 // dK/dV pass: lane = key; per chunk of queries the Q rows, dO rows and both transposed, plus
 // the chunk's LSE and delta values (wave-uniform per query: read as LDS broadcasts).
-template <int HD, int MAXT>
+template <int HD, int MAXT, bool LP>
 __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ delta,
     AttnDims a, float* __restrict__ dk, float* __restrict__ dv) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef typename Elem<LP>::T T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
     constexpr int G = HD / 4;
     const int CH = Geo<HD>::chunk_rows();
     const int TS = CH + 4;
     const int KW = blockDim.x >> 8;
     const int KB = KW * 64;
-    const int kblocks = (a.Sk + KB - 1) / KB;
     const int hgroups = (a.H + HPB - 1) / HPB;
     int bid = blockIdx.x;
     const int hg = bid % hgroups; bid /= hgroups;
     const int n = bid % a.N; bid /= a.N;
     const int kbk = bid;                                // earliest key blocks are the heaviest (causal)
-    (void)kblocks;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hh = wave & 3, kq = wave >> 2;
@@ -394,23 +448,18 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(
     const bool active = head_ok && j < a.Sk;
     const int li = lane & 3;
     const int cols_valid = (a.H - hg * HPB) * HD;
-    // per buffer: Q rows | dO rows | Q^T | dO^T | LSE[4][CH] | delta[4][CH]
-    const int BUF = 2 * CH * Geo<HD>::RS + 2 * Geo<HD>::W * TS + 2 * HPB * CH;
+    // per buffer (elements of T): Q rows | dO rows | Q^T | dO^T; the LSE / delta arrays
+    // ([2 buffers][LSE[4][CH] | delta[4][CH]] floats) sit behind both image buffers
+    const int BUF = 2 * CH * Geo<HD>::RS + 2 * Geo<HD>::W * TS;
     const int GOFF = CH * Geo<HD>::RS, QTOFF = 2 * CH * Geo<HD>::RS;
-    const int GTOFF = QTOFF + Geo<HD>::W * TS, LOFF = GTOFF + Geo<HD>::W * TS, DOFF = LOFF + HPB * CH;
+    const int GTOFF = QTOFF + Geo<HD>::W * TS;
+    float* ldbase = reinterpret_cast<float*>(smem_raw + (((size_t)2 * BUF * sizeof(T) + 15) & ~(size_t)15));
+    const int LDBUF = 2 * HPB * CH;
 
     const int64_t roff = ((int64_t)n * a.Sk + (active ? j : 0)) * D + h * HD;
-    float kv[HD], vv[HD];
-#pragma unroll
-    for (int c = 0; c < HD; c += 4) {
-        float4 tk = make_float4(0.f, 0.f, 0.f, 0.f), tv = tk;
-        if (active) {
-            tk = *reinterpret_cast<const float4*>(k + roff + c);
-            tv = *reinterpret_cast<const float4*>(v + roff + c);
-        }
-        kv[c] = tk.x; kv[c + 1] = tk.y; kv[c + 2] = tk.z; kv[c + 3] = tk.w;
-        vv[c] = tv.x; vv[c + 1] = tv.y; vv[c + 2] = tv.z; vv[c + 3] = tv.w;
-    }
+    Own<LP, HD> kv, vv;
+    own_load<LP, HD>(kv, k + roff, active);
+    own_load<LP, HD>(vv, v + roff, active);
     f32x4 dka[G], dva[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) { dka[g] = f32x4{0.f, 0.f, 0.f, 0.f}; dva[g] = dka[g]; }
@@ -443,7 +492,7 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(
         chunk_store_rows<HD>(smem + GOFF, rg);
         chunk_store_transposed<HD>(smem + QTOFF, TS, rq);
         chunk_store_transposed<HD>(smem + GTOFF, TS, rg);
-        if (lth) { smem[LOFF + threadIdx.x] = rl; smem[DOFF + threadIdx.x] = rd; }
+        if (lth) { ldbase[threadIdx.x] = rl; ldbase[HPB * CH + threadIdx.x] = rd; }
     }
     __syncthreads();
     for (int t = 0; t < nchunks; ++t) {
@@ -453,13 +502,13 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(
             rg = chunk_load<HD>(gbase, D, c0 + CH, a.Sq, cols_valid);
             load_ld(c0 + CH, rl, rd);
         }
-        const float* cb = smem + (t & 1) * BUF;
-        const float* Qc = cb + hh * HD;
-        const float* Gc = cb + GOFF + hh * HD;
-        const float* QTc = cb + QTOFF + (hh * HD) * TS;
-        const float* GTc = cb + GTOFF + (hh * HD) * TS;
-        const float* Lc = cb + LOFF + hh * CH;
-        const float* Dc = cb + DOFF + hh * CH;
+        const T* cb = smem + (t & 1) * BUF;
+        const T* Qc = cb + hh * HD;
+        const T* Gc = cb + GOFF + hh * HD;
+        const T* QTc = cb + QTOFF + (hh * HD) * TS;
+        const T* GTc = cb + GTOFF + (hh * HD) * TS;
+        const float* Lc = ldbase + (t & 1) * LDBUF + hh * CH;
+        const float* Dc = Lc + HPB * CH;
         const int i1 = min(c0 + CH, a.Sq);
         // first 8-aligned step that holds a query this wave needs
         int i0 = c0;
@@ -467,22 +516,12 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(
         for (; i0 < i1; i0 += 8) {
             const int ii = i0 - c0;
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
-            const float* qr = Qc + (ii + li) * Geo<HD>::RS;
-            const float* gr = Gc + (ii + li) * Geo<HD>::RS;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const f32x4 qa = *reinterpret_cast<const f32x4*>(qr + 4 * g);
-                const f32x4 qb4 = *reinterpret_cast<const f32x4*>(qr + 4 * Geo<HD>::RS + 4 * g);
-                const f32x4 ga = *reinterpret_cast<const f32x4*>(gr + 4 * g);
-                const f32x4 gb4 = *reinterpret_cast<const f32x4*>(gr + 4 * Geo<HD>::RS + 4 * g);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    s0 = mfma4(qa[c], kv[4 * g + c], s0);
-                    s1 = mfma4(qb4[c], kv[4 * g + c], s1);
-                    d0 = mfma4(ga[c], vv[4 * g + c], d0);
-                    d1 = mfma4(gb4[c], vv[4 * g + c], d1);
-                }
-            }
+            const T* qr = Qc + (ii + li) * Geo<HD>::RS;
+            const T* gr = Gc + (ii + li) * Geo<HD>::RS;
+            dot_rows<LP, HD>(s0, qr, kv);
+            dot_rows<LP, HD>(s1, qr + 4 * Geo<HD>::RS, kv);
+            dot_rows<LP, HD>(d0, gr, vv);
+            dot_rows<LP, HD>(d1, gr + 4 * Geo<HD>::RS, vv);
             const f32x4 La = *reinterpret_cast<const f32x4*>(Lc + ii);
             const f32x4 Lb = *reinterpret_cast<const f32x4*>(Lc + ii + 4);
             const f32x4 Da = *reinterpret_cast<const f32x4*>(Dc + ii);
@@ -503,33 +542,45 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(
                 ds[r] = p[r] * (d0[r] - Da[r]);
                 ds[4 + r] = p[4 + r] * (d1[r] - Db[r]);
             }
+            const Vals<LP> pa = make_vals<LP>(p[0], p[1], p[2], p[3]);
+            const Vals<LP> pb = make_vals<LP>(p[4], p[5], p[6], p[7]);
+            const Vals<LP> da = make_vals<LP>(ds[0], ds[1], ds[2], ds[3]);
+            const Vals<LP> dbv = make_vals<LP>(ds[4], ds[5], ds[6], ds[7]);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const float* gt = GTc + (4 * g + li) * TS + ii;
-                const float* qt = QTc + (4 * g + li) * TS + ii;
-                const f32x4 ga = *reinterpret_cast<const f32x4*>(gt);
-                const f32x4 gb4 = *reinterpret_cast<const f32x4*>(gt + 4);
-                const f32x4 qa = *reinterpret_cast<const f32x4*>(qt);
-                const f32x4 qb4 = *reinterpret_cast<const f32x4*>(qt + 4);
+                const T* gt = GTc + (4 * g + li) * TS + ii;
+                const T* qt = QTc + (4 * g + li) * TS + ii;
+                if constexpr (LP) {
+                    acc_cols<LP>(dva[g], gt, pa);
+                    acc_cols<LP>(dka[g], qt, da);
+                    acc_cols<LP>(dva[g], gt + 4, pb);
+                    acc_cols<LP>(dka[g], qt + 4, dbv);
+                } else {       // the fp32 chains interleaved as before: dV and dK, query ascending
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(gt);
+                    const f32x4 gb4 = *reinterpret_cast<const f32x4*>(gt + 4);
+                    const f32x4 qa = *reinterpret_cast<const f32x4*>(qt);
+                    const f32x4 qb4 = *reinterpret_cast<const f32x4*>(qt + 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dva[g] = mfma4(ga[r], p[r], dva[g]);
-                    dka[g] = mfma4(qa[r], ds[r], dka[g]);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        dva[g] = mfma4(ga[r], p[r], dva[g]);
+                        dka[g] = mfma4(qa[r], ds[r], dka[g]);
+                    }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dva[g] = mfma4(gb4[r], p[4 + r], dva[g]);
-                    dka[g] = mfma4(qb4[r], ds[4 + r], dka[g]);
+                    for (int r = 0; r < 4; ++r) {
+                        dva[g] = mfma4(gb4[r], p[4 + r], dva[g]);
+                        dka[g] = mfma4(qb4[r], ds[4 + r], dka[g]);
+                    }
                 }
             }
         }
         if (t + 1 < nchunks) {
-            float* nb = smem + ((t + 1) & 1) * BUF;
+            T* nb = smem + ((t + 1) & 1) * BUF;
             chunk_store_rows<HD>(nb, rq);
             chunk_store_rows<HD>(nb + GOFF, rg);
             chunk_store_transposed<HD>(nb + QTOFF, TS, rq);
             chunk_store_transposed<HD>(nb + GTOFF, TS, rg);
-            if (lth) { nb[LOFF + threadIdx.x] = rl; nb[DOFF + threadIdx.x] = rd; }
+            float* nl = ldbase + ((t + 1) & 1) * LDBUF;
+            if (lth) { nl[threadIdx.x] = rl; nl[HPB * CH + threadIdx.x] = rd; }
         }
         __syncthreads();
     }
@@ -689,16 +740,15 @@ static int attn_set_lds(K kernel, size_t bytes, const char* what) {
 }
 
 // floats of LDS per double-buffered chunk set: `rows` row images + `tr` transposed images (+ LSE/delta)
-static size_t attn_lds_bytes(int threads, int d, int rows, int tr, bool ld) {
+static size_t attn_lds_bytes(int threads, int d, int rows, int tr, bool ld, int lp) {
     const int W = HPB * d, CH = threads / (W / 4);
-    return 2 * sizeof(float) * ((size_t)rows * CH * (W + 4) + (size_t)tr * W * (CH + 4) + (ld ? 2 * HPB * CH : 0));
+    const size_t img = 2 * (lp ? 2 : 4) * ((size_t)rows * CH * (W + 4) + (size_t)tr * W * (CH + 4));
+    return ((img + 15) & ~(size_t)15) + (ld ? 2 * sizeof(float) * 2 * HPB * CH : 0);
 }
 
-// q: (N,Sq,H*d); k,v: (N,Sk,H*d); o: (N,Sq,H*d); lse: (N,H,Sq).  sqrt_d is passed by
-// the host as float(d ** 0.5), the divisor the reference uses (layers.py:446).
-extern "C" int qarig_attention_fwd(const float* q, const float* k, const float* v, int N, int Sq,
-                                   int Sk, int H, int d, int causal, float sqrt_d, float* o,
-                                   float* lse, void* stream) {
+template <bool LP>
+static int attention_fwd_impl(const float* q, const float* k, const float* v, int N, int Sq, int Sk,
+                              int H, int d, int causal, float sqrt_d, float* o, float* lse, void* stream) {
     QARIG_CHECK_ARG(q && k && v && o && lse, "attention_fwd: null pointer");
     if (int e = attn_check(N, Sq, Sk, H, d, causal)) return e;
     AttnDims a{N, Sq, Sk, H, causal, 1.4426950408889634f / sqrt_d, 1.0f / sqrt_d};
@@ -707,10 +757,10 @@ extern "C" int qarig_attention_fwd(const float* q, const float* k, const float* 
     // W = 1 reads them 2.5x, and keeps two workgroups per CU to even out the causal imbalance
     const int W = attn_waves(Sq, d, "QARIG_ATTN_QW", 2, d <= 16 ? 4 : 2);
     const int threads = 256 * W, rows = 64 * W;
-    const size_t lds = attn_lds_bytes(threads, d, 1, 1, false);
+    const size_t lds = attn_lds_bytes(threads, d, 1, 1, false, LP);
     dim3 grid((unsigned)(N * ((H + HPB - 1) / HPB) * ((Sq + rows - 1) / rows))), block(threads);
     QARIG_HD_DISPATCH(d, {
-        auto kern = attn_fwd_kernel<HD, QARIG_FWD_MAXT(HD)>;
+        auto kern = attn_fwd_kernel<HD, QARIG_FWD_MAXT(HD), LP>;
         if (int e = attn_set_lds(kern, lds, "attention_fwd")) return e;
         hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, q, k, v, a, o, lse);
     });
@@ -718,11 +768,11 @@ extern "C" int qarig_attention_fwd(const float* q, const float* k, const float* 
     return QARIG_OK;
 }
 
-// delta: caller-provided (N,H,Sq) scratch.
-extern "C" int qarig_attention_bwd(const float* q, const float* k, const float* v, const float* o,
-                                   const float* dO, const float* lse, int N, int Sq, int Sk, int H,
-                                   int d, int causal, float sqrt_d, float* dq, float* dk, float* dv,
-                                   float* delta, void* stream) {
+template <bool LP>
+static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o,
+                              const float* dO, const float* lse, int N, int Sq, int Sk, int H, int d,
+                              int causal, float sqrt_d, float* dq, float* dk, float* dv, float* delta,
+                              void* stream) {
     QARIG_CHECK_ARG(q && k && v && o && dO && lse && dq && dk && dv && delta,
                     "attention_bwd: null pointer");
     if (int e = attn_check(N, Sq, Sk, H, d, causal)) return e;
@@ -731,10 +781,10 @@ extern "C" int qarig_attention_bwd(const float* q, const float* k, const float* 
     {
         const int W = attn_waves(Sq, d, "QARIG_ATTN_BW", 2, 2);
         const int threads = 256 * W, rows = 64 * W;
-        const size_t lds = attn_lds_bytes(threads, d, 2, 1, false);
+        const size_t lds = attn_lds_bytes(threads, d, 2, 1, false, LP);
         dim3 grid((unsigned)(N * hgroups * ((Sq + rows - 1) / rows))), block(threads);
         QARIG_HD_DISPATCH(d, {
-            auto kern = attn_bwd_dq_kernel<HD, 512>;
+            auto kern = attn_bwd_dq_kernel<HD, 512, LP>;
             if (int e = attn_set_lds(kern, lds, "attention_bwd dq")) return e;
             hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, q, k, v, o, dO, lse, a, dq, delta);
         });
@@ -743,16 +793,49 @@ extern "C" int qarig_attention_bwd(const float* q, const float* k, const float* 
     {
         const int W = attn_waves(Sk, d, "QARIG_ATTN_BW", 2, 2);
         const int threads = 256 * W, rows = 64 * W;
-        const size_t lds = attn_lds_bytes(threads, d, 2, 2, true);
+        const size_t lds = attn_lds_bytes(threads, d, 2, 2, true, LP);
         dim3 grid((unsigned)(N * hgroups * ((Sk + rows - 1) / rows))), block(threads);
         QARIG_HD_DISPATCH(d, {
-            auto kern = attn_bwd_dkv_kernel<HD, 512>;
+            auto kern = attn_bwd_dkv_kernel<HD, 512, LP>;
             if (int e = attn_set_lds(kern, lds, "attention_bwd dkv")) return e;
             hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, q, k, v, dO, lse, delta, a, dk, dv);
         });
         QARIG_CHECK_LAUNCH("attention_bwd dkv");
     }
     return QARIG_OK;
+}
+
+// q: (N,Sq,H*d); k,v: (N,Sk,H*d); o: (N,Sq,H*d); lse: (N,H,Sq).  sqrt_d is passed by
+// the host as float(d ** 0.5), the divisor the reference uses (layers.py:446).
+extern "C" int qarig_attention_fwd(const float* q, const float* k, const float* v, int N, int Sq,
+                                   int Sk, int H, int d, int causal, float sqrt_d, float* o,
+                                   float* lse, void* stream) {
+    return attention_fwd_impl<false>(q, k, v, N, Sq, Sk, H, d, causal, sqrt_d, o, lse, stream);
+}
+
+// delta: caller-provided (N,H,Sq) scratch.
+extern "C" int qarig_attention_bwd(const float* q, const float* k, const float* v, const float* o,
+                                   const float* dO, const float* lse, int N, int Sq, int Sk, int H,
+                                   int d, int causal, float sqrt_d, float* dq, float* dk, float* dv,
+                                   float* delta, void* stream) {
+    return attention_bwd_impl<false>(q, k, v, o, dO, lse, N, Sq, Sk, H, d, causal, sqrt_d, dq, dk, dv,
+                                     delta, stream);
+}
+
+// The same two entry points with the QK^T / PV (and dS-side) products on the bf16 MFMA
+// (operands rounded to bf16, fp32 accumulation, softmax and tensors): BASELINE config 5's
+// reduced-precision attention; opt-in, never the fp32 parity path.
+extern "C" int qarig_attention_lp_fwd(const float* q, const float* k, const float* v, int N, int Sq,
+                                      int Sk, int H, int d, int causal, float sqrt_d, float* o,
+                                      float* lse, void* stream) {
+    return attention_fwd_impl<true>(q, k, v, N, Sq, Sk, H, d, causal, sqrt_d, o, lse, stream);
+}
+extern "C" int qarig_attention_lp_bwd(const float* q, const float* k, const float* v, const float* o,
+                                      const float* dO, const float* lse, int N, int Sq, int Sk, int H,
+                                      int d, int causal, float sqrt_d, float* dq, float* dk, float* dv,
+                                      float* delta, void* stream) {
+    return attention_bwd_impl<true>(q, k, v, o, dO, lse, N, Sq, Sk, H, d, causal, sqrt_d, dq, dk, dv,
+                                    delta, stream);
 }
 
 // One decode step with a KV cache (generation; no reference counterpart - the reference

@@ -57,6 +57,8 @@ SIGNATURES = {
     "qarig_mul_rows_fwd": (I, [P, P, P, P, I, I, P]),
     "qarig_mul_rows_bwd": (I, [P, P, P, P, P, P, I, I, P]),
     "qarig_attention_fwd": (I, [P, P, P, I, I, I, I, I, I, F, P, P, P]),
+    "qarig_attention_lp_fwd": (I, [P, P, P, I, I, I, I, I, I, F, P, P, P]),
+    "qarig_attention_lp_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P, P, P, P, P]),
     "qarig_attention_decode": (I, [P, P, P, P, P, I, I, I, I, P, I, L, F, P, P, P]),
     "qarig_gemm_grouped_skinny_f32": (I, [P, L, L, P, L, L, P, L, L, P, L, I, I, I, I, I, P]),
     "qarig_attention_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P, P, P, P, P]),

@@ -587,9 +587,10 @@ def attention_fwd(q, k, v, heads, causal):
     d = D // heads
     o = torch.empty_like(q)
     lse = torch.empty((N, heads, Sq), dtype=torch.float32, device=q.device)
-    check(_lib.load().qarig_attention_fwd(ptr(q), ptr(k), ptr(v), N, Sq, Sk, heads, d, int(causal),
-                                          float(d ** 0.5), ptr(o), ptr(lse), stream()),
-          "qarig_attention_fwd")
+    lib = _lib.load()
+    fn = lib.qarig_attention_lp_fwd if PRECISION == "bf16" else lib.qarig_attention_fwd
+    check(fn(ptr(q), ptr(k), ptr(v), N, Sq, Sk, heads, d, int(causal), float(d ** 0.5), ptr(o), ptr(lse),
+             stream()), "qarig_attention_fwd")
     return o, lse
 
 
@@ -619,10 +620,10 @@ def attention_bwd(q, k, v, o, dO, lse, heads, causal):
     dk = torch.empty_like(k)
     dv = torch.empty_like(v)
     delta = torch.empty_like(lse)
-    check(_lib.load().qarig_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), N, Sq,
-                                          Sk, heads, d, int(causal), float(d ** 0.5), ptr(dq),
-                                          ptr(dk), ptr(dv), ptr(delta), stream()),
-          "qarig_attention_bwd")
+    lib = _lib.load()
+    fn = lib.qarig_attention_lp_bwd if PRECISION == "bf16" else lib.qarig_attention_bwd
+    check(fn(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), N, Sq, Sk, heads, d, int(causal),
+             float(d ** 0.5), ptr(dq), ptr(dk), ptr(dv), ptr(delta), stream()), "qarig_attention_bwd")
     return dq, dk, dv
 
 

@@ -222,6 +222,45 @@ def test_lp_qkv_and_residual_nodes_track_fp32_nodes(bf16_mode):
         assert rel_err(a, b) < 1.5e-2 and _cos(a, b) > 0.9999
 
 
+@pytest.mark.parametrize("N,Sq,Sk,H,d,causal", [(2, 300, 300, 6, 8, True), (1, 1024, 1024, 8, 8, True),
+                                                (2, 200, 333, 5, 8, False), (1, 130, 130, 4, 16, True),
+                                                (1, 96, 96, 2, 64, False)])
+def test_lp_attention_tracks_fp64(bf16_mode, N, Sq, Sk, H, d, causal):
+    """Attention with the QK^T / PV (and backward) products on the bf16 MFMA, fp32 softmax and
+    accumulation: against fp64 attention of the bf16-ROUNDED q, k, v the remaining error is the
+    rounding of the probabilities / score gradients to bf16 (2^-9 relative each) -- output and
+    all three gradients within 1e-2 of the tensor's largest value, cosine > 0.9995."""
+    ops = bf16_mode
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(Sq + Sk + H + d)
+    D = H * d
+    q, k, v = (torch.randn((N, S, D), generator=g).cuda() for S in (Sq, Sk, Sk))
+    do = torch.randn((N, Sq, D), generator=g).cuda()
+
+    def ref(q, k, v):
+        qh = q.reshape(N, Sq, H, d).permute(0, 2, 1, 3)
+        kh = k.reshape(N, Sk, H, d).permute(0, 2, 1, 3)
+        vh = v.reshape(N, Sk, H, d).permute(0, 2, 1, 3)
+        s = qh @ kh.transpose(-1, -2) / (d ** 0.5)
+        if causal:
+            s = s.masked_fill(torch.triu(torch.ones(Sq, Sk, dtype=torch.bool, device=q.device), 1), float("-inf"))
+        return (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(N, Sq, D)
+
+    a = [t.bfloat16().double().requires_grad_(True) for t in (q, k, v)]
+    oa = ref(*a)
+    (oa * do.bfloat16().double()).sum().backward()
+    b = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    o = QF.attention(b[0], b[1], b[2], H, causal)
+    (o * do).sum().backward()
+    assert rel_err(o, oa) < 1e-2 and _cos(o, oa) > 0.9995
+    for x, y in zip(b, a):
+        assert rel_err(x.grad, y.grad) < 1.5e-2 and _cos(x.grad, y.grad) > 0.9995
+    ops.PRECISION = "f32"            # and the fp32 kernels are untouched by the mode switch
+    o32 = QF.attention(q, k, v, H, causal)
+    ops.PRECISION = "bf16"
+    assert not torch.equal(o32, o.detach()) and rel_err(o32, ref(q.double(), k.double(), v.double())) < 2e-6
+
+
 def test_bf16_train_step_tracks_fp32_step():
     """One README-shaped (narrower/shallower) training step in both modes from the same
     weights: loss within 2e-3 relative, flat gradient cosine similarity > 0.999."""
