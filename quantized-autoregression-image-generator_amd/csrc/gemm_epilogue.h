@@ -36,18 +36,30 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 // LDS in two 32-row halves, so that every global access of the epilogue (C, preact,
 // residual, gradz, slabs) is a 16-B-per-lane, 256-B-per-row dwordx4 instead of 4x as many
 // 4-B accesses (the epilogue is store-issue bound otherwise).  `lds`: >= 32 KB, free.
+// General form: the wave's tile starts at (mb, nb); `stage` = this wave's 32 x 64 floats of LDS.
+__device__ __forceinline__ void gemm_epilogue_wave(const Acc& acc, const GemmEpilogue& ep, float* stage,
+                                                   int mb, int nb, int M, int N, int splitk,
+                                                   float* slabs);
+
 __device__ __forceinline__ void gemm_epilogue_wide(const Acc& acc, const GemmEpilogue& ep, float* lds,
                                                    int m0, int n0, int M, int N, int splitk,
                                                    float* slabs) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wave = threadIdx.x >> 6;
+    // 4 waves x 32 x 64 floats = 32 KB
+    gemm_epilogue_wave(acc, ep, lds + wave * (32 * 64), m0 + (wave >> 1) * 64, n0 + (wave & 1) * 64, M, N,
+                       splitk, slabs);
+}
+
+__device__ __forceinline__ void gemm_epilogue_wave(const Acc& acc, const GemmEpilogue& ep, float* stage,
+                                                   int mb, int nb, int M, int N, int splitk,
+                                                   float* slabs) {
+    const int lane = threadIdx.x & 63;
     const int cl = lane & 31;
-    // 4 waves x 32 x 64 floats = 32 KB; unpadded rows are conflict-free for both the b32
-    // writes (half-waves hit different rows) and the b128 reads
+    // unpadded rows are conflict-free for both the b32 writes (half-waves hit different rows)
+    // and the b128 reads
     constexpr int EL = 64;
-    float* stage = lds + wave * (32 * EL);
     const int er = lane >> 4, ec = (lane & 15) * 4;
-    const int gc = n0 + wn * 64 + ec;
+    const int gc = nb + ec;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ep.bias && splitk == 1) bv = *reinterpret_cast<const float4*>(ep.bias + gc);
 #pragma unroll
@@ -61,7 +73,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const Acc& acc, const GemmEpi
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int lr = it * 4 + er;
-            const int64_t row = m0 + wm * 64 + i * 32 + lr;
+            const int64_t row = mb + i * 32 + lr;
             float4 t = *reinterpret_cast<const float4*>(stage + lr * EL + ec);
             if (splitk > 1) {
                 *reinterpret_cast<float4*>(slabs + ((int64_t)blockIdx.z * M + row) * N + gc) = t;
