@@ -392,121 +392,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_pf_kernel(const float* _
     gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, slabs);
 }
 
-// ---------------------------------------------------------------------------------
-// Interior GEMM, ONE 16-wave workgroup per CU: tile 256 x 256 x 16, waves 4 x 4, each the usual
-// 64 x 64 sub-tile.  The 4-wave kernels above share every SIMD between workgroups that barrier
-// independently, and their MFMA pipes idle 24-29 % (profiles/r02j_sq_by_kernel.csv); here the
-// four waves of a SIMD belong to ONE workgroup: between two barriers a SIMD has 4 x 32 MFMAs =
-// 8192 pipe cycles of work against one barrier / DMA-issue / fragment-read gap, and every wave
-// issues only 2 DMAs per k-tile (1 KiB of each operand).  LDS: 2 x 32 KB ring, reused as the
-// 16 x 8 KB epilogue staging (128 KB).  Operand images: the 128-row images of gemm_dma_kernel,
-// twice as tall (row-major operands) or wide (reduction-major operands: 1-KB k-rows).
-// ---------------------------------------------------------------------------------
-constexpr int BIG = 256;
-constexpr int BIG_OP_FLOATS = BIG * BK;               // 16 KB per operand per stage
-constexpr int BIG_STAGE_FLOATS = 2 * BIG_OP_FLOATS;
-constexpr int BIG_THREADS = 1024;
-
-template <bool KC>
-__device__ __forceinline__ void big_dma(const float* __restrict__ P, int64_t ld, int x0, int k0, float* tile,
-                                        int wave, int lane) {
-    const float* src;
-    if (KC) {   // [x][k]: rows 16*wave .. +15, 64 B each, chunk-swizzled
-        const int r = 16 * wave + (lane >> 2);
-        const int c = (lane & 3) ^ ((r >> 2) & 3);
-        src = P + (int64_t)(x0 + r) * ld + k0 + 4 * c;
-    } else {    // [k][x]: k-row `wave`, 1 KB
-        src = P + (int64_t)(k0 + wave) * ld + x0 + lane * 4;
-    }
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + wave * 256), 16, 0, 0);
-}
-
-template <bool KC>
-__device__ __forceinline__ void big_frag(const float* tile, int x, int h, f32x4& lo, f32x4& hi) {
-    if (KC) {
-        frag_read<true>(tile, x, h, lo, hi);      // same [x][16] image, x < 256
-    } else {
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const unsigned base = lds_addr(tile + (8 * h) * BIG + x);   // rows are 1 KB = 4 x 64 dwords
-        f32x2 p0, p1, p2, p3;
-        asm volatile("ds_read2st64_b32 %0, %1 offset0:0 offset1:4" : "=v"(p0) : "v"(base));
-        asm volatile("ds_read2st64_b32 %0, %1 offset0:8 offset1:12" : "=v"(p1) : "v"(base));
-        asm volatile("ds_read2st64_b32 %0, %1 offset0:16 offset1:20" : "=v"(p2) : "v"(base));
-        asm volatile("ds_read2st64_b32 %0, %1 offset0:24 offset1:28" : "=v"(p3) : "v"(base));
-        lo = f32x4{p0.x, p0.y, p1.x, p1.y};
-        hi = f32x4{p2.x, p2.y, p3.x, p3.y};
-    }
-}
-
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(BIG_THREADS) void gemm_big_kernel(const float* __restrict__ A, int64_t lda,
-                                                               const float* __restrict__ B, int64_t ldb,
-                                                               GemmEpilogue ep, int M, int N, int K,
-                                                               int tiles_n, int splitk, float* slabs) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];    // 128 KB
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * BIG, n0 = tn * BIG;
-    int k_begin = 0, k_end = K;
-    if (splitk > 1) {
-        const int per = K / splitk;          // host: per % 16 == 0
-        k_begin = blockIdx.z * per;
-        k_end = k_begin + per;
-    }
-    const int nk = (k_end - k_begin) / BK;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int x = lane & 31, h = lane >> 5;
-    Acc acc;
-    acc_zero(acc);
-    // bias gradient riding on the dW GEMM: sum_k A(m0 + tid, k) for tid < 256 (A = dT^T, [k][x])
-    float rs = 0.0f;
-    const bool do_rs = !AKC && ep.rowsum != nullptr && tn == 0 && tid < BIG;
-    if (nk > 0) {
-        big_dma<AKC>(A, lda, m0, k_begin, lds, wave, lane);
-        big_dma<BKC>(B, ldb, n0, k_begin, lds + BIG_OP_FLOATS, wave, lane);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int st = kt & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nk) {
-                const int kn = k_begin + (kt + 1) * BK;
-                big_dma<AKC>(A, lda, m0, kn, lds + (st ^ 1) * BIG_STAGE_FLOATS, wave, lane);
-                big_dma<BKC>(B, ldb, n0, kn, lds + (st ^ 1) * BIG_STAGE_FLOATS + BIG_OP_FLOATS, wave, lane);
-            }
-            const float* ta = lds + st * BIG_STAGE_FLOATS;
-            const float* tb = ta + BIG_OP_FLOATS;
-            Frags8 f;
-            big_frag<AKC>(ta, wm * 64 + x, h, f.a0l, f.a0h);
-            big_frag<BKC>(tb, wn * 64 + x, h, f.b0l, f.b0h);
-            big_frag<AKC>(ta, wm * 64 + 32 + x, h, f.a1l, f.a1h);
-            big_frag<BKC>(tb, wn * 64 + 32 + x, h, f.b1l, f.b1h);
-            f32x4 r0, r1, r2, r3;
-            if (do_rs) {
-                big_frag<false>(ta, tid, 0, r0, r1);
-                big_frag<false>(ta, tid, 1, r2, r3);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (do_rs) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rs += r0[q];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rs += r1[q];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rs += r2[q];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rs += r3[q];
-            }
-            frags_mma(acc, f);
-        }
-    }
-    if (do_rs) ep.rowsum[(int64_t)blockIdx.z * M + m0 + tid] = rs;
-    __syncthreads();                      // ring no longer in use: the epilogue stages through it
-    gemm_epilogue_wave(acc, ep, lds + wave * (32 * 64), m0 + wm * 64, n0 + wn * 64, M, N, splitk, slabs);
-}
-
 // out[i] (+ld handling) = sum_z slabs[z][i], z ascending: deterministic.
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                    int64_t ldc, int M, int N, int nslab, int accumulate) {
@@ -761,31 +646,7 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     // QARIG_GEMM_PF=0 restores the 2-stage kernel, =1 forces the prefetch form on every shape
     const char* pf_e = getenv("QARIG_GEMM_PF");
     const bool pf = pf_e ? pf_e[0] == '1' || (pf_e[0] != '0' && dma_shape) : (dma_on && dma_shape);
-    // experiment / option: one 16-wave workgroup per CU on 256 x 256 tiles (QARIG_GEMM_BIG=1)
-    const char* big_e = getenv("QARIG_GEMM_BIG");
-    const bool big = big_e && big_e[0] == '1' && M % BIG == 0 && N % BIG == 0 && K % BK == 0 && va && vb &&
-                     vec_epi && (splitk == 1 || (K % splitk == 0 && (K / splitk) % BK == 0)) &&
-                     !(a_rowsum && a_kcontig) && !(!a_kcontig && b_kcontig);
-    if (big) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipFuncSetAttribute((const void*)gemm_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            hipFuncSetAttribute((const void*)gemm_big_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            hipFuncSetAttribute((const void*)gemm_big_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            attr_done = true;
-        }
-        const int btn = N / BIG;
-        dim3 bgrid((M / BIG) * btn, 1, splitk), bblock(BIG_THREADS);
-        if (a_kcontig && b_kcontig)
-            hipLaunchKernelGGL((gemm_big_kernel<true, true>), bgrid, bblock, 128 * 1024, st, A, lda, B, ldb, ep,
-                               M, N, K, btn, splitk, slabs);
-        else if (a_kcontig)
-            hipLaunchKernelGGL((gemm_big_kernel<true, false>), bgrid, bblock, 128 * 1024, st, A, lda, B, ldb, ep,
-                               M, N, K, btn, splitk, slabs);
-        else
-            hipLaunchKernelGGL((gemm_big_kernel<false, false>), bgrid, bblock, 128 * 1024, st, A, lda, B, ldb, ep,
-                               M, N, K, btn, splitk, slabs);
-    } else if (pf && fast && vec_epi && !(a_rowsum && a_kcontig) && !(!a_kcontig && b_kcontig)) {
+    if (pf && fast && vec_epi && !(a_rowsum && a_kcontig) && !(!a_kcontig && b_kcontig)) {
         if (a_kcontig && b_kcontig)
             hipLaunchKernelGGL((gemm_dma_pf_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
                                N, K, tiles_n, splitk, slabs);

@@ -37,6 +37,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 // residual, gradz, slabs) is a 16-B-per-lane, 256-B-per-row dwordx4 instead of 4x as many
 // 4-B accesses (the epilogue is store-issue bound otherwise).  `lds`: >= 32 KB, free.
 // General form: the wave's tile starts at (mb, nb); `stage` = this wave's 32 x 64 floats of LDS.
+template <int NJ = 2>
 __device__ __forceinline__ void gemm_epilogue_wave(const Acc& acc, const GemmEpilogue& ep, float* stage,
                                                    int mb, int nb, int M, int N, int splitk,
                                                    float* slabs);
@@ -50,29 +51,31 @@ __device__ __forceinline__ void gemm_epilogue_wide(const Acc& acc, const GemmEpi
                        splitk, slabs);
 }
 
+template <int NJ>
 __device__ __forceinline__ void gemm_epilogue_wave(const Acc& acc, const GemmEpilogue& ep, float* stage,
                                                    int mb, int nb, int M, int N, int splitk,
                                                    float* slabs) {
     const int lane = threadIdx.x & 63;
     const int cl = lane & 31;
     // unpadded rows are conflict-free for both the b32 writes (half-waves hit different rows)
-    // and the b128 reads
-    constexpr int EL = 64;
-    const int er = lane >> 4, ec = (lane & 15) * 4;
+    // and the b128 reads.  The wave's tile is 64 rows x 32*NJ columns (NJ = 1: accumulators t[i][0])
+    constexpr int EL = 32 * NJ;
+    constexpr int LPR = 8 * NJ;            // lanes per staged row (4 columns each)
+    const int er = lane / LPR, ec = (lane % LPR) * 4;
     const int gc = nb + ec;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ep.bias && splitk == 1) bv = *reinterpret_cast<const float4*>(ep.bias + gc);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 stage[acc_row(r, lane) * EL + j * 32 + cl] = acc.t[i][j][r];
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int lr = it * 4 + er;
+        for (int it = 0; it < 4 * NJ; ++it) {
+            const int lr = it * (64 / LPR) + er;
             const int64_t row = mb + i * 32 + lr;
             float4 t = *reinterpret_cast<const float4*>(stage + lr * EL + ec);
             if (splitk > 1) {
