@@ -184,6 +184,8 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
     constexpr int G = HD / 4;
+    constexpr int KS = HD <= 8 ? 16 : 8;    // keys per online-softmax step
+    constexpr int NQ = KS / 4;
     const int CH = Geo<HD>::chunk_rows();
     const int TS = CH + 4;
     const int QW = blockDim.x >> 8;                    // query slices (waves per head)
@@ -239,41 +241,45 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const float* __restrict_
         const T* Kc = smem + (t & 1) * BUF + hh * HD;
         const T* Vc = smem + (t & 1) * BUF + VOFF + (hh * HD) * TS;
         const int jw = min(c0 + CH, jend);
-        for (int j0 = c0; j0 < jw; j0 += 8) {
+        for (int j0 = c0; j0 < jw; j0 += KS) {
             const int jj = j0 - c0;
-            // S^T for 8 keys: two accumulators (keys jj..jj+3, jj+4..jj+7), c ascending
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+            // S^T for KS keys: NQ accumulators of 4 keys each, c ascending
+            f32x4 s[NQ];
             const T* kr = Kc + (jj + li) * Geo<HD>::RS;
-            dot_rows<LP, HD>(s0, kr, qv);
-            dot_rows<LP, HD>(s1, kr + 4 * Geo<HD>::RS, qv);
-            float sc[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { sc[r] = s0[r] * a.c2; sc[4 + r] = s1[r] * a.c2; }
-            if (j0 + 8 > jw || (a.causal && j0 + 7 > q0)) {          // wave-uniform: edge steps only
+            for (int u = 0; u < NQ; ++u) {
+                s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dot_rows<LP, HD>(s[u], kr + 4 * u * Geo<HD>::RS, qv);
+            }
+            float sc[KS];
 #pragma unroll
-                for (int r = 0; r < 8; ++r)
+            for (int u = 0; u < NQ; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[4 * u + r] = s[u][r] * a.c2;
+            if (j0 + KS > jw || (a.causal && j0 + KS - 1 > q0)) {     // wave-uniform: edge steps only
+#pragma unroll
+                for (int r = 0; r < KS; ++r)
                     if (j0 + r >= jw || (a.causal && j0 + r > i)) sc[r] = -INFINITY;
             }
-            float mc = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])),
-                             fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+            float mc = sc[0];
+#pragma unroll
+            for (int r = 1; r < KS; ++r) mc = fmaxf(mc, sc[r]);
             const float mn = fmaxf(m, mc);
             const float msafe = mn == -INFINITY ? 0.0f : mn;     // fully masked so far: p = 0
             const float alpha = exp2_fast(m - msafe);
             l *= alpha;
 #pragma unroll
             for (int g = 0; g < G; ++g) ov[g] *= alpha;
-            float p[8];
+            float p[KS];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { p[r] = exp2_fast(sc[r] - msafe); l += p[r]; }
+            for (int r = 0; r < KS; ++r) { p[r] = exp2_fast(sc[r] - msafe); l += p[r]; }
             m = mn;
             // PV: keys ascending per output column group
-            const Vals<LP> pa = make_vals<LP>(p[0], p[1], p[2], p[3]);
-            const Vals<LP> pb = make_vals<LP>(p[4], p[5], p[6], p[7]);
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const T* vr = Vc + (4 * g + li) * TS + jj;
-                acc_cols<LP>(ov[g], vr, pa);
-                acc_cols<LP>(ov[g], vr + 4, pb);
+            for (int u = 0; u < NQ; ++u) {
+                const Vals<LP> pv = make_vals<LP>(p[4 * u], p[4 * u + 1], p[4 * u + 2], p[4 * u + 3]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc_cols<LP>(ov[g], Vc + (4 * g + li) * TS + jj + 4 * u, pv);
             }
         }
         if (t + 1 < nchunks) {
@@ -304,6 +310,8 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* smem = reinterpret_cast<T*>(smem_raw);
     constexpr int G = HD / 4;
+    constexpr int KS = HD <= 8 ? 16 : 8;    // keys per step
+    constexpr int NQ = KS / 4;
     const int CH = Geo<HD>::chunk_rows();
     const int TS = CH + 4;
     const int QW = blockDim.x >> 8;
@@ -371,33 +379,34 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_kernel(
         const T* Vc = smem + (t & 1) * BUF + VOFF + hh * HD;
         const T* Tc = smem + (t & 1) * BUF + TOFF + (hh * HD) * TS;
         const int jw = min(c0 + CH, jend);
-        for (int j0 = c0; j0 < jw; j0 += 8) {
+        for (int j0 = c0; j0 < jw; j0 += KS) {
             const int jj = j0 - c0;
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
+            f32x4 s[NQ], dpv[NQ];
             const T* kr = Kc + (jj + li) * Geo<HD>::RS;
             const T* vr = Vc + (jj + li) * Geo<HD>::RS;
-            dot_rows<LP, HD>(s0, kr, qv);
-            dot_rows<LP, HD>(s1, kr + 4 * Geo<HD>::RS, qv);
-            dot_rows<LP, HD>(d0, vr, dov);
-            dot_rows<LP, HD>(d1, vr + 4 * Geo<HD>::RS, dov);
-            float ds[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ds[r] = exp2_fast(fmaf(s0[r], a.c2, -L)) * (d0[r] - dl);
-                ds[4 + r] = exp2_fast(fmaf(s1[r], a.c2, -L)) * (d1[r] - dl);
+            for (int u = 0; u < NQ; ++u) {
+                s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dpv[u] = s[u];
+                dot_rows<LP, HD>(s[u], kr + 4 * u * Geo<HD>::RS, qv);
+                dot_rows<LP, HD>(dpv[u], vr + 4 * u * Geo<HD>::RS, dov);
             }
-            if (j0 + 8 > jw || (a.causal && j0 + 7 > q0)) {
+            float ds[KS];
 #pragma unroll
-                for (int r = 0; r < 8; ++r)
+            for (int u = 0; u < NQ; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ds[4 * u + r] = exp2_fast(fmaf(s[u][r], a.c2, -L)) * (dpv[u][r] - dl);
+            if (j0 + KS > jw || (a.causal && j0 + KS - 1 > q0)) {
+#pragma unroll
+                for (int r = 0; r < KS; ++r)
                     if (j0 + r >= jw || (a.causal && j0 + r > i)) ds[r] = 0.0f;
             }
-            const Vals<LP> da = make_vals<LP>(ds[0], ds[1], ds[2], ds[3]);
-            const Vals<LP> db = make_vals<LP>(ds[4], ds[5], ds[6], ds[7]);
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const T* tr = Tc + (4 * g + li) * TS + jj;
-                acc_cols<LP>(acc[g], tr, da);
-                acc_cols<LP>(acc[g], tr + 4, db);
+            for (int u = 0; u < NQ; ++u) {
+                const Vals<LP> dv4 = make_vals<LP>(ds[4 * u], ds[4 * u + 1], ds[4 * u + 2], ds[4 * u + 3]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc_cols<LP>(acc[g], Tc + (4 * g + li) * TS + jj + 4 * u, dv4);
             }
         }
         if (t + 1 < nchunks) {

@@ -41,7 +41,7 @@ def _report_done(param):
         cb(param)
 
 
-def _wgrad(dT, X, param=None, bias_param=None, want_bias=False):
+def _wgrad(dT, X, param=None, bias_param=None, want_bias=False, flop_frac=1.0):
     """dW[N,K] = dT^T X over the row dimension (split-K through fp32 slabs) and, riding on
     the same launch, db[N] = column sums of dT (the row sums of the A operand dT^T).
     Returns (dW, db); an entry is None when it was accumulated into the parameter's .grad
@@ -59,7 +59,7 @@ def _wgrad(dT, X, param=None, bias_param=None, want_bias=False):
             _report_done(bias_param)
         return None, None
     db = torch.zeros(N, dtype=torch.float32, device=dT.device) if want_bias else None
-    dw = ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=sk, a_rowsum=db)
+    dw = ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=sk, a_rowsum=db, flop_frac=flop_frac)
     return dw, db
 
 
@@ -161,7 +161,7 @@ class _MLP2(torch.autograd.Function):
             w2p[:N].copy_(w2.detach())
             b2p = torch.zeros(Np, dtype=torch.float32, device=w2.device)
             b2p[:N].copy_(b2.detach())
-            y, t2 = ops.gemm(h, w2p, bias=b2p)[:, :N].contiguous(), None
+            y, t2 = ops.gemm(h, w2p, bias=b2p, flop_frac=N / Np)[:, :N].contiguous(), None
             ctx.save_for_backward(x2, w1, w2p, t1, h, t2)
         else:
             if act2:
@@ -183,9 +183,9 @@ class _MLP2(torch.autograd.Function):
             Np = w2.shape[0]                      # w2 here is the zero-padded copy
             dT2 = torch.zeros((dy2.shape[0], Np), dtype=torch.float32, device=dy2.device)
             dT2[:, :N].copy_(dy2)
-            dT1 = ops.gemm(dT2, w2, a_kcontig=True, b_kcontig=False, gradz=t1, gact=ctx.act1)
+            dT1 = ops.gemm(dT2, w2, a_kcontig=True, b_kcontig=False, gradz=t1, gact=ctx.act1, flop_frac=N / Np)
             if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
-                dwp, dbp = _wgrad(dT2, h, None, None, True)
+                dwp, dbp = _wgrad(dT2, h, None, None, True, flop_frac=N / Np)
                 wslot, bslot = _grad_slot(ctx.params[2]), _grad_slot(ctx.params[3])
                 if ctx.needs_input_grad[3]:
                     if wslot is not None:

@@ -63,8 +63,11 @@ def set_precision(name):
 
 
 def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_preact=False,
-         act=0, gradz=None, gact=0, splitk=None, out=None, accumulate=False, a_rowsum=None):
+         act=0, gradz=None, gact=0, splitk=None, out=None, accumulate=False, a_rowsum=None,
+         flop_frac=1.0):
     """C[M,N] = epilogue(sum_k A(m,k) B(n,k)); see include/qarig.h qarig_gemm_f32.
+    flop_frac: fraction of the 2MNK products that are algorithmic work (zero-padded operands
+    of the ragged classifier): only bench.py's FLOP accounting reads it.
 
     A is (M,K) if a_kcontig else (K,M); B is (N,K) if b_kcontig else (K,N).
     Returns C, or (C, preact) when want_preact."""
@@ -114,7 +117,7 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
     if GEMM_EVENTS is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        GEMM_EVENTS.append((2.0 * M * N * K, ev0, ev1))
+        GEMM_EVENTS.append((2.0 * M * N * K * flop_frac, ev0, ev1))
     return (C, pre) if want_preact else C
 
 
