@@ -23,6 +23,7 @@
 // re-scanned by the whole block with the literal definition above, so the result is
 // bit-identical to it on every input.
 #include <limits.h>
+#include <type_traits>
 
 #include "qarig_common.h"
 
@@ -135,7 +136,7 @@ __device__ __forceinline__ int bmu_needs_exact(const BmuState& s, float x2) {
 // Literal re-scan of the flagged rows of a 128-row block, all 256 threads per row:
 // thread t takes codes t, t+256, ... (ascending), the block reduces (d, index) with the
 // first-index rule.  Same fp32 chains as the MFMA path and the oracle.
-__device__ __noinline__ void bmu_exact_rows(const PatchGeom& g, const float* __restrict__ w, int K, int p0,
+__device__ __forceinline__ void bmu_exact_rows(const PatchGeom& g, const float* __restrict__ w, int K, int p0,
                                const int* flags, float* lds, int64_t* __restrict__ out) {
     float* rs = lds;                                  // [256]
     int* ri = reinterpret_cast<int*>(lds + 256);      // [256]
@@ -406,6 +407,354 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_small_kernel(PatchGeom g,
                      part_x2, out);
 }
 
+// ---------------------------------------------------------------------------------
+// Narrow patches (D <= 16: the HR stages of the cascade), codebook resident in LDS.
+// The block stages its code range ONCE as MFMA A-fragments (-2w split into even / odd
+// elements, |w|^2 beside them), every wave keeps its 32 patch rows as B-fragments in
+// registers for the whole launch, and the main loop has no barrier: per 32-code tile
+// 2 x ds_read_b128 + KS+1 MFMAs + a 4-op scan per candidate.  |w|^2 enters through one
+// extra MFMA step (A = |w|^2, B = 1): the chain's last operation is then
+// fma(|w|^2, 1, acc) = round(acc + |w|^2), the `acc + w2` of the definition above.
+// CS waves share a row tile and split the block's codes among them (launches with few rows
+// still fill the chip: 32 * 4/CS rows per block).  grid.y = code chunks when the codebook
+// exceeds the LDS budget; their partial states go through bmu_finalize_kernel.
+// The resident kernel's inner loop is written as a sequence of volatile asm statements, which
+// the compiler keeps in source order: one MFMA of the NEXT tile pair, then the scan of two
+// candidates of the CURRENT pair (8 VALU ops, in the shadow of that MFMA's 64 cycles), and so
+// on.  Left to the compiler the loop becomes 18 MFMAs followed by 128 VALU ops, and the
+// co-resident waves -- which run in lock-step -- then queue for the matrix pipe together and
+// for the vector ALU together.
+// Scan of one candidate: 4 VALU ops (v_med3, v_cmp, v_cndmask, v_min) with the candidate's
+// position inside the pair as an inline constant; the compiler's own fminf() canonicalises
+// both operands first, and v_cndmask cannot take an SGPR position next to VCC on gfx9.
+template <int R>
+__device__ __forceinline__ void res_scan2(float t0, float t1, float& best, int& rnew, float& sec) {
+    static_assert(R >= 0 && R + 1 <= 64, "positions must stay inline constants");
+    asm volatile(
+        "v_med3_f32 %2, %0, %3, %2\n"
+        "v_cmp_nlt_f32 vcc, %3, %0\n"
+        "v_cndmask_b32 %1, %5, %1, vcc\n"
+        "v_min_f32 %0, %0, %3\n"
+        "v_med3_f32 %2, %0, %4, %2\n"
+        "v_cmp_nlt_f32 vcc, %4, %0\n"
+        "v_cndmask_b32 %1, %6, %1, vcc\n"
+        "v_min_f32 %0, %0, %4\n"
+        : "+v"(best), "+v"(rnew), "+v"(sec)
+        : "v"(t0), "v"(t1), "n"(R), "n"(R + 1)
+        : "vcc");
+}
+template <bool FIRST>
+__device__ __forceinline__ void res_mfma(f32x16& acc, float a, float b) {
+    // s_nop 1: an MFMA may read a VGPR no sooner than 2 wait states after a vector-ALU write
+    // of it; the compiler inserts those for its own MFMAs, not for one inside inline asm (the
+    // |w|^2 operand is a v_cndmask result the scheduler likes to place right in front)
+    if constexpr (FIRST)
+        asm volatile("s_nop 1\nv_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+    else
+        asm volatile("s_nop 1\nv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct PatchOffsets {
+    int off[16];   // element e of a patch, relative to the patch's first element
+};
+
+constexpr int RES_MAX_LDS = 59 * 1024;   // staged codes; + 4.5 KB of combine scratch < 64 KB
+
+template <int KS>
+__device__ __forceinline__ void res_frag(const float* AE, int c, int hi, int chunk, float (&a)[KS]) {
+    // half `hi` of code c: KS floats, 16-B chunks swapped on alternate groups of 8 codes so that
+    // the 16 lanes of a b128 phase cover all banks
+    const float* p = AE + ((size_t)hi * chunk + c) * KS;
+    if constexpr (KS == 8) {
+        const int sw = (c >> 3) & 1;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(p + 4 * sw);
+        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(p + 4 * (sw ^ 1));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = lo[q]; a[4 + q] = hi4[q]; }
+    } else if constexpr (KS == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = v[q];
+    } else {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 v = *reinterpret_cast<const f32x2*>(p);
+        a[0] = v[0]; a[1] = v[1];
+    }
+}
+
+// Literal re-scan of the flagged rows (bmu_exact_rows) for a single-chunk launch of the
+// resident kernel: the codes are read back from their LDS image (-2w, so the product chain
+// takes them as they are; w = -0.5 * (-2w) is exact) and the patch row is fetched with all
+// its loads in flight at once -- a flagged row costs about one memory round trip instead of
+// ~50 dependent ones, which matters because the launch ends with its slowest workgroup.
+template <int KS>
+__device__ __forceinline__ void res_exact_rows(const PatchGeom& g, const PatchOffsets& po, const float* AE,
+                                            const float* W2, int chunk, int K, int p0, const int* flags,
+                                            float* lds, int64_t* __restrict__ out) {
+    float* rs = lds;                                  // [4] per-wave minima
+    int* ri = reinterpret_cast<int*>(lds + 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long* masks = reinterpret_cast<const unsigned long long*>(flags);
+    for (int half = 0; half < 2; ++half)
+    for (unsigned long long m = masks[half]; m; m &= m - 1) {
+        const int r = half * 64 + __ffsll((long long)m) - 1;
+        const int row = p0 + r;
+        const float* px = g.x + patch_row_base(g, row);
+        float xs[2 * KS];
+#pragma unroll
+        for (int e = 0; e < 2 * KS; ++e) {
+            const float v = px[po.off[e]];
+            xs[e] = e < g.D ? v : 0.0f;
+        }
+        float x2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 2 * KS; ++e) x2 = fmaf(xs[e], xs[e], x2);
+        float best = INFINITY;
+        int bidx = INT_MAX;
+        for (int k = tid; k < K; k += NTHREADS) {      // K <= chunk: one chunk
+            float ev[KS], od[KS];
+            res_frag<KS>(AE, k, 0, chunk, ev);
+            res_frag<KS>(AE, k, 1, chunk, od);
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+                acc = fmaf(ev[q], xs[2 * q], acc);
+                acc = fmaf(od[q], xs[2 * q + 1], acc);
+            }
+            const float d = sqrtf(fmaxf((acc + W2[k]) + x2, 0.0f));
+            if (d < best) { best = d; bidx = k; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float s2 = __shfl_xor(best, o);
+            const int i2 = __shfl_xor(bidx, o);
+            if (s2 < best || (s2 == best && i2 < bidx)) { best = s2; bidx = i2; }
+        }
+        __syncthreads();
+        if (lane == 0) { rs[wave] = best; ri[wave] = bidx; }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (rs[q] < best || (rs[q] == best && ri[q] < bidx)) { best = rs[q]; bidx = ri[q]; }
+            out[row] = bidx == INT_MAX ? 0 : (int64_t)bidx;
+        }
+    }
+}
+
+template <int KS, int CS>
+__global__ __launch_bounds__(NTHREADS, 2) void bmu_resident_kernel(PatchGeom g, PatchOffsets po,
+                                                                   const float* __restrict__ w, int K,
+                                                                   int chunk,
+                                                                   float* __restrict__ part_d,
+                                                                   int* __restrict__ part_i,
+                                                                   float* __restrict__ part_s,
+                                                                   float* __restrict__ part_x2,
+                                                                   int64_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int RPB = 32 * (4 / CS);          // patch rows per block
+    float* AE = lds;                            // [2][chunk][KS]: even, then odd elements of -2w
+    float* W2 = lds + (size_t)2 * chunk * KS;   // [chunk]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, cl = lane & 31;
+    const int cbase = blockIdx.y * chunk;
+    const int p0 = blockIdx.x * RPB;
+
+    // ---- stage the code range: one code per thread per pass
+    const bool vec = (g.D % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    for (int c = tid; c < chunk; c += NTHREADS) {
+        const int code = cbase + c;
+        float we[2 * KS];
+#pragma unroll
+        for (int e = 0; e < 2 * KS; ++e) we[e] = 0.0f;
+        float w2 = INFINITY;
+        if (code < K) {
+            const float* wk = w + (int64_t)code * g.D;
+            if (vec) {
+#pragma unroll
+                for (int q = 0; q < KS / 2; ++q) {
+                    const bool in = 4 * q < g.D;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(wk + (in ? 4 * q : 0));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) we[4 * q + u] = in ? v[u] : 0.0f;
+                }
+            } else {   // clamped address + select: no divergent branch per element
+#pragma unroll
+                for (int e = 0; e < 2 * KS; ++e) {
+                    const float v = wk[e < g.D ? e : 0];
+                    we[e] = e < g.D ? v : 0.0f;
+                }
+            }
+            w2 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 2 * KS; ++e) w2 = fmaf(we[e], we[e], w2);
+        }
+        float* pe = AE + (size_t)c * KS;
+        float* po_ = AE + ((size_t)chunk + c) * KS;
+        if constexpr (KS == 8) {
+            const int sw = (c >> 3) & 1;
+            *reinterpret_cast<f32x4*>(pe + 4 * sw) = f32x4{-2.0f * we[0], -2.0f * we[2], -2.0f * we[4], -2.0f * we[6]};
+            *reinterpret_cast<f32x4*>(pe + 4 * (sw ^ 1)) = f32x4{-2.0f * we[8], -2.0f * we[10], -2.0f * we[12], -2.0f * we[14]};
+            *reinterpret_cast<f32x4*>(po_ + 4 * sw) = f32x4{-2.0f * we[1], -2.0f * we[3], -2.0f * we[5], -2.0f * we[7]};
+            *reinterpret_cast<f32x4*>(po_ + 4 * (sw ^ 1)) = f32x4{-2.0f * we[9], -2.0f * we[11], -2.0f * we[13], -2.0f * we[15]};
+        } else {
+#pragma unroll
+            for (int q = 0; q < KS; ++q) { pe[q] = -2.0f * we[2 * q]; po_[q] = -2.0f * we[2 * q + 1]; }
+        }
+        W2[c] = w2;
+    }
+
+    // ---- this lane's patch row: all elements (the |x|^2 chain runs over them in order), then
+    // the half this lane feeds to the MFMA (k = 2 s + hi)
+    const int rtile = wave / CS, cpart = wave % CS;
+    const int row = p0 + rtile * 32 + cl;
+    // (no array of the row's elements: a select between two array slots becomes an indexed
+    // access, i.e. a trip through scratch memory)
+    float x2 = 0.0f;
+    float b[KS];
+    {   // rows past the end read row 0 and are never written; po.off[e >= D] = off[0]
+        const float* px = g.x + patch_row_base(g, row < g.R ? row : 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float v0 = px[po.off[2 * s]], v1 = px[po.off[2 * s + 1]];
+            const float e0 = 2 * s < g.D ? v0 : 0.0f, e1 = 2 * s + 1 < g.D ? v1 : 0.0f;
+            x2 = fmaf(e0, e0, x2);
+            x2 = fmaf(e1, e1, x2);
+            b[s] = hi ? e1 : e0;
+        }
+    }
+    const float b_ext = hi ? 0.0f : 1.0f;
+    __syncthreads();
+
+    // ---- main loop: this wave's code tiles, two at a time (independent accumulators); the
+    // MFMAs of the next pair are issued before the current pair is scanned, so the scan's VALU
+    // work runs under them
+    const int tiles_w = chunk / (32 * CS);            // even (host)
+    const int t0 = cpart * tiles_w;
+    float best = INFINITY, sec = INFINITY;
+    int seq_best = INT_MAX;
+    // step<ISSUE, SCAN>: the 2 KS + 2 MFMAs of pair tpn into (n0, n1), interleaved with the scan
+    // of pair tpc held in (c0, c1).  Candidates ascend within the lane: seq = 16 * tile + r.
+    auto step = [&](auto issue_c, auto scan_c, int tpn, f32x16& n0, f32x16& n1, int tpc, f32x16& c0,
+                    f32x16& c1) {
+        constexpr bool ISSUE = decltype(issue_c)::value, SCAN = decltype(scan_c)::value;
+        constexpr int SLOTS = 2 * KS + 2;
+        float a0[KS], a1[KS], w0 = 0.0f, w1 = 0.0f;
+        if constexpr (ISSUE) {
+            const int cc = (t0 + tpn) * 32 + cl;
+            res_frag<KS>(AE, cc, hi, chunk, a0);
+            res_frag<KS>(AE, cc + 32, hi, chunk, a1);
+            const float w0v = W2[cc], w1v = W2[cc + 32];
+            w0 = hi ? 0.0f : w0v;
+            w1 = hi ? 0.0f : w1v;
+        }
+        int rnew = -1;
+        static_for<0, SLOTS>([&](auto mc) {
+            constexpr int M = decltype(mc)::value;
+            if constexpr (ISSUE) {
+                constexpr int S = M / 2;
+                if constexpr (S < KS) {
+                    if constexpr (M % 2 == 0) res_mfma<S == 0>(n0, a0[S], b[S]);
+                    else res_mfma<S == 0>(n1, a1[S], b[S]);
+                } else {
+                    if constexpr (M % 2 == 0) res_mfma<false>(n0, w0, b_ext);
+                    else res_mfma<false>(n1, w1, b_ext);
+                }
+            }
+            if constexpr (SCAN) {
+                // scan2 chunk j (16 per pair) follows MFMA floor(j * SLOTS / 16)
+                static_for<0, 16>([&](auto jc) {
+                    constexpr int J = decltype(jc)::value;
+                    if constexpr (J * SLOTS / 16 == M) {
+                        if constexpr (J < 8) res_scan2<2 * J>(c0[2 * J], c0[2 * J + 1], best, rnew, sec);
+                        else res_scan2<2 * J>(c1[2 * J - 16], c1[2 * J - 15], best, rnew, sec);
+                    }
+                });
+            }
+        });
+        // The MFMAs sit in inline asm, so the compiler inserts none of the wait states it owes
+        // between a matrix-core write and a vector-ALU read of the same registers -- and it
+        // does read them: register copies of an accumulator at the loop edges.  Every issuing
+        // step therefore ends with the 16-pass latency in nops (24 cycles per 18 MFMAs).
+        if constexpr (ISSUE) asm volatile("s_nop 15\ns_nop 7" : "+v"(n0), "+v"(n1));
+        if constexpr (SCAN) seq_best = rnew >= 0 ? tpc * 16 + rnew : seq_best;
+    };
+    {
+        f32x16 A0, A1, B0, B1;
+        constexpr std::true_type yes{};
+        constexpr std::false_type no{};
+        step(yes, no, 0, A0, A1, 0, B0, B1);
+        int tp = 0;
+        while (true) {
+            if (tp + 2 < tiles_w) step(yes, yes, tp + 2, B0, B1, tp, A0, A1);
+            else step(no, yes, 0, B0, B1, tp, A0, A1);
+            tp += 2;
+            if (tp >= tiles_w) break;
+            if (tp + 2 < tiles_w) step(yes, yes, tp + 2, A0, A1, tp, B0, B1);
+            else step(no, yes, 0, A0, A1, tp, B0, B1);
+            tp += 2;
+            if (tp >= tiles_w) break;
+        }
+    }
+    // seq -> code: tile t0 + seq/16, accumulator row acc_row(seq % 16, lane)
+    BmuState st{best, INT_MAX, sec};
+    if (seq_best != INT_MAX) {
+        const int code = cbase + (t0 + (seq_best >> 4)) * 32 + acc_row(seq_best & 15, lane);
+        st.idx = code < K ? code : INT_MAX;
+    }
+    {   // the two lane halves hold disjoint codes of the same row
+        BmuState o{__shfl_xor(st.d2, 32), __shfl_xor(st.idx, 32), __shfl_xor(st.sec, 32)};
+        st = bmu_merge(st, o);
+    }
+    // combine scratch behind the staged codes (they stay readable for the exact re-scan)
+    float* sc = W2 + chunk;
+    float* cd = sc;                                    // [CS][RPB]
+    int* ci = reinterpret_cast<int*>(sc + CS * RPB);
+    float* cs = sc + 2 * CS * RPB;
+    float* cx = sc + 3 * CS * RPB;                     // [RPB] |x|^2
+    int* flags = reinterpret_cast<int*>(sc + 3 * CS * RPB + RPB);   // 128 ints (two 64-bit ballots)
+    float* scratch = sc + 3 * CS * RPB + RPB + 128;    // 512 floats for the exact re-scan
+    if (hi == 0) {
+        const int col = rtile * 32 + cl;
+        cd[cpart * RPB + col] = st.d2;
+        ci[cpart * RPB + col] = st.idx;
+        cs[cpart * RPB + col] = st.sec;
+        if (cpart == 0) cx[col] = x2;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int prow = p0 + tid;
+        int flag = 0;
+        if (tid < RPB && prow < g.R) {
+            BmuState m{cd[tid], ci[tid], cs[tid]};
+#pragma unroll
+            for (int q = 1; q < CS; ++q) m = bmu_merge(m, BmuState{cd[q * RPB + tid], ci[q * RPB + tid], cs[q * RPB + tid]});
+            if (out) {
+                flag = bmu_needs_exact(m, cx[tid]);
+                out[prow] = m.idx == INT_MAX ? 0 : (int64_t)m.idx;
+            } else {
+                const int64_t o = (int64_t)blockIdx.y * g.R + prow;
+                part_d[o] = m.d2;
+                part_i[o] = m.idx;
+                part_s[o] = m.sec;
+                if (blockIdx.y == 0) part_x2[prow] = cx[tid];
+            }
+        }
+        const unsigned long long mk = __ballot(flag);
+        if (lane == 0) reinterpret_cast<unsigned long long*>(flags)[wave] = mk;
+    }
+    __syncthreads();
+    if (out) res_exact_rows<KS>(g, po, AE, W2, chunk, K, p0, flags, scratch, out);
+}
+
 // Merge of the per-split partial states (splits cover ascending code ranges), then the
 // exact re-scan of flagged rows.  One block per 128 rows.
 __global__ __launch_bounds__(256) void bmu_finalize_kernel(PatchGeom g, const float* __restrict__ w,
@@ -645,6 +994,48 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
     const int per = (ctiles + nsplit - 1) / nsplit;
     nsplit = (ctiles + per - 1) / per;
     int64_t* direct = nsplit == 1 ? out_idx : (int64_t*)nullptr;
+    static const bool resident_on = []() { const char* e = getenv("QARIG_BMU_RESIDENT"); return !(e && e[0] == '0'); }();
+    if (D <= 16 && resident_on) {
+        const int ks = D <= 4 ? 2 : (D <= 8 ? 4 : 8);
+        const int bpc = (2 * ks + 1) * 4;                         // LDS bytes per code
+        const int chunk_max = RES_MAX_LDS / bpc / 256 * 256;
+        const int nchunks = (K + chunk_max - 1) / chunk_max;
+        // waves sharing a row tile: as few as still give the chip two workgroups per CU
+        int cs = 1;
+        while (cs < 4 && (int64_t)((g.R + 128 / cs - 1) / (128 / cs)) * nchunks < 512) cs *= 2;
+        const int unit = 64 * cs;                                 // two 32-code tiles per wave
+        const int chunk = ((K + nchunks - 1) / nchunks + unit - 1) / unit * unit;
+        const size_t shm = (size_t)chunk * bpc + (size_t)(3 * 128 + 128 + 128 + 512) * sizeof(float);
+        PatchOffsets po;
+        for (int e = 0; e < 16; ++e) {
+            const int ee = e < D ? e : 0;
+            const int j = ee % pW, i = (ee / pW) % pH, c = ee / (pW * pH);
+            po.off[e] = (c * H + i) * W + j;
+        }
+        int64_t* direct_r = nchunks == 1 ? out_idx : (int64_t*)nullptr;
+        dim3 grid((g.R + 128 / cs - 1) / (128 / cs), nchunks), block(NTHREADS);
+#define QARIG_BMU_RES(KS_, CS_)                                                                    \
+        hipLaunchKernelGGL((bmu_resident_kernel<KS_, CS_>), grid, block, shm, st, g, po, codebook, K,  \
+                           chunk, part_d, part_i, part_s, part_x2, direct_r)
+#define QARIG_BMU_RES_CS(KS_)                                                                      \
+        do {                                                                                       \
+            if (cs == 1) QARIG_BMU_RES(KS_, 1);                                                    \
+            else if (cs == 2) QARIG_BMU_RES(KS_, 2);                                               \
+            else QARIG_BMU_RES(KS_, 4);                                                            \
+        } while (0)
+        if (ks == 2) QARIG_BMU_RES_CS(2);
+        else if (ks == 4) QARIG_BMU_RES_CS(4);
+        else QARIG_BMU_RES_CS(8);
+#undef QARIG_BMU_RES_CS
+#undef QARIG_BMU_RES
+        QARIG_CHECK_LAUNCH("bmu resident");
+        if (nchunks > 1) {
+            hipLaunchKernelGGL(bmu_finalize_kernel, dim3((g.R + 127) / 128), dim3(256), 0, st, g, codebook,
+                               K, part_d, part_i, part_s, part_x2, nchunks, out_idx);
+            QARIG_CHECK_LAUNCH("bmu finalize");
+        }
+        return QARIG_OK;
+    }
     if (D <= 64) {
         const int nkt = D <= 16 ? 1 : (D <= 32 ? 2 : 4);
         const size_t shm = (size_t)3 * nkt * TILE_FLOATS * sizeof(float);

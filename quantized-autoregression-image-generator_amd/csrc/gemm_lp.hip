@@ -63,16 +63,30 @@ __device__ __forceinline__ void lp_stage(const bf16_t* __restrict__ P, int64_t l
 }
 
 // Fragment of the 32-row (column) tile starting at x0 for k-step ks (16 deep): lane l holds
-// element j = operand(x0 + (l & 31), k = 16 ks + 8 (l >> 5) + j).
+// element j = operand(x0 + (l & 31), k = 16 ks + 8 (l >> 5) + j).  The LDS reads are inline asm
+// (hipcc would otherwise drain the DMA queue in front of every LDS read); their destination
+// registers are touched again only in value(), which callers invoke behind the lgkmcnt wait.
+typedef short s16x4_lp __attribute__((ext_vector_type(4)));
+typedef short s16x8_lp __attribute__((ext_vector_type(8)));
+template <bool TN> struct LpFrag {
+    bf16x8 v;
+    __device__ __forceinline__ bf16x8 value() const { return v; }
+};
+template <> struct LpFrag<true> {
+    s16x4_lp lo, hi;
+    __device__ __forceinline__ bf16x8 value() const {
+        const s16x8_lp both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, both);
+    }
+};
 template <bool TN>
-__device__ __forceinline__ void lp_frag(const bf16_t* tile, int x0, int ks, int lane, bf16x8& f) {
-    if (!TN) {
+__device__ __forceinline__ void lp_frag(const bf16_t* tile, int x0, int ks, int lane, LpFrag<TN>& f) {
+    if constexpr (!TN) {
         const int r = x0 + (lane & 31);
         const int c = (ks * 2 + (lane >> 5)) ^ (r & 7);
         const unsigned a = lds_addr_lp(tile) + r * 128 + (c << 4);
-        asm volatile("ds_read_b128 %0, %1" : "=v"(f) : "v"(a));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f.v) : "v"(a));
     } else {
-        typedef short s16x4 __attribute__((ext_vector_type(4)));
         const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
         const int ch = ((x0 + 16 * (g & 1)) >> 3) + (p >> 1);
         const int r0 = ks * 16 + 8 * (g >> 1) + q;
@@ -80,12 +94,8 @@ __device__ __forceinline__ void lp_frag(const bf16_t* tile, int x0, int ks, int 
         const unsigned base = lds_addr_lp(tile) + 8 * (p & 1);
         const unsigned a0 = base + 256 * r0 + ((ch ^ tn_swz(r0)) << 4);
         const unsigned a1 = base + 256 * r1 + ((ch ^ tn_swz(r1)) << 4);
-        s16x4 lo, hi;
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
-        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        f = __builtin_bit_cast(bf16x8, both);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a1));
     }
 }
 
@@ -127,7 +137,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_lp_kernel(const bf16_t* __re
             }
             const bf16_t* ta = lds + st * LP_STAGE;
             const bf16_t* tb = ta + LP_OP;
-            bf16x8 fa[4][2], fb[4][2];
+            // all 16 fragments of the stage are requested, then one wait: the other resident
+            // waves' MFMAs cover the reads (interleaving reads per k-step measured 8-17 % slower)
+            LpFrag<TNA> fa[4][2];
+            LpFrag<TNB> fb[4][2];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -144,8 +157,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_lp_kernel(const bf16_t* __re
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc.t[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j],
-                                                                              acc.t[i][j], 0, 0, 0);
+                        acc.t[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            fa[ks][i].value(), fb[ks][j].value(), acc.t[i][j], 0, 0, 0);
         }
     }
     __syncthreads();                      // ring no longer in use: the epilogue stages through it

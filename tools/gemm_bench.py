@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "quantized-autoregression-image-generator_
 import torch  # noqa: E402
 from qarig import ops  # noqa: E402
 
-M = 16384
+M = int(os.environ.get("ROWS", "16384"))   # ROWS=2048: the 8-sequence shard of BASELINE config 4
 SHAPES = [  # (name, M, N, K, a_kcontig, b_kcontig, kwargs)
     ("fwd 512->2048 +bias+silu+preact", M, 2048, 512, True, True, dict(bias=True, act=1, pre=True)),
     ("fwd 2048->512 +bias", M, 512, 2048, True, True, dict(bias=True)),
@@ -66,6 +66,31 @@ def main():
                     res.setdefault((name, st), []).append(2.0 * m * n * k / (e0.elapsed_time(e1) / 10) / 1e9)
         for name, m, n, k, kw in cases[:9]:
             print(f"{name:36s} " + "  ".join(f"{sweep_env[-8:]}={st}: {sorted(res[(name, st)])[2]:6.1f}" for st in sweep))
+        return
+    if os.environ.get("SPLITS"):
+        # SPLITS=0,1,2,4,8: time each shape (reduce pass included) per reduction split; 0 = the
+        # library's own choice (ops.auto_splitk for the forward shapes, pick_splitk for dW)
+        splits = [int(v) for v in os.environ["SPLITS"].split(",")]
+        for name, m, n, k, kw in cases[:9]:
+            line = []
+            for sk in splits:
+                kw2 = dict(kw)
+                kw2["splitk"] = (kw["splitk"] if kw["splitk"] > 1 else None) if sk == 0 else sk
+                if sk > 1 and (k % sk or (k // sk) % 16):
+                    continue
+                ts = []
+                for rnd in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ops.gemm(**kw2)
+                    e0.record()
+                    for _ in range(10):
+                        ops.gemm(**kw2)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) / 10)
+                us = sorted(ts)[2] * 1e3
+                line.append(f"sk={sk}: {us:6.1f} us {2.0 * m * n * k / us / 1e6:6.1f} TF")
+            print(f"{name:34s} M={m:5d} N={n:5d} K={k:5d}  " + " | ".join(line))
         return
     for rnd in range(4):
         for name, m, n, k, kw in cases:
