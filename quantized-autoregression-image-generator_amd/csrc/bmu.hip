@@ -463,7 +463,21 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 struct PatchOffsets {
     int off[16];   // element e of a patch, relative to the patch's first element
+    // floor(n / d) = (n * m) >> sh for 0 <= n < 2^31 (Granlund-Montgomery: m = floor(2^sh / d) + 1,
+    // sh = 31 + ceil(log2 d)): the two divisions of patch_row_base without ~35-op integer divides
+    unsigned m_per, m_gw;
+    int sh_per, sh_gw;
 };
+__device__ __forceinline__ int fast_div(int n, unsigned m, int sh) {
+    return (int)(((unsigned long long)(unsigned)n * m) >> sh);
+}
+__device__ __forceinline__ int64_t patch_row_base_fast(const PatchGeom& g, const PatchOffsets& po, int row) {
+    const int per = g.gh * g.gw;
+    const int n = fast_div(row, po.m_per, po.sh_per);
+    const int rem = row - n * per;
+    const int ph = fast_div(rem, po.m_gw, po.sh_gw), pw = rem - ph * g.gw;
+    return ((int64_t)n * g.C * g.H + (int64_t)ph * g.pH) * g.W + (int64_t)pw * g.pW;
+}
 
 constexpr int RES_MAX_LDS = 59 * 1024;   // staged codes; + 4.5 KB of combine scratch < 64 KB
 
@@ -568,68 +582,74 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_resident_kernel(PatchGeom g, 
     const int cbase = blockIdx.y * chunk;
     const int p0 = blockIdx.x * RPB;
 
-    // ---- stage the code range: one code per thread per pass
-    const bool vec = (g.D % 4 == 0) && (((uintptr_t)w & 15) == 0);
-    for (int c = tid; c < chunk; c += NTHREADS) {
-        const int code = cbase + c;
-        float we[2 * KS];
+    // ---- global loads first, all in flight together: this lane's patch row, then two codes
+    // per thread per staging pass (a launch of a few hundred workgroups is a chain of memory
+    // round trips before anything else: every dependent trip removed is ~0.7 us of its ~6)
+    const int rtile = wave / CS, cpart = wave % CS;
+    const int row = p0 + rtile * 32 + cl;
+    float xv[2 * KS];
+    {   // rows past the end read row 0 and are never written; po.off[e >= D] = off[0]
+        const float* px = g.x + patch_row_base_fast(g, po, row < g.R ? row : 0);
 #pragma unroll
-        for (int e = 0; e < 2 * KS; ++e) we[e] = 0.0f;
-        float w2 = INFINITY;
-        if (code < K) {
-            const float* wk = w + (int64_t)code * g.D;
+        for (int e = 0; e < 2 * KS; ++e) xv[e] = px[po.off[e]];
+    }
+    const bool vec = (g.D % 4 == 0) && (((uintptr_t)w & 15) == 0);
+    for (int c = tid; c < chunk; c += 2 * NTHREADS) {
+        float we[2][2 * KS];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int code = cbase + c + u * NTHREADS;
+            const float* wk = w + (int64_t)(code < K ? code : 0) * g.D;   // clamped: selected away below
             if (vec) {
 #pragma unroll
                 for (int q = 0; q < KS / 2; ++q) {
-                    const bool in = 4 * q < g.D;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(wk + (in ? 4 * q : 0));
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(wk + (4 * q < g.D ? 4 * q : 0));
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) we[4 * q + u] = in ? v[u] : 0.0f;
+                    for (int t = 0; t < 4; ++t) we[u][4 * q + t] = v[t];
                 }
-            } else {   // clamped address + select: no divergent branch per element
+            } else {
 #pragma unroll
-                for (int e = 0; e < 2 * KS; ++e) {
-                    const float v = wk[e < g.D ? e : 0];
-                    we[e] = e < g.D ? v : 0.0f;
-                }
+                for (int e = 0; e < 2 * KS; ++e) we[u][e] = wk[e < g.D ? e : 0];
             }
-            w2 = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 2 * KS; ++e) w2 = fmaf(we[e], we[e], w2);
         }
-        float* pe = AE + (size_t)c * KS;
-        float* po_ = AE + ((size_t)chunk + c) * KS;
-        if constexpr (KS == 8) {
-            const int sw = (c >> 3) & 1;
-            *reinterpret_cast<f32x4*>(pe + 4 * sw) = f32x4{-2.0f * we[0], -2.0f * we[2], -2.0f * we[4], -2.0f * we[6]};
-            *reinterpret_cast<f32x4*>(pe + 4 * (sw ^ 1)) = f32x4{-2.0f * we[8], -2.0f * we[10], -2.0f * we[12], -2.0f * we[14]};
-            *reinterpret_cast<f32x4*>(po_ + 4 * sw) = f32x4{-2.0f * we[1], -2.0f * we[3], -2.0f * we[5], -2.0f * we[7]};
-            *reinterpret_cast<f32x4*>(po_ + 4 * (sw ^ 1)) = f32x4{-2.0f * we[9], -2.0f * we[11], -2.0f * we[13], -2.0f * we[15]};
-        } else {
 #pragma unroll
-            for (int q = 0; q < KS; ++q) { pe[q] = -2.0f * we[2 * q]; po_[q] = -2.0f * we[2 * q + 1]; }
+        for (int u = 0; u < 2; ++u) {
+            const int cc = c + u * NTHREADS;
+            const bool live = cbase + cc < K;
+#pragma unroll
+            for (int e = 0; e < 2 * KS; ++e) we[u][e] = (live && e < g.D) ? we[u][e] : 0.0f;
+            float w2 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 2 * KS; ++e) w2 = fmaf(we[u][e], we[u][e], w2);
+            if (cc < chunk) {
+                float* pe = AE + (size_t)cc * KS;
+                float* po_ = AE + ((size_t)chunk + cc) * KS;
+                if constexpr (KS == 8) {
+                    const int sw = (cc >> 3) & 1;
+                    *reinterpret_cast<f32x4*>(pe + 4 * sw) = f32x4{-2.0f * we[u][0], -2.0f * we[u][2], -2.0f * we[u][4], -2.0f * we[u][6]};
+                    *reinterpret_cast<f32x4*>(pe + 4 * (sw ^ 1)) = f32x4{-2.0f * we[u][8], -2.0f * we[u][10], -2.0f * we[u][12], -2.0f * we[u][14]};
+                    *reinterpret_cast<f32x4*>(po_ + 4 * sw) = f32x4{-2.0f * we[u][1], -2.0f * we[u][3], -2.0f * we[u][5], -2.0f * we[u][7]};
+                    *reinterpret_cast<f32x4*>(po_ + 4 * (sw ^ 1)) = f32x4{-2.0f * we[u][9], -2.0f * we[u][11], -2.0f * we[u][13], -2.0f * we[u][15]};
+                } else {
+#pragma unroll
+                    for (int q = 0; q < KS; ++q) { pe[q] = -2.0f * we[u][2 * q]; po_[q] = -2.0f * we[u][2 * q + 1]; }
+                }
+                W2[cc] = live ? w2 : INFINITY;
+            }
         }
-        W2[c] = w2;
     }
 
-    // ---- this lane's patch row: all elements (the |x|^2 chain runs over them in order), then
-    // the half this lane feeds to the MFMA (k = 2 s + hi)
-    const int rtile = wave / CS, cpart = wave % CS;
-    const int row = p0 + rtile * 32 + cl;
-    // (no array of the row's elements: a select between two array slots becomes an indexed
-    // access, i.e. a trip through scratch memory)
+    // ---- the patch row: |x|^2 chain over its elements in order, then the half this lane feeds
+    // to the MFMA (k = 2 s + hi).  (A select between two slots of one array would become an
+    // indexed access, i.e. a trip through scratch memory: pairs of scalars instead.)
     float x2 = 0.0f;
     float b[KS];
-    {   // rows past the end read row 0 and are never written; po.off[e >= D] = off[0]
-        const float* px = g.x + patch_row_base(g, row < g.R ? row : 0);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float v0 = px[po.off[2 * s]], v1 = px[po.off[2 * s + 1]];
-            const float e0 = 2 * s < g.D ? v0 : 0.0f, e1 = 2 * s + 1 < g.D ? v1 : 0.0f;
-            x2 = fmaf(e0, e0, x2);
-            x2 = fmaf(e1, e1, x2);
-            b[s] = hi ? e1 : e0;
-        }
+    for (int s = 0; s < KS; ++s) {
+        const float e0 = 2 * s < g.D ? xv[2 * s] : 0.0f, e1 = 2 * s + 1 < g.D ? xv[2 * s + 1] : 0.0f;
+        x2 = fmaf(e0, e0, x2);
+        x2 = fmaf(e1, e1, x2);
+        b[s] = hi ? e1 : e0;
     }
     const float b_ext = hi ? 0.0f : 1.0f;
     __syncthreads();
@@ -1003,6 +1023,7 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
         // waves sharing a row tile: as few as still give the chip two workgroups per CU
         int cs = 1;
         while (cs < 4 && (int64_t)((g.R + 128 / cs - 1) / (128 / cs)) * nchunks < 512) cs *= 2;
+        if (const char* e = getenv("QARIG_BMU_CS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) cs = v; }
         const int unit = 64 * cs;                                 // two 32-code tiles per wave
         const int chunk = ((K + nchunks - 1) / nchunks + unit - 1) / unit * unit;
         const size_t shm = (size_t)chunk * bpc + (size_t)(3 * 128 + 128 + 128 + 512) * sizeof(float);
@@ -1012,6 +1033,14 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
             const int j = ee % pW, i = (ee / pW) % pH, c = ee / (pW * pH);
             po.off[e] = (c * H + i) * W + j;
         }
+        auto magic = [](int d, unsigned& m, int& sh) {
+            int L = 0;
+            while ((1LL << L) < d) ++L;
+            sh = 31 + L;
+            m = (unsigned)((1ULL << sh) / (unsigned long long)d + 1ULL);
+        };
+        magic(g.gh * g.gw, po.m_per, po.sh_per);
+        magic(g.gw, po.m_gw, po.sh_gw);
         int64_t* direct_r = nchunks == 1 ? out_idx : (int64_t*)nullptr;
         dim3 grid((g.R + 128 / cs - 1) / (128 / cs), nchunks), block(NTHREADS);
 #define QARIG_BMU_RES(KS_, CS_)                                                                    \

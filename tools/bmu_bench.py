@@ -22,6 +22,12 @@ SHAPES = [  # (name, latent shape, patch, K)
 
 
 def main():
+    if os.environ.get("K_SWEEP"):   # time against codebook size: slope = main loop, intercept = fixed cost
+        del SHAPES[:]
+        for k in (64, 256, 512, 768):
+            SHAPES.append((f"65536 rows x {k} x 16", (64, 4, 64, 64), (2, 2), k))
+        for k in (64, 256, 512, 768):
+            SHAPES.append((f"16384 rows x {k} x 16", (64, 4, 32, 32), (2, 2), k))
     dev = torch.device("cuda")
     g = torch.Generator().manual_seed(9)
     reps = 20
