@@ -392,6 +392,145 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_pf_kernel(const float* _
     gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, slabs);
 }
 
+// ---------------------------------------------------------------------------------
+// Paired form for launches of at most one workgroup per CU (M = a few thousand rows: the
+// per-GPU shard of a small global batch, autoregressive decode with many beams).  With 256
+// 128x128 tiles or fewer the kernels above leave one wave per SIMD, and a lone wave exposes
+// every barrier and DMA wait.  Here a workgroup is 8 waves = two 4-wave teams on the SAME tile:
+// team 0 reduces the first half of the block's k-range, team 1 the second, each through its own
+// 3-stage ring (96 KB of LDS), so every SIMD holds two waves at different points of the k-loop
+// without a second slab in HBM.  At the end the teams swap halves of their accumulators through
+// LDS: wave (team h, tile position w) keeps the 32-row half h of its 64x64 tile, adds its
+// partner's partial (low-k + high-k, a fixed order) and runs the epilogue on those 32 rows.
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(2 * NTHREADS, 1) void gemm_dma_pf2_kernel(const float* __restrict__ A, int64_t lda,
+                                                                       const float* __restrict__ B, int64_t ldb,
+                                                                       GemmEpilogue ep, int M, int N, int K,
+                                                                       int tiles_n, int splitk, float* slabs) {
+    constexpr int ST = 3;
+    constexpr int RING = ST * DMA_STAGE_FLOATS;                      // 48 KB per team
+    extern __shared__ __attribute__((aligned(16))) float lds2[];    // 2 rings = 96 KB
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    int k_begin = 0, k_end = K;
+    if (splitk > 1) {
+        const int per = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
+        k_begin = blockIdx.z * per;
+        k_end = min(K, k_begin + per);
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = wave8 >> 2, wave = wave8 & 3;
+    const int tt = tid & 255;                                        // thread index inside the team
+    const int nk = (k_end - k_begin) / BK / 2;                       // k-tiles per team (host: even split)
+    k_begin += team * nk * BK;
+    float* lds = lds2 + team * RING;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int x = lane & 31, h = lane >> 5;
+    const int last = k_begin + (nk - 1) * BK;
+
+    Acc acc;
+    acc_zero(acc);
+    float rs = 0.0f;
+    const bool do_rs = !AKC && ep.rowsum != nullptr && tn == 0 && tt < 128;
+    auto stage_of = [](int t) { return t % ST; };
+    auto issue = [&](int t) {
+        const int k = min(k_begin + t * BK, last);
+        float* dst = lds + stage_of(t) * DMA_STAGE_FLOATS;
+        dma_tile<AKC>(A, lda, m0, k, dst, wave, lane);
+        dma_tile<BKC>(B, ldb, n0, k, dst + DMA_OP_FLOATS, wave, lane);
+    };
+    auto rowsum_tile = [&](int t) {
+        f32x4 r0, r1, r2, r3;
+        const float* ta = lds + stage_of(t) * DMA_STAGE_FLOATS;
+        frag_read<false>(ta, tt, 0, r0, r1);
+        frag_read<false>(ta, tt, 1, r2, r3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rs += r0[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rs += r1[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rs += r2[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rs += r3[q];
+    };
+    // both teams run the same number of k-tiles, so the workgroup-wide barriers pair up
+    {
+        issue(0);
+        issue(1);
+        issue(2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        Frags8 P, Q;
+        frags_read<AKC, BKC>(P, lds, lds + DMA_OP_FLOATS, wm, wn, x, h);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_rs) rowsum_tile(0);
+        int t = 0;
+#define QARIG_PF_BODY(CUR, NXT)                                                                   \
+        {                                                                                         \
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                      \
+            __builtin_amdgcn_s_barrier();                                                         \
+            issue(t + 3);                                                                         \
+            const float* na = lds + stage_of(t + 1) * DMA_STAGE_FLOATS;                           \
+            frags_read<AKC, BKC>(NXT, na, na + DMA_OP_FLOATS, wm, wn, x, h);                      \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            frags_mma(acc, CUR);                                                                  \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            if (do_rs && t + 1 < nk) rowsum_tile(t + 1);                                          \
+            ++t;                                                                                  \
+        }
+        while (t + 2 <= nk) {
+            QARIG_PF_BODY(P, Q)
+            QARIG_PF_BODY(Q, P)
+        }
+        if (t < nk) QARIG_PF_BODY(P, Q)
+#undef QARIG_PF_BODY
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();                      // both rings idle: exchange + epilogue staging reuse them
+    // ---- swap accumulator halves: this wave sends its partial of the 32-row half it does NOT keep
+    float* xch = lds2;                    // [8 waves][8 x f32x4][64 lanes]: 64 KB
+    {
+        f32x4* mine = reinterpret_cast<f32x4*>(xch) + (size_t)wave8 * 8 * 64 + lane;
+        auto send = [&](const f32x16& s, int j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                mine[(j * 4 + q) * 64] = f32x4{s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]};
+        };
+        if (team == 0) { send(acc.t[1][0], 0); send(acc.t[1][1], 1); }      // wave-uniform branch
+        else { send(acc.t[0][0], 0); send(acc.t[0][1], 1); }
+    }
+    float* rsx = lds2 + 8 * 8 * 64 * 4;   // 128 floats behind the exchange buffer
+    if (do_rs && team == 1) rsx[tt] = rs;
+    __syncthreads();
+    {
+        const f32x4* theirs = reinterpret_cast<const f32x4*>(xch) + (size_t)(wave8 ^ 4) * 8 * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = theirs[(j * 4 + q) * 64];
+                // low-k partial + high-k partial
+                if (team == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc.t[0][j][4 * q + u] = acc.t[0][j][4 * q + u] + v[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc.t[1][j][4 * q + u] = v[u] + acc.t[1][j][4 * q + u];
+                }
+            }
+    }
+    if (do_rs && team == 0) ep.rowsum[(int64_t)blockIdx.z * M + m0 + tt] = rs + rsx[tt];
+    __syncthreads();                      // exchange buffer read: the epilogue stages through it
+    gemm_epilogue_wave(acc, ep, lds2 + wave8 * (32 * 64), m0 + wm * 64, n0 + wn * 64, M, N, splitk, slabs,
+                       team, team + 1);
+}
+
 // out[i] (+ld handling) = sum_z slabs[z][i], z ascending: deterministic.
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                    int64_t ldc, int M, int N, int nslab, int accumulate) {
@@ -646,7 +785,35 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     // QARIG_GEMM_PF=0 restores the 2-stage kernel, =1 forces the prefetch form on every shape
     const char* pf_e = getenv("QARIG_GEMM_PF");
     const bool pf = pf_e ? pf_e[0] == '1' || (pf_e[0] != '0' && dma_shape) : (dma_on && dma_shape);
-    if (pf && fast && vec_epi && !(a_rowsum && a_kcontig) && !(!a_kcontig && b_kcontig)) {
+    // paired form (two 4-wave teams per tile, 96 KB of LDS): launches that would leave one
+    // workgroup per CU; QARIG_GEMM_PAIR=0 disables, =1 forces it wherever it is eligible
+    static const int pair_env = []() { const char* e = getenv("QARIG_GEMM_PAIR"); return e ? atoi(e) : -1; }();
+    const int nk_block = per / BK;
+    const bool pair_ok = dma_on && fast && vec_epi && !(a_rowsum && a_kcontig) && !(!a_kcontig && b_kcontig) &&
+                         nk_block % 2 == 0 && nk_block >= 4;
+    if (pair_ok && pair_env != 0 && (pair_env == 1 || (long)grid.x * grid.z <= 256)) {
+        constexpr int PAIR_LDS = 2 * 3 * DMA_STAGE_FLOATS * (int)sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_dma_pf2_kernel<true, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS);
+            (void)hipFuncSetAttribute((const void*)gemm_dma_pf2_kernel<true, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS);
+            (void)hipFuncSetAttribute((const void*)gemm_dma_pf2_kernel<false, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS);
+            attr_set = true;
+        }
+        dim3 block2(2 * NTHREADS);
+        if (a_kcontig && b_kcontig)
+            hipLaunchKernelGGL((gemm_dma_pf2_kernel<true, true>), grid, block2, PAIR_LDS, st, A, lda, B, ldb, ep,
+                               M, N, K, tiles_n, splitk, slabs);
+        else if (a_kcontig)
+            hipLaunchKernelGGL((gemm_dma_pf2_kernel<true, false>), grid, block2, PAIR_LDS, st, A, lda, B, ldb, ep,
+                               M, N, K, tiles_n, splitk, slabs);
+        else
+            hipLaunchKernelGGL((gemm_dma_pf2_kernel<false, false>), grid, block2, PAIR_LDS, st, A, lda, B, ldb, ep,
+                               M, N, K, tiles_n, splitk, slabs);
+    } else if (pf && fast && vec_epi && !(a_rowsum && a_kcontig) && !(!a_kcontig && b_kcontig)) {
         if (a_kcontig && b_kcontig)
             hipLaunchKernelGGL((gemm_dma_pf_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
                                N, K, tiles_n, splitk, slabs);

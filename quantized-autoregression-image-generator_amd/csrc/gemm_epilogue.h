@@ -40,7 +40,32 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 template <int NJ = 2>
 __device__ __forceinline__ void gemm_epilogue_wave(const Acc& acc, const GemmEpilogue& ep, float* stage,
                                                    int mb, int nb, int M, int N, int splitk,
-                                                   float* slabs);
+                                                   float* slabs, int i_begin = 0, int i_end = 2);
+
+// Activation ids as template arguments: ACT_RUNTIME keeps the per-element switch on the runtime id.
+// The epilogue is specialised for the combinations the Transformer uses (plain, SiLU forward, SiLU
+// backward fusion): with the switch inside the element loop every output value costs two scalar
+// branch trees, and a K = 512 tile spends ~15 % of its time there (fp32 MFMA and the rest of the
+// instruction stream do not overlap on this chip).
+constexpr int ACT_RUNTIME = -1;
+template <int A>
+__device__ __forceinline__ float act_fwd_t(float x, int act) {
+    if constexpr (A == ACT_RUNTIME) return act_fwd(x, act);
+    else if constexpr (A == ACT_SILU) return x * sigmoid_f(x);
+    else return x;
+}
+template <int A>
+__device__ __forceinline__ float act_grad_t(float x, int act) {
+    if constexpr (A == ACT_RUNTIME) return act_grad(x, act);
+    else if constexpr (A == ACT_SILU) {
+        const float sg = sigmoid_f(x);
+        return sg * (1.0f + x * (1.0f - sg));
+    } else return 1.0f;
+}
+template <int NJ, int A, int GA>
+__device__ __forceinline__ void gemm_epilogue_wave_t(const Acc& acc, const GemmEpilogue& ep, float* stage,
+                                                     int mb, int nb, int M, int N, int splitk,
+                                                     float* slabs, int i_begin, int i_end);
 
 __device__ __forceinline__ void gemm_epilogue_wide(const Acc& acc, const GemmEpilogue& ep, float* lds,
                                                    int m0, int n0, int M, int N, int splitk,
@@ -51,10 +76,27 @@ __device__ __forceinline__ void gemm_epilogue_wide(const Acc& acc, const GemmEpi
                        splitk, slabs);
 }
 
+// [i_begin, i_end): which 32-row halves of the wave's tile this call stores (wave-uniform; the
+// paired kernel gives each of its two waves per tile one half).
 template <int NJ>
 __device__ __forceinline__ void gemm_epilogue_wave(const Acc& acc, const GemmEpilogue& ep, float* stage,
                                                    int mb, int nb, int M, int N, int splitk,
-                                                   float* slabs) {
+                                                   float* slabs, int i_begin, int i_end) {
+    const bool grad = ep.gradz != nullptr || ep.gradzb != nullptr;
+    if (ep.act == ACT_NONE && !grad)
+        gemm_epilogue_wave_t<NJ, ACT_NONE, ACT_NONE>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
+    else if (ep.act == ACT_SILU && !grad)
+        gemm_epilogue_wave_t<NJ, ACT_SILU, ACT_NONE>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
+    else if (ep.act == ACT_NONE && ep.gact == ACT_SILU)
+        gemm_epilogue_wave_t<NJ, ACT_NONE, ACT_SILU>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
+    else
+        gemm_epilogue_wave_t<NJ, ACT_RUNTIME, ACT_RUNTIME>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
+}
+
+template <int NJ, int A, int GA>
+__device__ __forceinline__ void gemm_epilogue_wave_t(const Acc& acc, const GemmEpilogue& ep, float* stage,
+                                                     int mb, int nb, int M, int N, int splitk,
+                                                     float* slabs, int i_begin, int i_end) {
     const int lane = threadIdx.x & 63;
     const int cl = lane & 31;
     // unpadded rows are conflict-free for both the b32 writes (half-waves hit different rows)
@@ -67,6 +109,7 @@ __device__ __forceinline__ void gemm_epilogue_wave(const Acc& acc, const GemmEpi
     if (ep.bias && splitk == 1) bv = *reinterpret_cast<const float4*>(ep.bias + gc);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        if (i < i_begin || i >= i_end) continue;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -91,18 +134,20 @@ __device__ __forceinline__ void gemm_epilogue_wave(const Acc& acc, const GemmEpi
             if (ep.Pb)
                 *reinterpret_cast<uint2*>(ep.Pb + row * ep.ldpb + gc) =
                     make_uint2(pack_bf16x2(t.x, t.y), pack_bf16x2(t.z, t.w));
-            float4 y = make_float4(act_fwd(t.x, ep.act), act_fwd(t.y, ep.act),
-                                   act_fwd(t.z, ep.act), act_fwd(t.w, ep.act));
-            if (ep.gradz) {
-                const float4 z = *reinterpret_cast<const float4*>(ep.gradz + row * ep.ldz + gc);
-                y.x *= act_grad(z.x, ep.gact); y.y *= act_grad(z.y, ep.gact);
-                y.z *= act_grad(z.z, ep.gact); y.w *= act_grad(z.w, ep.gact);
-            } else if (ep.gradzb) {
-                const uint2 zb = *reinterpret_cast<const uint2*>(ep.gradzb + row * ep.ldzb + gc);
-                y.x *= act_grad(bf16_bits_to_f32(zb.x & 0xffffu), ep.gact);
-                y.y *= act_grad(bf16_bits_to_f32(zb.x >> 16), ep.gact);
-                y.z *= act_grad(bf16_bits_to_f32(zb.y & 0xffffu), ep.gact);
-                y.w *= act_grad(bf16_bits_to_f32(zb.y >> 16), ep.gact);
+            float4 y = make_float4(act_fwd_t<A>(t.x, ep.act), act_fwd_t<A>(t.y, ep.act),
+                                   act_fwd_t<A>(t.z, ep.act), act_fwd_t<A>(t.w, ep.act));
+            if constexpr (GA != ACT_NONE) {   // (a gradz with gact = none multiplies by 1)
+                if (ep.gradz) {
+                    const float4 z = *reinterpret_cast<const float4*>(ep.gradz + row * ep.ldz + gc);
+                    y.x *= act_grad_t<GA>(z.x, ep.gact); y.y *= act_grad_t<GA>(z.y, ep.gact);
+                    y.z *= act_grad_t<GA>(z.z, ep.gact); y.w *= act_grad_t<GA>(z.w, ep.gact);
+                } else if (ep.gradzb) {
+                    const uint2 zb = *reinterpret_cast<const uint2*>(ep.gradzb + row * ep.ldzb + gc);
+                    y.x *= act_grad_t<GA>(bf16_bits_to_f32(zb.x & 0xffffu), ep.gact);
+                    y.y *= act_grad_t<GA>(bf16_bits_to_f32(zb.x >> 16), ep.gact);
+                    y.z *= act_grad_t<GA>(bf16_bits_to_f32(zb.y & 0xffffu), ep.gact);
+                    y.w *= act_grad_t<GA>(bf16_bits_to_f32(zb.y >> 16), ep.gact);
+                }
             }
             if (ep.C) *reinterpret_cast<float4*>(ep.C + row * ep.ldc + gc) = y;
             if (ep.Cb)

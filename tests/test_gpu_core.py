@@ -98,6 +98,54 @@ def test_gemm_skinny_decode_shapes(M, N, K):
     assert torch.equal(ops.gemm(A, W), ops.gemm(A, W, splitk=4))    # own K split, deterministic
 
 
+@pytest.mark.parametrize("M,N,K,ak,bk,splitk", [
+    (2048, 2048, 512, True, True, 1),      # 256 tiles: Linear 512->2048 of an 8-sequence shard
+    (2048, 2048, 512, True, False, 1),     # input gradient of 2048->512... operand order (kc, xc)
+    (2048, 512, 2048, True, True, 4),      # 64 tiles x 4 slabs
+    (2048, 512, 2048, False, False, 4),    # weight gradient (xc, xc) with the A row sums riding on it
+    (1024, 1024, 256, True, True, 1),      # 64 tiles, 8 k-tiles per team
+    (512, 640, 1024, False, False, 2),     # ragged tile count (4 x 5), two slabs
+])
+def test_gemm_paired_teams(M, N, K, ak, bk, splitk):
+    """Launches of at most one workgroup per CU run the paired kernel (two 4-wave teams per tile,
+    each reducing half of the k-range, accumulators swapped through LDS): every epilogue option
+    against fp64, the bias-gradient row sums, determinism, and agreement with the one-team
+    kernels up to the changed summation order."""
+    from qarig import ops
+    from oracle import ref_models as rm
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + splitk)
+    A = torch.randn((M, K) if ak else (K, M), generator=g).cuda()
+    B = (torch.randn((N, K) if bk else (K, N), generator=g) * 0.1).cuda()
+    ref = _ref_gemm(A, B, ak, bk)
+    tol = GEMM_TOL * max(1, K / 512) ** 0.5
+    C = ops.gemm(A, B, ak, bk, splitk=splitk)
+    assert rel_err(C, ref) < tol
+    assert torch.equal(C, ops.gemm(A, B, ak, bk, splitk=splitk))
+    if splitk == 1:
+        b = torch.randn((N,), generator=g).cuda()
+        R = torch.randn((M, N), generator=g).cuda()
+        Z = torch.randn((M, N), generator=g).cuda()
+        for act_name, act in (("silu", 1), ("tanh", 2), (None, 0)):
+            Y, pre = ops.gemm(A, B, ak, bk, bias=b, residual=R, want_preact=True, act=act)
+            t = ref + b.double().cpu() + R.double().cpu()
+            assert rel_err(pre, t) < tol
+            # |t| reaches 14 here: its 5e-7 relative error is 7e-6 absolute, which tanh passes
+            # through unchanged near 0 where |tanh| <= 1 is the scale of the comparison
+            assert rel_err(Y, rm.activation(t, act_name)) < (2e-5 if act_name == "tanh" else 5e-6)
+        Zd = Z.double().cpu().requires_grad_(True)
+        rm.activation(Zd, "silu").sum().backward()
+        assert rel_err(ops.gemm(A, B, ak, bk, gradz=Z, gact=1), ref * Zd.grad) < 5e-6
+        out = torch.randn((M, N), generator=g).cuda()
+        want = out.double().cpu() + ref
+        ops.gemm(A, B, ak, bk, out=out, accumulate=True)
+        assert rel_err(out, want) < tol
+    if not ak:
+        rs = torch.zeros(M, device="cuda")
+        C2 = ops.gemm(A, B, ak, bk, splitk=splitk, a_rowsum=rs)
+        assert torch.equal(C2, C)
+        assert rel_err(rs, A.double().cpu().sum(0)) < 2e-6 * max(1, K / 512) ** 0.5
+
+
 def test_gemm_strided_views():
     from qarig import ops
     g = torch.Generator().manual_seed(2)
