@@ -92,6 +92,21 @@ int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t ldb, int la
                   int gradz_is_bf16, int gact, int splitk, int accumulate, void* Cb, int64_t ldcb,
                   void* Pb, int64_t ldpb, void* workspace, size_t ws_bytes, void* stream);
 
+/* fp8 (OCP e4m3) forward products of the same Linear layers (BASELINE config 5 names the fp8
+ * MFMA; models/layers.py:234-254, 389-418): A (M,K) and B (N,K) are e4m3 BYTES quantised per
+ * tensor by qarig_cast_fp8 (scale 448 / max|x|; lda / ldb in bytes), products on
+ * v_mfma_f32_32x32x64_f8f6f4, fp32 accumulation, the accumulator multiplied by the two device
+ * scalars inv_a[0] * inv_b[0] before the usual epilogue.  qarig_cast_fp8: dst = n bytes,
+ * inv_scale[0] receives max|x| / 448, scratch = 4 bytes of device memory (receives max|x|),
+ * bf16_dst = optional bf16 copy of src from the same pass (the backward products read it). */
+int qarig_gemm_f8_supported(int M, int N, int K);
+int qarig_cast_fp8(const float* src, int64_t n, void* dst, float* inv_scale, void* scratch,
+                   void* bf16_dst, void* stream);
+int qarig_gemm_f8(const void* A, int64_t lda, const void* B, int64_t ldb, const float* inv_a,
+                  const float* inv_b, float* C, int64_t ldc, int M, int N, int K, const float* bias,
+                  const float* residual, int64_t ldr, float* preact, int64_t ldp, int act, void* Cb,
+                  int64_t ldcb, void* Pb, int64_t ldpb, void* stream);
+
 /* Operand conversion of the reduced-precision mode (no reference counterpart): fp32 -> bf16,
  * round to nearest even; n contiguous elements, or the transpose (C, R) of a (R, C) matrix
  * with row stride ld (the W^T shadow of an nn.Linear weight). */

@@ -19,6 +19,9 @@ struct GemmEpilogue {
     unsigned short* Cb; int64_t ldcb;     // optional bf16 copy of what goes to C (consumer GEMMs), or null
     unsigned short* Pb; int64_t ldpb;     // optional bf16 copy of the saved pre-activation, or null
     const unsigned short* gradzb; int64_t ldzb;   // gradz given in bf16 (reduced-precision mode), or null
+    // fp8 operands (gemm_f8_kernel): the accumulator is multiplied by *alpha_a * *alpha_b (the two
+    // per-tensor dequantisation factors, device scalars written by the cast kernels) first; or null
+    const float* alpha_a; const float* alpha_b;
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned int hi16) { return __uint_as_float(hi16 << 16); }
@@ -107,6 +110,7 @@ __device__ __forceinline__ void gemm_epilogue_wave_t(const Acc& acc, const GemmE
     const int gc = nb + ec;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ep.bias && splitk == 1) bv = *reinterpret_cast<const float4*>(ep.bias + gc);
+    const float alpha = ep.alpha_a ? *ep.alpha_a * *ep.alpha_b : 1.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         if (i < i_begin || i >= i_end) continue;
@@ -125,6 +129,7 @@ __device__ __forceinline__ void gemm_epilogue_wave_t(const Acc& acc, const GemmE
                 *reinterpret_cast<float4*>(slabs + ((int64_t)blockIdx.z * M + row) * N + gc) = t;
                 continue;
             }
+            if (ep.alpha_a) { t.x *= alpha; t.y *= alpha; t.z *= alpha; t.w *= alpha; }
             t.x += bv.x; t.y += bv.y; t.z += bv.z; t.w += bv.w;
             if (ep.residual) {
                 const float4 rv = *reinterpret_cast<const float4*>(ep.residual + row * ep.ldr + gc);

@@ -165,6 +165,122 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_lp_kernel(const bf16_t* __re
     gemm_epilogue_wide(acc, ep, reinterpret_cast<float*>(lds), m0, n0, M, N, splitk, slabs);
 }
 
+// ---------------------------------------------------------------------------------
+// fp8 (OCP e4m3) operands: BASELINE config 5 names the fp8 MFMA.  NT layout only (the forward
+// products x W^T): A (M,K) and B (N,K) are bytes, per-tensor scaled by the cast kernels below;
+// products on v_mfma_f32_32x32x64_f8f6f4 (64 deep per instruction, twice the bf16 rate), fp32
+// accumulation, the accumulator multiplied by the two dequantisation factors in the shared
+// epilogue.  A 128-deep k-tile is 128 bytes per row: the LDS image, its DMA and its chunk
+// swizzle are exactly those of the bf16 NT tile (lp_stage<false> on the bytes).
+// Fragment for k-step ks (64 deep): lane l holds the 32 bytes k = 64 ks + 32 (l >> 5) ... + 31 of
+// row x0 + (l & 31) = two 16-B chunks.
+typedef int i32x8_f8 __attribute__((ext_vector_type(8)));
+typedef int i32x4_f8 __attribute__((ext_vector_type(4)));
+struct F8Frag {
+    i32x4_f8 lo, hi;
+    __device__ __forceinline__ i32x8_f8 value() const {
+        return i32x8_f8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+};
+__device__ __forceinline__ void f8_frag(const bf16_t* tile, int x0, int ks, int lane, F8Frag& f) {
+    const int r = x0 + (lane & 31);
+    const int c0 = ks * 4 + (lane >> 5) * 2;
+    const unsigned base = lds_addr_lp(tile) + r * 128;
+    const unsigned a0 = base + (((c0) ^ (r & 7)) << 4), a1 = base + (((c0 + 1) ^ (r & 7)) << 4);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f.lo) : "v"(a0));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(f.hi) : "v"(a1));
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_f8_kernel(const unsigned char* __restrict__ A, int64_t lda,
+                                                              const unsigned char* __restrict__ B, int64_t ldb,
+                                                              GemmEpilogue ep, int M, int N, int K, int tiles_n) {
+    constexpr int FBK = 128;                                             // bytes = elements per k-tile
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * LP_STAGE];   // 64 KB: 2 workgroups per CU
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = K / FBK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // the byte matrices seen as 2-byte elements: leading dimensions and k offsets halve
+    const bf16_t* A2 = reinterpret_cast<const bf16_t*>(A);
+    const bf16_t* B2 = reinterpret_cast<const bf16_t*>(B);
+    const int64_t lda2 = lda / 2, ldb2 = ldb / 2;
+
+    Acc acc;
+    acc_zero(acc);
+    if (nk > 0) {
+        lp_stage<false>(A2, lda2, m0, 0, lds, wave, lane);
+        lp_stage<false>(B2, ldb2, n0, 0, lds + LP_OP, wave, lane);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int st = kt & 1;
+            if (kt + 1 < nk) {
+                const int kn = (kt + 1) * (FBK / 2);
+                lp_stage<false>(A2, lda2, m0, kn, lds + (st ^ 1) * LP_STAGE, wave, lane);
+                lp_stage<false>(B2, ldb2, n0, kn, lds + (st ^ 1) * LP_STAGE + LP_OP, wave, lane);
+            }
+            const bf16_t* ta = lds + st * LP_STAGE;
+            const bf16_t* tb = ta + LP_OP;
+            F8Frag fa[2][2], fb[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f8_frag(ta, wm * 64 + i * 32, ks, lane, fa[ks][i]);
+                    f8_frag(tb, wn * 64 + i * 32, ks, lane, fb[ks][i]);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc.t[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                            fa[ks][i].value(), fb[ks][j].value(), acc.t[i][j], 0, 0, 0, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    gemm_epilogue_wide(acc, ep, reinterpret_cast<float*>(lds), m0, n0, M, N, 1, nullptr);
+}
+
+// |x| maximum of a tensor as the bit pattern of a non-negative float (they order like
+// unsigned integers): *amax_bits must be zero before the launch.
+// With `bf` the bf16 copy of x (what the backward products read) is written in the same pass.
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n4,
+                                                   unsigned* __restrict__ amax_bits, uint2* __restrict__ bf) {
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        if (bf) bf[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
+}
+// dst = e4m3(src * 448 / amax) (round to nearest even, saturating), *inv_scale = amax / 448: the
+// factor that takes products of the quantised values back.  amax = 0 quantises with scale 1.
+constexpr float F8_MAX = 448.0f;
+__global__ __launch_bounds__(256) void cast_fp8_kernel(const float* __restrict__ src, int64_t n4,
+                                                       const unsigned* __restrict__ amax_bits,
+                                                       unsigned* __restrict__ dst, float* __restrict__ inv_scale) {
+    const float amax = __uint_as_float(*amax_bits);
+    const float scale = amax > 0.0f ? F8_MAX / amax : 1.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *inv_scale = amax > 0.0f ? amax / F8_MAX : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        int p = __builtin_amdgcn_cvt_pk_fp8_f32(v.x * scale, v.y * scale, 0, false);
+        p = __builtin_amdgcn_cvt_pk_fp8_f32(v.z * scale, v.w * scale, p, true);
+        dst[i] = (unsigned)p;
+    }
+}
+
 // dst[i] = bf16(src[i]), round to nearest even; n % 8 == 0, 16-B aligned.
 __global__ void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n8) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
@@ -429,5 +545,65 @@ extern "C" int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t 
     QARIG_CHECK_LAUNCH("gemm_lp");
     if (splitk > 1)
         return qarig_slab_reduce_f32((const float*)workspace, C, ldc, M, N, splitk, accumulate, stream);
+    return QARIG_OK;
+}
+
+// ---- fp8 (e4m3) operands: see gemm_f8_kernel ------------------------------------------------
+extern "C" int qarig_gemm_f8_supported(int M, int N, int K) {
+    return M > 0 && N > 0 && K > 0 && M % BM == 0 && N % BN == 0 && K % 128 == 0;
+}
+
+// dst (n bytes, e4m3) = quantised src (n floats) with one scale for the tensor; scratch[0] receives
+// the |x| maximum (as float bits; zeroed here), inv_scale[0] the dequantisation factor; bf16_dst
+// (optional, n elements) the bf16 copy of src, written by the pass that finds the maximum.
+extern "C" int qarig_cast_fp8(const float* src, int64_t n, void* dst, float* inv_scale, void* scratch,
+                              void* bf16_dst, void* stream) {
+    QARIG_CHECK_ARG(src && dst && inv_scale && scratch, "cast_fp8: null pointer");
+    QARIG_CHECK_ARG(((uintptr_t)bf16_dst & 7) == 0, "cast_fp8: bf16 copy 8-B aligned");
+    QARIG_CHECK_ARG(n > 0 && n % 4 == 0 && n < (1LL << 40), "cast_fp8: n must be a positive multiple of 4");
+    QARIG_CHECK_ARG((((uintptr_t)src & 15) | ((uintptr_t)dst & 3) | ((uintptr_t)scratch & 3)) == 0,
+                    "cast_fp8: src 16-B aligned, dst 4-B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    if (hipMemsetAsync(scratch, 0, 4, st) != hipSuccess) {
+        qarig_set_error("cast_fp8: memset failed");
+        return QARIG_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, st, src, n4, (unsigned*)scratch,
+                       (uint2*)bf16_dst);
+    QARIG_CHECK_LAUNCH("cast_fp8 amax");
+    hipLaunchKernelGGL(cast_fp8_kernel, dim3(blocks), dim3(256), 0, st, src, n4, (const unsigned*)scratch,
+                       (unsigned*)dst, inv_scale);
+    QARIG_CHECK_LAUNCH("cast_fp8");
+    return QARIG_OK;
+}
+
+// C[M,N] = epilogue(inv_a * inv_b * sum_k A8[m][k] B8[n][k]): A8 (M,K), B8 (N,K) e4m3 bytes,
+// inv_a / inv_b the device scalars qarig_cast_fp8 wrote.  Epilogue options as qarig_gemm_lp
+// (no backward fusion, no split-K, no accumulate).
+extern "C" int qarig_gemm_f8(const void* A, int64_t lda, const void* B, int64_t ldb, const float* inv_a,
+                             const float* inv_b, float* C, int64_t ldc, int M, int N, int K,
+                             const float* bias, const float* residual, int64_t ldr, float* preact,
+                             int64_t ldp, int act, void* Cb, int64_t ldcb, void* Pb, int64_t ldpb,
+                             void* stream) {
+    QARIG_CHECK_ARG(A && B && inv_a && inv_b && (C || Cb), "gemm_f8: null operand");
+    QARIG_CHECK_ARG(act >= 0 && act <= 3, "gemm_f8: bad activation id");
+    QARIG_CHECK_ARG(qarig_gemm_f8_supported(M, N, K),
+                    "gemm_f8: needs M,N %% 128 == 0 and K %% 128 == 0 (M=%d N=%d K=%d)", M, N, K);
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    QARIG_CHECK_ARG(al16(A) && al16(B) && lda % 16 == 0 && ldb % 16 == 0, "gemm_f8: operands 16-B aligned, ld %% 16");
+    auto ok4 = [&](const void* p, int64_t ld) { return !p || (al16(p) && ld % 4 == 0); };
+    QARIG_CHECK_ARG(ok4(C, ldc) && ok4(bias, 4) && ok4(residual, ldr) && ok4(preact, ldp),
+                    "gemm_f8: fp32 epilogue tensors 16-B aligned, ld %% 4");
+    QARIG_CHECK_ARG((!Cb || (((uintptr_t)Cb & 7) == 0 && ldcb % 4 == 0)) &&
+                        (!Pb || (((uintptr_t)Pb & 7) == 0 && ldpb % 4 == 0)),
+                    "gemm_f8: bf16 outputs 8-B aligned, ld %% 4");
+    const int tiles_m = M / BM, tiles_n = N / BN;
+    GemmEpilogue ep{C, ldc, bias, residual, ldr, preact, ldp, act, nullptr, 0, 0, nullptr,
+                    (unsigned short*)Cb, ldcb, (unsigned short*)Pb, ldpb, nullptr, 0, inv_a, inv_b};
+    hipLaunchKernelGGL(gemm_f8_kernel, dim3(tiles_m * tiles_n), dim3(NTHREADS), 0, (hipStream_t)stream,
+                       (const unsigned char*)A, lda, (const unsigned char*)B, ldb, ep, M, N, K, tiles_n);
+    QARIG_CHECK_LAUNCH("gemm_f8");
     return QARIG_OK;
 }

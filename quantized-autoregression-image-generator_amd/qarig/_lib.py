@@ -34,6 +34,9 @@ SIGNATURES = {
     "qarig_gemm_lp_workspace_bytes": (Z, [I, I, I]),
     "qarig_gemm_lp": (I, [P, L, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, I, I, P, L, P, L, P, Z,
                           P]),
+    "qarig_gemm_f8_supported": (I, [I, I, I]),
+    "qarig_cast_fp8": (I, [P, L, P, P, P, P, P]),
+    "qarig_gemm_f8": (I, [P, L, P, L, P, P, P, L, I, I, I, P, P, L, P, L, I, P, L, P, L, P]),
     "qarig_cast_colsum_workspace_bytes": (Z, [I, I]),
     "qarig_cast_colsum": (I, [P, L, I, I, I, P, P, I, P, Z, P]),
     "qarig_cast_bf16": (I, [P, P, L, P]),

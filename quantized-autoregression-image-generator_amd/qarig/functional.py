@@ -123,7 +123,7 @@ def _lp():
 
 
 def linear_act(x, weight, bias=None, residual=None, act=0):
-    if ops.PRECISION == "bf16" and not _no_grad() and _lp().linear_supported(x, weight):
+    if ops.lp_mode() and not _no_grad() and _lp().linear_supported(x, weight):
         return _lp()._LinearActLP.apply(x, weight, bias, residual, act)
     if _no_grad():   # inference: straight to the kernel, no autograd node, no saved tensors
         require_cuda(x, weight)
@@ -217,7 +217,7 @@ class _MLP2(torch.autograd.Function):
 
 
 def mlp2(x, w1, b1, w2, b2, act1, act2=0):
-    if ops.PRECISION == "bf16" and not _no_grad() and _lp().mlp2_supported(x, w1, w2):
+    if ops.lp_mode() and not _no_grad() and _lp().mlp2_supported(x, w1, w2):
         return _lp()._MLP2LP.apply(x, w1, b1, w2, b2, act1, act2)
     if _no_grad():
         require_cuda(x, w1, w2)
@@ -289,7 +289,7 @@ def mlp2x3(x, blocks_params, act1, act2=0):
     """blocks_params: three (w1, b1, w2, b2) tuples (q, k, v).  Returns (q, k, v)."""
     if _no_grad():
         return tuple(mlp2(x, *p, act1, act2) for p in blocks_params)
-    if ops.PRECISION == "bf16" and all(_lp().mlp2_supported(x, p[0], p[2]) and p[2].shape[0] % 128 == 0
+    if ops.lp_mode() and all(_lp().mlp2_supported(x, p[0], p[2]) and p[2].shape[0] % 128 == 0
                                        for p in blocks_params):
         return _lp()._MLP2x3LP.apply(x, act1, act2, *[t for p in blocks_params for t in p])
     return _MLP2x3.apply(x, act1, act2, *[t for p in blocks_params for t in p])

@@ -47,6 +47,29 @@ def _shadow(w, transpose=False, pad_rows=0):
     return ops.cast_transpose_bf16(wd, cache=True) if transpose else ops.cast_bf16(wd, cache=True)
 
 
+def _cast_in(x2, shapes):
+    """bf16 copy of a node's fp32 input (backward reads it) and, in "fp8" mode when every forward
+    product of the node that reads x ((M, N, K) in `shapes`) fits the e4m3 kernel, its per-tensor
+    e4m3 quantisation from the same pass: (xb, (x8, inv_scale) or None)."""
+    if ops.PRECISION == "fp8" and all(ops.f8_supported(*s) for s in shapes):
+        x8, sx, xb = ops.cast_fp8(x2, want_bf16=True)
+        return xb, (x8, sx)
+    return ops.cast_bf16(x2), None
+
+
+def _fwd_nt(xq, xb, w, M, N, K, **epi):
+    """The forward product x W^T of a node: bf16 operands, or -- with xq from _cast_in -- x and W
+    quantised per tensor (W once per optimiser step) and multiplied on the fp8 MFMA.  Backward is
+    the bf16 one either way."""
+    if xq is not None:
+        wd = w.detach()
+        wd._qarig_weight = True
+        w8, sw = ops.cast_fp8(wd, cache=True)
+        ops.gemm_f8(xq[0], xq[1], w8, sw, M, N, K, **epi)
+    else:
+        ops.gemm_lp(xb, _shadow(w), 0, M, N, K, **epi)
+
+
 def _ok(M, N, K):
     return bool(ops._lib.load().qarig_gemm_lp_supported(M, N, K, 1))
 
@@ -111,10 +134,10 @@ class _MLP2LP(torch.autograd.Function):
         M, K = x2.shape
         H, N = w1.shape[0], w2.shape[0]
         Np = _pad128(N)
-        xb = ops.cast_bf16(x2)
+        xb, xq = _cast_in(x2, [(M, H, K)])
         hb = torch.empty((M, H), dtype=torch.bfloat16, device=x2.device)
         t1b = torch.empty((M, H), dtype=torch.bfloat16, device=x2.device) if act1 else None
-        ops.gemm_lp(xb, _shadow(w1), 0, M, H, K, bias=b1, act=act1, Cb=hb, Pb=t1b)
+        _fwd_nt(xq, xb, w1, M, H, K, bias=b1, act=act1, Cb=hb, Pb=t1b)
         y = torch.empty((M, Np), dtype=torch.float32, device=x2.device)
         t2 = torch.empty((M, Np), dtype=torch.float32, device=x2.device) if act2 else None
         b2p = b2
@@ -167,14 +190,14 @@ class _MLP2x3LP(torch.autograd.Function):
         shp = x.shape
         x2 = _2d(f32c(x))
         M, K = x2.shape
-        xb = ops.cast_bf16(x2)
+        xb, xq = _cast_in(x2, [(M, params[4 * i].shape[0], K) for i in range(3)])
         outs, saved = [], [xb]
         for i in range(3):
             w1, b1, w2, b2 = params[4 * i:4 * i + 4]
             H, N = w1.shape[0], w2.shape[0]
             hb = torch.empty((M, H), dtype=torch.bfloat16, device=x2.device)
             t1b = torch.empty((M, H), dtype=torch.bfloat16, device=x2.device) if act1 else hb
-            ops.gemm_lp(xb, _shadow(w1), 0, M, H, K, bias=b1, act=act1, Cb=hb, Pb=t1b if act1 else None)
+            _fwd_nt(xq, xb, w1, M, H, K, bias=b1, act=act1, Cb=hb, Pb=t1b if act1 else None)
             y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
             t2 = torch.empty((M, N), dtype=torch.float32, device=x2.device) if act2 else None
             ops.gemm_lp(hb, _shadow(w2), 0, M, N, H, C=y, bias=b2, preact=t2, act=act2)
@@ -229,11 +252,11 @@ class _LinearActLP(torch.autograd.Function):
         x2 = _2d(f32c(x))
         M, K = x2.shape
         N = weight.shape[0]
-        xb = ops.cast_bf16(x2)
+        xb, xq = _cast_in(x2, [(M, N, K)])
         r2 = _2d(f32c(residual)) if residual is not None else None
         y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
         t = torch.empty((M, N), dtype=torch.float32, device=x2.device) if act else None
-        ops.gemm_lp(xb, _shadow(weight), 0, M, N, K, C=y, bias=bias, residual=r2, preact=t, act=act)
+        _fwd_nt(xq, xb, weight, M, N, K, C=y, bias=bias, residual=r2, preact=t, act=act)
         ctx.save_for_backward(xb, t if t is not None else xb)
         ctx.cfg = (act, residual is not None, shp)
         ctx.params = (weight, bias)
@@ -266,11 +289,11 @@ def mlp2_supported(x, w1, w2):
     K, H, N = w1.shape[1], w1.shape[0], w2.shape[0]
     Np = _pad128(N)
     # forward (M,H,K), (M,Np,H); d-input (M,H,Np), (M,K,H); d-weight (Np,H,M), (H,K,M)
-    return (ops.PRECISION == "bf16" and M >= 1024 and _ok(M, H, K) and _ok(M, Np, H) and _ok(M, H, Np)
+    return (ops.lp_mode() and M >= 1024 and _ok(M, H, K) and _ok(M, Np, H) and _ok(M, H, Np)
             and _ok(M, K, H) and _ok(Np, H, M) and _ok(H, K, M))
 
 
 def linear_supported(x, weight):
     M = x.numel() // x.shape[-1]
     N, K = weight.shape
-    return (ops.PRECISION == "bf16" and M >= 1024 and _ok(M, N, K) and _ok(M, K, N) and _ok(N, K, M))
+    return (ops.lp_mode() and M >= 1024 and _ok(M, N, K) and _ok(M, K, N) and _ok(N, K, M))

@@ -51,7 +51,12 @@ GEMM_EVENTS = None
 # tensors; BASELINE config 5 direction, tolerance stated in tests/test_gpu_bf16.py).
 # QARIG_PRECISION in the environment sets the default.
 PRECISION = os.environ.get("QARIG_PRECISION", "f32")
-PRECISIONS = ("f32", "bf16")
+PRECISIONS = ("f32", "bf16", "fp8")
+
+
+def lp_mode():
+    """bf16 storage / bf16-MFMA nodes active ("bf16", and "fp8" which adds e4m3 forward products)."""
+    return PRECISION in ("bf16", "fp8")
 
 
 def set_precision(name):
@@ -96,7 +101,7 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
         nws = lib.qarig_gemm_workspace_bytes(M, N, splitk)
         ws = workspace(nws, A.device, "gemm")
         nws = ws.numel()
-    if PRECISION == "bf16":
+    if lp_mode():
         done = _gemm_lp(lib, A, B, a_kcontig, b_kcontig, C, pre, M, N, K, bias, residual, act, gradz,
                         gact, splitk, accumulate, a_rowsum)
         if done:
@@ -150,6 +155,52 @@ def cast_bf16(x, cache=False):
     if key is not None:
         _lp_cache[key] = out
     return out
+
+
+def cast_fp8(x, cache=False, want_bf16=False):
+    """(e4m3 bytes as torch.uint8 of x's shape, dequantisation factor as a 1-element fp32 tensor
+    [, bf16 copy of x from the same pass]) of a dense fp32 tensor: one scale for the tensor, 448 / max|x| (include/qarig.h
+    qarig_cast_fp8).  The factor stays on the device; the GEMM epilogue multiplies by it."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 4 == 0
+    key = None
+    if cache and not torch.cuda.is_current_stream_capturing():
+        key = ("f8", x.data_ptr(), tuple(x.shape), x._version, LP_EPOCH)
+        hit = _lp_cache.get(key)
+        if hit is not None:
+            return hit
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    aux = torch.empty(2, dtype=torch.float32, device=x.device)     # [0] inv_scale, [1] amax bits
+    xb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    check(_lib.load().qarig_cast_fp8(ptr(x), x.numel(), ptr(out), ptr(aux), aux.data_ptr() + 4, ptr(xb),
+                                     stream()), "qarig_cast_fp8")
+    res = (out, aux[:1], xb) if want_bf16 else (out, aux[:1])
+    if key is not None:
+        _lp_cache[key] = res
+    return res
+
+
+def f8_supported(M, N, K):
+    return bool(_lib.load().qarig_gemm_f8_supported(M, N, K))
+
+
+def gemm_f8(A8, inv_a, B8, inv_b, M, N, K, C=None, bias=None, residual=None, preact=None, act=0,
+            Cb=None, Pb=None):
+    """Forward product on e4m3 operands (include/qarig.h qarig_gemm_f8): C = epilogue(inv_a * inv_b *
+    A8 B8^T), A8 (M,K) and B8 (N,K) uint8 from cast_fp8."""
+    if GEMM_EVENTS is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(_lib.load().qarig_gemm_f8(
+        ptr(A8), A8.stride(0), ptr(B8), B8.stride(0), ptr(inv_a), ptr(inv_b),
+        ptr(C), C.stride(0) if C is not None else 0, M, N, K, ptr(bias),
+        ptr(residual), residual.stride(0) if residual is not None else 0,
+        ptr(preact), preact.stride(0) if preact is not None else 0, act,
+        ptr(Cb), Cb.stride(0) if Cb is not None else 0, ptr(Pb), Pb.stride(0) if Pb is not None else 0,
+        stream()), "qarig_gemm_f8")
+    if GEMM_EVENTS is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        GEMM_EVENTS.append((2.0 * M * N * K, ev0, ev1, "f8"))
 
 
 def cast_transpose_bf16(x, cache=False):
@@ -591,7 +642,7 @@ def attention_fwd(q, k, v, heads, causal):
     o = torch.empty_like(q)
     lse = torch.empty((N, heads, Sq), dtype=torch.float32, device=q.device)
     lib = _lib.load()
-    fn = lib.qarig_attention_lp_fwd if PRECISION == "bf16" else lib.qarig_attention_fwd
+    fn = lib.qarig_attention_lp_fwd if lp_mode() else lib.qarig_attention_fwd
     check(fn(ptr(q), ptr(k), ptr(v), N, Sq, Sk, heads, d, int(causal), float(d ** 0.5), ptr(o), ptr(lse),
              stream()), "qarig_attention_fwd")
     return o, lse
@@ -624,7 +675,7 @@ def attention_bwd(q, k, v, o, dO, lse, heads, causal):
     dv = torch.empty_like(v)
     delta = torch.empty_like(lse)
     lib = _lib.load()
-    fn = lib.qarig_attention_lp_bwd if PRECISION == "bf16" else lib.qarig_attention_bwd
+    fn = lib.qarig_attention_lp_bwd if lp_mode() else lib.qarig_attention_bwd
     check(fn(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), N, Sq, Sk, heads, d, int(causal),
              float(d ** 0.5), ptr(dq), ptr(dk), ptr(dv), ptr(delta), stream()), "qarig_attention_bwd")
     return dq, dk, dv

@@ -153,7 +153,7 @@ def test_bf16_mode_falls_back_to_fp32_kernels_off_the_interior(bf16_mode):
     assert torch.equal(got, ops.gemm(A, W))
     ops.PRECISION = "bf16"
     with pytest.raises(ValueError):
-        ops.PRECISION = "fp8"
+        ops.PRECISION = "int4"
         ops.gemm(A, W)
 
 

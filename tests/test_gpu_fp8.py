@@ -1,0 +1,181 @@
+"""Opt-in fp8 mode (qarig.ops.PRECISION = "fp8"; BASELINE config 5 names the fp8 MFMA).
+NOT the parity mode.  The forward products x W^T of the Linear layers run on e4m3 operands
+(csrc/gemm_lp.hip gemm_f8_kernel: bytes in HBM, one scale per tensor, v_mfma_f32_32x32x64_f8f6f4,
+fp32 accumulation); backward and everything else is the bf16 mode of tests/test_gpu_bf16.py.
+Pinned here: the quantiser against torch's own float8_e4m3fn conversion (bit-for-bit), the
+fragment map on exact integer data, the GEMM against an fp64 contraction of its own dequantised
+operands (6e-5 * sqrt(K/512): the fp8 dot-product unit's internal alignment), and the nodes / a training step against
+the fp32 ones within the e4m3 rounding budget (3 mantissa bits: tolerances stated per test)."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+F8 = torch.float8_e4m3fn
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a * b).sum() / (a.norm() * b.norm()))
+
+
+def _one(v=1.0):
+    return torch.tensor([v], dtype=torch.float32, device="cuda")
+
+
+def test_cast_fp8_matches_torch_e4m3fn():
+    """bytes == (x * 448 / max|x|).to(float8_e4m3fn), dequantisation factor == max|x| / 448 (fp32
+    arithmetic both sides); an all-zero tensor quantises with scale 1."""
+    from qarig import ops
+    g = torch.Generator().manual_seed(3)
+    for shape, mul in (((1024, 512), 1.0), ((256, 2048), 37.5), ((128, 128), 1e-3)):
+        x = (torch.randn(shape, generator=g) * mul).cuda()
+        q, inv = ops.cast_fp8(x)
+        amax = x.abs().max()
+        scale = torch.tensor(448.0, device="cuda") / amax
+        want = (x * scale).to(F8).view(torch.uint8)
+        assert q.dtype == torch.uint8 and q.shape == x.shape
+        assert torch.equal(q, want)
+        assert float(inv) == float(amax / torch.tensor(448.0, device="cuda"))
+    z = torch.zeros((128, 128), device="cuda")
+    q, inv = ops.cast_fp8(z)
+    assert int(q.max()) == 0 and float(inv) == 1.0
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 384, 512), (384, 128, 2048)])
+def test_f8_fragment_map_on_exact_integer_data(M, N, K):
+    """Small integers are exact in e4m3 and their products sum exactly in fp32: any slip in the
+    k order of the 32-byte fragments, the chunk swizzle or the tile map changes the result."""
+    from qarig import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randint(-4, 5, (M, K), generator=g).float()
+    B = torch.randint(-4, 5, (N, K), generator=g).float()
+    A8 = A.to(F8).view(torch.uint8).cuda()
+    B8 = B.to(F8).view(torch.uint8).cuda()
+    C = torch.empty((M, N), device="cuda")
+    ops.gemm_f8(A8, _one(), B8, _one(), M, N, K, C=C)
+    assert torch.equal(C.cpu(), A @ B.t())
+    # dequantisation factors (powers of two stay exact) and the epilogue behind them
+    bias = torch.randint(-3, 4, (N,), generator=g).float().cuda()
+    R = torch.randint(-3, 4, (M, N), generator=g).float().cuda()
+    pre = torch.empty((M, N), device="cuda")
+    Cb = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_f8(A8, _one(0.5), B8, _one(0.25), M, N, K, C=C, bias=bias, residual=R, preact=pre, act=1, Cb=Cb)
+    t = (A @ B.t()) * 0.125 + bias.cpu() + R.cpu()
+    assert torch.equal(pre.cpu(), t)
+    assert rel_err(C, torch.nn.functional.silu(t.double())) < 2e-6
+    assert torch.equal(Cb, C.bfloat16())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 512), (1024, 2048, 512), (512, 512, 2048)])
+def test_f8_gemm_is_exact_on_its_quantised_operands(M, N, K):
+    from qarig import ops
+    g = torch.Generator().manual_seed(11 + K)
+    x = torch.randn((M, K), generator=g).cuda()
+    w = (torch.randn((N, K), generator=g) * 0.05).cuda()
+    x8, sx = ops.cast_fp8(x)
+    w8, sw = ops.cast_fp8(w)
+    C = torch.empty((M, N), device="cuda")
+    ops.gemm_f8(x8, sx, w8, sw, M, N, K, C=C)
+    xd = x8.view(F8).double().cpu() * float(sx)
+    wd = w8.view(F8).double().cpu() * float(sw)
+    # not the 3e-6 of the bf16 kernel: one f8f6f4 instruction adds its 64 products in a dot-product
+    # unit that aligns them to the largest exponent first (measured 2e-5 of max|C| on this data;
+    # integer data, where nothing is shifted out, is exact: the test above)
+    assert rel_err(C, xd @ wd.t()) < 6e-5 * max(1, K / 512) ** 0.5
+    # and the quantisation itself stays inside the e4m3 budget: |x - dequant(x)| <= 2^-4 |x| + half
+    # of the smallest subnormal step
+    assert float(((xd - x.double().cpu()).abs() - x.double().cpu().abs() / 16).max()) <= float(sx) * 2 ** -10
+
+
+@pytest.fixture
+def fp8_mode():
+    from qarig import ops
+    old = ops.PRECISION
+    ops.PRECISION = "fp8"
+    yield ops
+    ops.PRECISION = old
+
+
+def test_f8_mlp_and_linear_nodes_track_fp32_nodes(fp8_mode):
+    """Forward on e4m3 operands (first GEMM of the MLP), backward as
+    in bf16 mode, from the same weights as the fp32 nodes.  e4m3 keeps 3 mantissa bits: per-element
+    rounding error <= 6.25 %, random in sign, so a 512-deep product carries ~3 % relative RMS error.
+    Stated bounds: outputs and input gradients cosine > 0.997, weight/bias gradients > 0.995."""
+    ops = fp8_mode
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(7)
+    M, K, H = 2048, 512, 2048
+    x = torch.randn((4, M // 4, K), generator=g).cuda()
+    w1, b1 = (torch.randn((H, K), generator=g) * 0.04).cuda(), (torch.randn(H, generator=g) * 0.1).cuda()
+    w2, b2 = (torch.randn((K, H), generator=g) * 0.02).cuda(), (torch.randn(K, generator=g) * 0.1).cuda()
+    dy = torch.randn((4, M // 4, K), generator=g).cuda()
+    res = {}
+    for mode in ("f32", "fp8"):
+        ops.PRECISION = mode
+        leaves = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        y = QF.mlp2(*leaves, 1, 0)
+        if mode == "fp8":
+            assert type(y.grad_fn).__name__ == "_MLP2LPBackward"
+        (y * dy).sum().backward()
+        res[mode] = [y.detach()] + [t.grad for t in leaves]
+    ops.PRECISION = "fp8"
+    names = ["y", "dx", "dw1", "db1", "dw2", "db2"]
+    for n, a, b in zip(names, res["fp8"], res["f32"]):
+        c = _cos(a, b)
+        assert c > (0.997 if n in ("y", "dx") else 0.995), (n, c)
+    assert not torch.equal(res["fp8"][0], res["f32"][0])
+
+
+def test_fp8_mode_routes_forward_products_to_the_e4m3_kernel(fp8_mode, monkeypatch):
+    """The mode must actually reach gemm_f8 on the interior shapes (and only the forward x W^T)."""
+    ops = fp8_mode
+    from qarig import functional as QF
+    calls = []
+    real = ops.gemm_f8
+    monkeypatch.setattr(ops, "gemm_f8", lambda *a, **k: (calls.append(a[4:7]), real(*a, **k))[1])
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((2048, 512), generator=g).cuda().requires_grad_(True)
+    w1, b1 = (torch.randn((2048, 512), generator=g) * 0.04).cuda().requires_grad_(True), torch.zeros(2048).cuda()
+    w2, b2 = (torch.randn((512, 2048), generator=g) * 0.02).cuda().requires_grad_(True), torch.zeros(512).cuda()
+    QF.mlp2(x, w1, b1, w2, b2, 1, 0).sum().backward()
+    assert calls == [(2048, 2048, 512)]
+
+
+def test_fp8_train_step_tracks_fp32_step():
+    """One training step (narrow README-shaped model) in fp32 and fp8 modes from the same weights:
+    loss within 2e-2 relative, flat gradient cosine similarity > 0.98."""
+    from models.Transformer import Transformer
+    from qarig import ops, pipeline
+    from qarig.optim import FlatAdam
+    res = {}
+    for mode in ("f32", "fp8"):
+        torch.manual_seed(2)
+        m = Transformer(use_encoder=False, use_pos_cond=True, num_enc_layers=None, num_dec_layers=2,
+                        num_enc_embedding=None, num_dec_embedding=1024, self_attn_heads=16,
+                        cross_attn_heads=None, transformer_in_dim=256, transformer_out_dim=513,
+                        transformer_hidden_dim=1024).cuda()
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.abs().max() == 0:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+        opt = FlatAdam(m.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        x = torch.randint(0, 1024, (8, 128), generator=g).cuda()
+        t = torch.randint(0, 513, (8, 128), generator=g).cuda()
+        pos = torch.arange(128)[None].repeat(8, 1).cuda()
+        old, ops.PRECISION = ops.PRECISION, mode
+        try:
+            opt.zero_grad()
+            loss = pipeline.train_step(m, opt, x, None, t, pos, dp=False)
+        finally:
+            ops.PRECISION = old
+        res[mode] = (float(loss), opt.flat_grad.detach().clone())
+    lf, gf = res["f32"]
+    l8, g8 = res["fp8"]
+    assert abs(l8 - lf) < 2e-2 * abs(lf), (l8, lf)
+    cos = float((gf * g8).sum() / (gf.norm() * g8.norm()))
+    assert cos > 0.98, cos
+    assert not torch.equal(gf, g8)
