@@ -152,9 +152,9 @@ extern "C" int qarig_assemble_tokens(const int64_t* lr, int S_lr, const int64_t*
     QARIG_CHECK_ARG(N > 0 && S_hr > 0 && W > 0 && (!base || S_lr > 0), "assemble_tokens: bad extents");
     QARIG_CHECK_DIMS("assemble_tokens", N, S_hr);
     QARIG_CHECK_DIMS("assemble_tokens", N, W);
+    QARIG_CHECK_ARG(base ? (S_lr <= (1 << 24)) : 1, "assemble_tokens: bad extents");
     const int s_in = (base ? S_lr : 1) + S_hr;
     QARIG_CHECK_ARG(W <= s_in && (offs || W == s_in), "assemble_tokens: window %d vs sequence %d", W, s_in);
-    QARIG_CHECK_ARG(base ? (S_lr <= (1 << 24)) : 1, "assemble_tokens: bad extents");
     // the target has S_hr + 1 entries; with the base model's S_lr leading tokens logits and
     // targets line up only for S_lr == 1 -- as in the reference, longer LR
     // sequences simply run out of target (guarded: <end> is written past it)

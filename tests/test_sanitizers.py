@@ -63,10 +63,15 @@ for (M, N, K, ak, bk, sk) in ((16384, 2048, 512, 1, 1, 1), (16384, 512, 2048, 1,
                               (640, 2048, 16384, 0, 0, 6), (100, 513, 96, 1, 1, 1), (64, 2048, 512, 1, 1, 1)):
     call("qarig_gemm_f32", X, K if ak else M, ak, X, K if bk else N, bk, X, N, M, N, K, X, None, 0, X, N, 1,
          None, 0, 0, sk, 0, None, X, 1 << 40, None)
-call("qarig_gemm_lp", X, 512, X, 512, 0, X, 2048, 16384, 2048, 512, X, None, 0, None, 0, 1, None, 0, 0, 1, 0,
+call("qarig_gemm_lp", X, 512, X, 512, 0, X, 2048, 16384, 2048, 512, X, None, 0, None, 0, 1, None, 0, 0, 0, 1, 0,
      X, 2048, None, 0, None, 0, None)
-call("qarig_gemm_lp", X, 2048, X, 512, 1, X, 512, 2048, 512, 16384, None, None, 0, None, 0, 0, None, 0, 0, 8, 0,
+call("qarig_gemm_lp", X, 2048, X, 512, 1, X, 512, 2048, 512, 16384, None, None, 0, None, 0, 0, None, 0, 0, 0, 8, 0,
      None, 0, None, 0, X, 1 << 40, None)
+call("qarig_gemm_f8", X, 512, X, 512, X, X, X, 2048, 16384, 2048, 512, X, None, 0, None, 0, 1, X, 2048, None, 0, None)
+call("qarig_cast_fp8", X, 16384 * 512, X, X, X, X, None)
+for (M, N, K, ak, bk, sk) in ((2048, 2048, 512, 1, 1, 1), (2048, 512, 2048, 0, 0, 4)):      # the paired kernel's launches
+    call("qarig_gemm_f32", X, K if ak else M, ak, X, K if bk else N, bk, X, N, M, N, K, None, None, 0, None, 0, 0,
+         None, 0, 0, sk, 0, None, X, 1 << 40, None)
 for (N, C, H, W, p, K) in ((64, 4, 32, 32, 2, 512), (64, 4, 32, 32, 32, 512), (64, 4, 64, 64, 1, 8192), (3, 4, 12, 20, 2, 77)):
     call("qarig_bmu_fwd", X, N, C, H, W, p, p, X, K, C * p * p, X, X, 1 << 40, None)
 for (N, Sq, Sk, H, d, causal) in ((64, 256, 256, 64, 8, 1), (2, 4096, 4096, 64, 8, 1), (2, 4096, 1024, 64, 8, 0),
