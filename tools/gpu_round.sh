@@ -18,3 +18,6 @@ step 300 $O/${TAG}_attn_bench.log python tools/attn_bench.py; cat $O/${TAG}_attn
 QARIG_CPU_BASELINE_SECONDS=3 step 300 $O/${TAG}_bench_c2.json python bench.py --steps 10 --warmup 3; cat $O/${TAG}_bench_c2.json
 step 300 $O/${TAG}_bench_c4.json python bench.py --config c4 --steps 10 --warmup 3; cat $O/${TAG}_bench_c4.json
 step 400 $O/${TAG}_bench_c5.json python bench.py --config c5 --steps 3 --warmup 1; cat $O/${TAG}_bench_c5.json; tail -3 $O/${TAG}_bench_c5.err
+step 400 $O/${TAG}_bench_c5_fp8.json python bench.py --config c5 --precision fp8 --steps 3 --warmup 1; cat $O/${TAG}_bench_c5_fp8.json | cut -c1-300
+step 200 $O/${TAG}_bmu_bench.log python tools/bmu_bench.py; cat $O/${TAG}_bmu_bench.log
+step 200 $O/${TAG}_smoke.log python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"; tail -2 $O/${TAG}_smoke.log
