@@ -261,7 +261,11 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
         if (bf) bf[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
     }
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
+    __shared__ float wmax[4];              // one atomic per workgroup: they all hit one L2 line
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 // dst = e4m3(src * 448 / amax) (round to nearest even, saturating), *inv_scale = amax / 448: the
 // factor that takes products of the quantised values back.  amax = 0 quantises with scale 1.
@@ -366,7 +370,16 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
     const int c = blockIdx.x * 64 + ct;
     float s = 0.0f;
     if (c < N)
-        for (int z = g; z < chunks; z += 4) s += part[(int64_t)z * N + c];
+        for (int z0 = g; z0 < chunks; z0 += 32) {      // 8 loads in flight, added in chunk order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int z = z0 + 4 * u;
+                v[u] = z < chunks ? part[(int64_t)z * N + c] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
     if (g > 0) red[g - 1][ct] = s;
     __syncthreads();
     if (g == 0 && c < N) {
@@ -565,7 +578,7 @@ extern "C" int qarig_cast_fp8(const float* src, int64_t n, void* dst, float* inv
                     "cast_fp8: src 16-B aligned, dst 4-B aligned");
     hipStream_t st = (hipStream_t)stream;
     const int64_t n4 = n / 4;
-    int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    int blocks = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
     if (hipMemsetAsync(scratch, 0, 4, st) != hipSuccess) {
         qarig_set_error("cast_fp8: memset failed");
         return QARIG_ERR_LAUNCH;
