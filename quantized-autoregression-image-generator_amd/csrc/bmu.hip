@@ -443,6 +443,30 @@ __device__ __forceinline__ void res_scan2(float t0, float t1, float& best, int& 
         : "v"(t0), "v"(t1), "n"(R), "n"(R + 1)
         : "vcc");
 }
+// Group form of the scan (GROUPS launches: code chunks of >= 8 tile pairs per wave): the minimum of 8
+// candidates by v_min3 (4 ops), then ONE 4-op scan step for the group -- 1 VALU op per candidate
+// instead of 4.  What the scan tracks is then (smallest group minimum, its group, second smallest
+// group minimum); the winning group's 8 candidates are re-evaluated exactly after the loop (the
+// same fma chain on the vector ALU gives the MFMA's bits), which recovers the index inside the
+// group and the second smallest value inside it.
+template <int R>
+__device__ __forceinline__ void res_scan_grp(float a0, float a1, float a2, float a3, float a4, float a5,
+                                             float a6, float a7, float& best, int& rnew, float& sec) {
+    static_assert(R >= 0 && R <= 64, "group positions must stay inline constants");
+    float tmp;
+    asm volatile(
+        "v_min3_f32 %3, %4, %5, %6\n"
+        "v_min3_f32 %3, %3, %7, %8\n"
+        "v_min3_f32 %3, %3, %9, %10\n"
+        "v_min_f32 %3, %3, %11\n"
+        "v_med3_f32 %2, %0, %3, %2\n"
+        "v_cmp_nlt_f32 vcc, %3, %0\n"
+        "v_cndmask_b32 %1, %12, %1, vcc\n"
+        "v_min_f32 %0, %0, %3\n"
+        : "+v"(best), "+v"(rnew), "+v"(sec), "=&v"(tmp)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "n"(R)
+        : "vcc");
+}
 template <bool FIRST>
 __device__ __forceinline__ void res_mfma(f32x16& acc, float a, float b) {
     // s_nop 1: an MFMA may read a VGPR no sooner than 2 wait states after a vector-ALU write
@@ -563,7 +587,7 @@ __device__ __forceinline__ void res_exact_rows(const PatchGeom& g, const PatchOf
     }
 }
 
-template <int KS, int CS>
+template <int KS, int CS, bool GROUPS, int NT>
 __global__ __launch_bounds__(NTHREADS, 2) void bmu_resident_kernel(PatchGeom g, PatchOffsets po,
                                                                    const float* __restrict__ w, int K,
                                                                    int chunk,
@@ -657,45 +681,58 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_resident_kernel(PatchGeom g, 
     // ---- main loop: this wave's code tiles, two at a time (independent accumulators); the
     // MFMAs of the next pair are issued before the current pair is scanned, so the scan's VALU
     // work runs under them
-    const int tiles_w = chunk / (32 * CS);            // even (host)
+    const int tiles_w = chunk / (32 * CS);            // a multiple of NT (host)
     const int t0 = cpart * tiles_w;
     float best = INFINITY, sec = INFINITY;
     int seq_best = INT_MAX;
-    // step<ISSUE, SCAN>: the 2 KS + 2 MFMAs of pair tpn into (n0, n1), interleaved with the scan
-    // of pair tpc held in (c0, c1).  Candidates ascend within the lane: seq = 16 * tile + r.
-    auto step = [&](auto issue_c, auto scan_c, int tpn, f32x16& n0, f32x16& n1, int tpc, f32x16& c0,
-                    f32x16& c1) {
-        constexpr bool ISSUE = decltype(issue_c)::value, SCAN = decltype(scan_c)::value;
-        constexpr int SLOTS = 2 * KS + 2;
-        float a0[KS], a1[KS], w0 = 0.0f, w1 = 0.0f;
-        if constexpr (ISSUE) {
-            const int cc = (t0 + tpn) * 32 + cl;
-            res_frag<KS>(AE, cc, hi, chunk, a0);
-            res_frag<KS>(AE, cc + 32, hi, chunk, a1);
-            const float w0v = W2[cc], w1v = W2[cc + 32];
-            w0 = hi ? 0.0f : w0v;
-            w1 = hi ? 0.0f : w1v;
+    // step<ISSUE, SCAN>: the NT (KS + 1) MFMAs of the NT tiles starting at tile tpn into n[], NT
+    // independent accumulate chains taken round robin (with NT = 2 every MFMA waits for the one but
+    // last: measured 15 % of the launch), interleaved with the scan of the NT tiles starting at tpc
+    // held in c[].  Candidates ascend within the lane: seq = 16 * tile + r (2 * tile + half for groups).
+    struct Tiles { f32x16 t[NT]; };
+    struct Frags { float af[NT][KS]; float wf[NT]; };     // A fragments + |w|^2 of NT code tiles
+    auto fetch = [&](int tp, Frags& f) {
+        const int cc = (t0 + tp) * 32 + cl;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            res_frag<KS>(AE, cc + 32 * u, hi, chunk, f.af[u]);
+            const float wv = W2[cc + 32 * u];
+            f.wf[u] = hi ? 0.0f : wv;
         }
+    };
+    // fn: the fragments of the tiles being issued (fetched one step earlier, so their LDS latency
+    // is behind a step of MFMAs); ff: receives the fragments of the tiles at tpf (< 0: none)
+    auto step = [&](auto issue_c, auto scan_c, int tpn, Tiles& n, Frags& fn, int tpf, Frags& ff, int tpc, Tiles& c) {
+        constexpr bool ISSUE = decltype(issue_c)::value, SCAN = decltype(scan_c)::value;
+        constexpr int SLOTS = NT * (KS + 1);
         int rnew = -1;
         static_for<0, SLOTS>([&](auto mc) {
             constexpr int M = decltype(mc)::value;
             if constexpr (ISSUE) {
-                constexpr int S = M / 2;
-                if constexpr (S < KS) {
-                    if constexpr (M % 2 == 0) res_mfma<S == 0>(n0, a0[S], b[S]);
-                    else res_mfma<S == 0>(n1, a1[S], b[S]);
-                } else {
-                    if constexpr (M % 2 == 0) res_mfma<false>(n0, w0, b_ext);
-                    else res_mfma<false>(n1, w1, b_ext);
-                }
+                constexpr int S = M / NT, U = M % NT;
+                if constexpr (S < KS) res_mfma<S == 0>(n.t[U], fn.af[U][S], b[S]);
+                else res_mfma<false>(n.t[U], fn.wf[U], b_ext);
+                if constexpr (M == NT - 1)
+                    if (tpf >= 0) fetch(tpf, ff);       // behind the first round of MFMAs
             }
-            if constexpr (SCAN) {
-                // scan2 chunk j (16 per pair) follows MFMA floor(j * SLOTS / 16)
-                static_for<0, 16>([&](auto jc) {
+            if constexpr (SCAN && !GROUPS) {
+                // scan2 chunk j (8 per tile) follows MFMA floor(j * SLOTS / (8 NT))
+                static_for<0, 8 * NT>([&](auto jc) {
                     constexpr int J = decltype(jc)::value;
-                    if constexpr (J * SLOTS / 16 == M) {
-                        if constexpr (J < 8) res_scan2<2 * J>(c0[2 * J], c0[2 * J + 1], best, rnew, sec);
-                        else res_scan2<2 * J>(c1[2 * J - 16], c1[2 * J - 15], best, rnew, sec);
+                    if constexpr (J * SLOTS / (8 * NT) == M)
+                        res_scan2<2 * J>(c.t[J / 8][2 * (J % 8)], c.t[J / 8][2 * (J % 8) + 1], best, rnew, sec);
+                });
+            }
+            if constexpr (SCAN && GROUPS) {
+                // group j (2 per tile: halves of an accumulator tile, ascending codes within the
+                // lane) follows MFMA floor(j * SLOTS / (2 NT))
+                static_for<0, 2 * NT>([&](auto jc) {
+                    constexpr int J = decltype(jc)::value;
+                    if constexpr (J * SLOTS / (2 * NT) == M) {
+                        const f32x16& ct = c.t[J / 2];
+                        constexpr int o = 8 * (J & 1);
+                        res_scan_grp<J>(ct[o], ct[o + 1], ct[o + 2], ct[o + 3], ct[o + 4], ct[o + 5], ct[o + 6],
+                                        ct[o + 7], best, rnew, sec);
                     }
                 });
             }
@@ -703,32 +740,64 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_resident_kernel(PatchGeom g, 
         // The MFMAs sit in inline asm, so the compiler inserts none of the wait states it owes
         // between a matrix-core write and a vector-ALU read of the same registers -- and it
         // does read them: register copies of an accumulator at the loop edges.  Every issuing
-        // step therefore ends with the 16-pass latency in nops (24 cycles per 18 MFMAs).
-        if constexpr (ISSUE) asm volatile("s_nop 15\ns_nop 7" : "+v"(n0), "+v"(n1));
-        if constexpr (SCAN) seq_best = rnew >= 0 ? tpc * 16 + rnew : seq_best;
+        // step therefore ends with the 16-pass latency in nops (24 cycles per NT (KS + 1) MFMAs).
+        if constexpr (ISSUE) {
+            if constexpr (NT == 2) asm volatile("s_nop 15\ns_nop 7" : "+v"(n.t[0]), "+v"(n.t[1]));
+            else asm volatile("s_nop 15\ns_nop 7" : "+v"(n.t[0]), "+v"(n.t[1]), "+v"(n.t[2]), "+v"(n.t[3]));
+        }
+        // position of the winner: candidate (16 per tile) or group (2 per tile) index within the wave
+        if constexpr (SCAN) seq_best = rnew >= 0 ? tpc * (GROUPS ? 2 : 16) + rnew : seq_best;
     };
     {
-        f32x16 A0, A1, B0, B1;
+        Tiles A, B;
+        Frags FA, FB;
         constexpr std::true_type yes{};
         constexpr std::false_type no{};
-        step(yes, no, 0, A0, A1, 0, B0, B1);
+        fetch(0, FA);
+        step(yes, no, 0, A, FA, NT < tiles_w ? NT : -1, FB, 0, B);
         int tp = 0;
         while (true) {
-            if (tp + 2 < tiles_w) step(yes, yes, tp + 2, B0, B1, tp, A0, A1);
-            else step(no, yes, 0, B0, B1, tp, A0, A1);
-            tp += 2;
+            if (tp + NT < tiles_w) step(yes, yes, tp + NT, B, FB, tp + 2 * NT < tiles_w ? tp + 2 * NT : -1, FA, tp, A);
+            else step(no, yes, 0, B, FB, -1, FA, tp, A);
+            tp += NT;
             if (tp >= tiles_w) break;
-            if (tp + 2 < tiles_w) step(yes, yes, tp + 2, A0, A1, tp, B0, B1);
-            else step(no, yes, 0, A0, A1, tp, B0, B1);
-            tp += 2;
+            if (tp + NT < tiles_w) step(yes, yes, tp + NT, A, FA, tp + 2 * NT < tiles_w ? tp + 2 * NT : -1, FB, tp, B);
+            else step(no, yes, 0, A, FA, -1, FB, tp, B);
+            tp += NT;
             if (tp >= tiles_w) break;
         }
     }
     // seq -> code: tile t0 + seq/16, accumulator row acc_row(seq % 16, lane)
     BmuState st{best, INT_MAX, sec};
-    if (seq_best != INT_MAX) {
-        const int code = cbase + (t0 + (seq_best >> 4)) * 32 + acc_row(seq_best & 15, lane);
-        st.idx = code < K ? code : INT_MAX;
+    if constexpr (!GROUPS) {
+        if (seq_best != INT_MAX) {
+            const int code = cbase + (t0 + (seq_best >> 4)) * 32 + acc_row(seq_best & 15, lane);
+            st.idx = code < K ? code : INT_MAX;
+        }
+    } else if (seq_best != INT_MAX) {
+        // the winning group, candidate by candidate: t = fma chain over the elements in order, then
+        // + |w|^2 -- the bits the MFMA produced -- through the plain 5-op scan; its minimum is `best`
+        // again, its first index is the lane's index, its second smallest joins `sec`
+        const int tile = t0 + (seq_best >> 1), o = 8 * (seq_best & 1);
+        float gb = INFINITY, gs = INFINITY;
+        int gi = INT_MAX;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int cl_ = tile * 32 + acc_row(o + r, lane);       // code inside the chunk
+            float ev[KS], od[KS];
+            res_frag<KS>(AE, cl_, 0, chunk, ev);
+            res_frag<KS>(AE, cl_, 1, chunk, od);
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+                acc = fmaf(ev[q], 2 * q < g.D ? xv[2 * q] : 0.0f, acc);
+                acc = fmaf(od[q], 2 * q + 1 < g.D ? xv[2 * q + 1] : 0.0f, acc);
+            }
+            const int code = cbase + cl_;
+            bmu_scan(acc + W2[cl_], code < K ? code : INT_MAX, gb, gi, gs);
+        }
+        st.idx = gi;
+        st.sec = fminf(sec, gs);
     }
     {   // the two lane halves hold disjoint codes of the same row
         BmuState o{__shfl_xor(st.d2, 32), __shfl_xor(st.idx, 32), __shfl_xor(st.sec, 32)};
@@ -1043,9 +1112,26 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
         magic(g.gw, po.m_gw, po.sh_gw);
         int64_t* direct_r = nchunks == 1 ? out_idx : (int64_t*)nullptr;
         dim3 grid((g.R + 128 / cs - 1) / (128 / cs), nchunks), block(NTHREADS);
+        // group scan where a wave walks at least 4 tile pairs (its one-off re-evaluation of the winning
+        // group costs about what it saves on 2); QARIG_BMU_GROUPS=0/1 overrides
+        static const int groups_env = []() { const char* e = getenv("QARIG_BMU_GROUPS"); return e ? atoi(e) : -1; }();
+        // (D <= 8 only: with D = 16 the nine MFMAs per tile dominate and the group form measured no gain)
+        const bool groups = groups_env >= 0 ? groups_env != 0 : (ks <= 4 && chunk / (32 * cs) >= 8);
+        // four tiles per step (four independent accumulate chains) where the wave's tile count allows
+        static const int quad_env = []() { const char* e = getenv("QARIG_BMU_QUADS"); return e ? atoi(e) : -1; }();
+        const bool quads = groups && (chunk / (32 * cs)) % 4 == 0 && quad_env == 1;   // measured: no gain; opt-in
 #define QARIG_BMU_RES(KS_, CS_)                                                                    \
-        hipLaunchKernelGGL((bmu_resident_kernel<KS_, CS_>), grid, block, shm, st, g, po, codebook, K,  \
-                           chunk, part_d, part_i, part_s, part_x2, direct_r)
+        do {                                                                                       \
+            if (quads)                                                                             \
+                hipLaunchKernelGGL((bmu_resident_kernel<KS_, CS_, true, 4>), grid, block, shm, st, g, po,     \
+                                   codebook, K, chunk, part_d, part_i, part_s, part_x2, direct_r); \
+            else if (groups)                                                                       \
+                hipLaunchKernelGGL((bmu_resident_kernel<KS_, CS_, true, 2>), grid, block, shm, st, g, po,     \
+                                   codebook, K, chunk, part_d, part_i, part_s, part_x2, direct_r); \
+            else                                                                                   \
+                hipLaunchKernelGGL((bmu_resident_kernel<KS_, CS_, false, 2>), grid, block, shm, st, g, po,    \
+                                   codebook, K, chunk, part_d, part_i, part_s, part_x2, direct_r); \
+        } while (0)
 #define QARIG_BMU_RES_CS(KS_)                                                                      \
         do {                                                                                       \
             if (cs == 1) QARIG_BMU_RES(KS_, 1);                                                    \
