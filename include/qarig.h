@@ -191,9 +191,12 @@ int qarig_embedding_bwd(const int64_t* ids, int M, int D, int V, const float* dy
 int qarig_layernorm_fwd(const float* x, int M, int D, float eps, const float* gamma,
                         const float* beta, const float* scale, const float* shift,
                         const int* mod_idx, float* y, float* mean, float* rstd, void* stream);
+/* dx_add (optional, (M,D)): added to dx -- the gradient that reaches the same x through the block's
+ * skip connection (models/layers.py:362-366, 530-534, 595-599), so that autograd's accumulation
+ * of the two contributions is not a separate elementwise launch. */
 int qarig_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                         const float* gamma, const float* scale, const int* mod_idx, int M, int D,
-                        float* dx, float* dy_xhat, void* stream);
+                        float* dx, float* dy_xhat, const float* dx_add, void* stream);
 
 /* Position-table form of the conditioning path.  `cond` (models/Transformer.py:154-167) is a
  * function of the token's integer position alone, so pos_cond_layer and every

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean_in,
     const float* __restrict__ rstd_in, const float* __restrict__ gamma,
     const float* __restrict__ scale, const int* __restrict__ mod_idx, int M, int D,
-    float* __restrict__ dx, float* __restrict__ dy_xhat) {
+    float* __restrict__ dx, float* __restrict__ dy_xhat, const float* __restrict__ dx_add) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -126,9 +126,13 @@ __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
-            *reinterpret_cast<float4*>(dx + off + c) =
-                make_float4(rstd * ((g[i].x - s1) - h[i].x * s2), rstd * ((g[i].y - s1) - h[i].y * s2),
-                            rstd * ((g[i].z - s1) - h[i].z * s2), rstd * ((g[i].w - s1) - h[i].w * s2));
+            float4 r = make_float4(rstd * ((g[i].x - s1) - h[i].x * s2), rstd * ((g[i].y - s1) - h[i].y * s2),
+                                   rstd * ((g[i].z - s1) - h[i].z * s2), rstd * ((g[i].w - s1) - h[i].w * s2));
+            if (dx_add) {   // the skip connection's gradient of the same x: autograd's own add, fused
+                const float4 a = *reinterpret_cast<const float4*>(dx_add + off + c);
+                r = make_float4(a.x + r.x, a.y + r.y, a.z + r.z, a.w + r.w);
+            }
+            *reinterpret_cast<float4*>(dx + off + c) = r;
             if (dy_xhat)
                 *reinterpret_cast<float4*>(dy_xhat + off + c) =
                     make_float4(d[i].x * h[i].x, d[i].y * h[i].y, d[i].z * h[i].z, d[i].w * h[i].w);
@@ -149,7 +153,8 @@ __global__ __launch_bounds__(LN_WAVES * 64) void layernorm_bwd_kernel(
         const float h = (x[off + c] - mean) * rstd;
         const float d = dy[off + c];
         const float g = gamma ? d * gamma[c] : (scale ? d * scale[moff + c] : d);
-        dx[off + c] = rstd * ((g - s1) - h * s2);
+        const float r = rstd * ((g - s1) - h * s2);
+        dx[off + c] = dx_add ? dx_add[off + c] + r : r;
         if (dy_xhat) dy_xhat[off + c] = d * h;
     }
 }
@@ -190,17 +195,17 @@ extern "C" int qarig_layernorm_fwd(const float* x, int M, int D, float eps, cons
 extern "C" int qarig_layernorm_bwd(const float* dy, const float* x, const float* mean,
                                    const float* rstd, const float* gamma, const float* scale,
                                    const int* mod_idx, int M, int D, float* dx, float* dy_xhat,
-                                   void* stream) {
+                                   const float* dx_add, void* stream) {
     QARIG_CHECK_ARG(dy && x && mean && rstd && dx && M > 0 && D > 0, "layernorm_bwd: bad arguments");
     QARIG_CHECK_DIMS("layernorm_bwd", M, D);
     QARIG_CHECK_ARG(!(gamma && scale), "layernorm_bwd: affine and AdaLN forms are exclusive");
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     const bool vec = D % 256 == 0 && al16(dy) && al16(x) && al16(gamma) && al16(scale) && al16(dx) &&
-                     al16(dy_xhat);
+                     al16(dy_xhat) && al16(dx_add);
     const dim3 grid((M + LN_WAVES - 1) / LN_WAVES), block(LN_WAVES * 64);
 #define QARIG_LNB_LAUNCH(NV)                                                                       \
     hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), grid, block, 0, (hipStream_t)stream, dy, x, mean, \
-                       rstd, gamma, scale, mod_idx, M, D, dx, dy_xhat)
+                       rstd, gamma, scale, mod_idx, M, D, dx, dy_xhat, dx_add)
     switch (vec ? D / 256 : 0) {
         case 1: QARIG_LNB_LAUNCH(1); break;
         case 2: QARIG_LNB_LAUNCH(2); break;

@@ -78,17 +78,21 @@ class AdaLNZero(nn.Module):
         self.scale_layer = ScaleLayer(in_dim=in_dim, out_dim=out_dim)
         self.shift_layer = ShiftLayer(in_dim=in_dim, out_dim=out_dim)
 
-    def forward(self, x, cond):
+    def forward(self, x, cond, with_skip=False):
         if isinstance(cond, QF.CondTable):     # projections once per position, indexed per token
             return QF.layernorm_mod_table(x, cond.projection(self.scale_layer.scale),
-                                          cond.projection(self.shift_layer.shift), cond, self.norm.eps)
-        return QF.layernorm_mod(x, self.scale_layer(cond), self.shift_layer(cond), self.norm.eps)
+                                          cond.projection(self.shift_layer.shift), cond, self.norm.eps,
+                                          with_skip=with_skip)
+        return QF.layernorm_mod(x, self.scale_layer(cond), self.shift_layer(cond), self.norm.eps,
+                                with_skip=with_skip)
 
 
 def _norm_forward(norm, x, cond, use_adaln0):
+    """(normalised x, alias of x for the block's skip connection): both gradients of x then meet in
+    the normalisation node's backward, whose kernel adds them (no separate accumulation launch)."""
     if use_adaln0:
-        return norm(x, cond=cond)
-    return QF.layernorm_affine(x, norm.weight, norm.bias, norm.eps)
+        return norm(x, cond=cond, with_skip=True)
+    return QF.layernorm_affine(x, norm.weight, norm.bias, norm.eps, with_skip=True)
 
 
 class ConvLayer(nn.Module):
@@ -216,9 +220,9 @@ class FeedforwardBlock(nn.Module):
             use_scale_layer=use_scale_layer, activation_type=activation_type)
 
     def forward(self, x, cond=None):
-        h = _norm_forward(self.feedforward_norm, x, cond, self.use_adaln0)
+        h, xs = _norm_forward(self.feedforward_norm, x, cond, self.use_adaln0)
         h = _mlp2_forward(self.feedforward, h)
-        return self.feedforward_res(x=h, x_skip=x, cond=cond)
+        return self.feedforward_res(x=h, x_skip=xs, cond=cond)
 
 
 class AttentionLayer(nn.Module):
@@ -282,9 +286,9 @@ class SelfAttentionBlock(nn.Module):
             use_scale_layer=use_scale_layer, activation_type=activation_type)
 
     def forward(self, x, cond=None):
-        h = _norm_forward(self.self_attn_norm, x, cond, self.use_adaln0)
+        h, xs = _norm_forward(self.self_attn_norm, x, cond, self.use_adaln0)
         h = self.self_attn(h)
-        return self.self_attn_res(x=h, x_skip=x, cond=cond)
+        return self.self_attn_res(x=h, x_skip=xs, cond=cond)
 
 
 class CrossAttentionBlock(nn.Module):
@@ -306,9 +310,9 @@ class CrossAttentionBlock(nn.Module):
             use_scale_layer=use_scale_layer, activation_type=activation_type)
 
     def forward(self, x, cross_cond, cond=None):
-        h = _norm_forward(self.cross_attn_norm, x, cond, self.use_adaln0)
+        h, xs = _norm_forward(self.cross_attn_norm, x, cond, self.use_adaln0)
         h = self.cross_attn(x=h, cross_cond=cross_cond)
-        return self.cross_attn_res(x=h, cond=cond, x_skip=x)
+        return self.cross_attn_res(x=h, cond=cond, x_skip=xs)
 
 
 class TransformerBlock(nn.Module):

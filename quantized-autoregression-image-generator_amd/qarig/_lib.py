@@ -54,7 +54,7 @@ SIGNATURES = {
     "qarig_embedding_fwd": (I, [P, I, I, I, I, P, P, P, P, P]),
     "qarig_embedding_bwd": (I, [P, I, I, I, P, P, P]),
     "qarig_layernorm_fwd": (I, [P, I, I, F, P, P, P, P, P, P, P, P, P]),
-    "qarig_layernorm_bwd": (I, [P, P, P, P, P, P, P, I, I, P, P, P]),
+    "qarig_layernorm_bwd": (I, [P, P, P, P, P, P, P, I, I, P, P, P, P]),
     "qarig_rowmap_build": (I, [P, I, I, P, P, P, P, P]),
     "qarig_segment_sum": (I, [P, P, P, I, I, P, P]),
     "qarig_mul_rows_fwd": (I, [P, P, P, P, I, I, P]),

@@ -317,30 +317,51 @@ def mul(a, b):
     return _Mul.apply(a, b)
 
 
+def _with_skip(y, x, with_skip):
+    """(y, alias of x) for a normalisation node that also hands x to the block's skip connection."""
+    return (y, x.view_as(x)) if with_skip else y
+
+
+def _skip_grads(dy, dskip, x2):
+    """Upstream gradients of a with_skip node -> (dy (M,D), skip gradient (M,D) or None).  Either
+    may be missing (set_materialize_grads(False)): a consumer that ignores one of the outputs."""
+    if dy is None:
+        dy2 = torch.zeros_like(x2)
+    else:
+        dy2 = _2d(f32c(dy))
+    add = _2d(f32c(dskip)) if dskip is not None else None
+    return dy2, add
+
+
 class _LayerNormAffine(torch.autograd.Function):
     """nn.LayerNorm(D) with gamma/beta (encoder blocks)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, with_skip=False):
         require_cuda(x, gamma, beta)
         x2 = _2d(f32c(x))
         y, mean, rstd = ops.layernorm_fwd(x2, gamma=gamma, beta=beta, eps=eps)
         ctx.save_for_backward(x2, gamma, mean, rstd)
-        return y.reshape(x.shape)
+        ctx.shape = x.shape
+        ctx.set_materialize_grads(False)
+        return _with_skip(y.reshape(x.shape), x, with_skip)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x2, gamma, mean, rstd = ctx.saved_tensors
-        dy2 = _2d(f32c(dy))
-        dx, dyx = ops.layernorm_bwd(dy2, x2, mean, rstd, gamma=gamma, want_dy_xhat=True)
-        return dx.reshape(dy.shape), ops.colsum(dyx), ops.colsum(dy2), None
+        dy2, add = _skip_grads(dy, dskip, x2)
+        dx, dyx = ops.layernorm_bwd(dy2, x2, mean, rstd, gamma=gamma, want_dy_xhat=True, dx_add=add)
+        return dx.reshape(ctx.shape), ops.colsum(dyx), ops.colsum(dy2), None, None
 
 
-def layernorm_affine(x, gamma, beta, eps=1e-5):
+def layernorm_affine(x, gamma, beta, eps=1e-5, with_skip=False):
+    """with_skip: returns (y, x_alias); the block's skip connection takes x_alias, so that both
+    gradients of x arrive in this node's backward and are added by the LayerNorm kernel."""
     if _no_grad():
         require_cuda(x, gamma, beta)
-        return ops.layernorm_fwd(_2d(f32c(x)), gamma=gamma, beta=beta, eps=eps)[0].reshape(x.shape)
-    return _LayerNormAffine.apply(x, gamma, beta, eps)
+        y = ops.layernorm_fwd(_2d(f32c(x)), gamma=gamma, beta=beta, eps=eps)[0].reshape(x.shape)
+        return (y, x) if with_skip else y
+    return _LayerNormAffine.apply(x, gamma, beta, eps, with_skip)
 
 
 class _LayerNormMod(torch.autograd.Function):
@@ -348,28 +369,31 @@ class _LayerNormMod(torch.autograd.Function):
     (reference models/layers.py:146-153)."""
 
     @staticmethod
-    def forward(ctx, x, scale, shift, eps):
+    def forward(ctx, x, scale, shift, eps, with_skip=False):
         require_cuda(x, scale, shift)
         x2 = _2d(f32c(x))
         s2 = _2d(f32c(scale))
         y, mean, rstd = ops.layernorm_fwd(x2, scale=s2, shift=_2d(f32c(shift)), eps=eps)
         ctx.save_for_backward(x2, s2, mean, rstd)
-        return y.reshape(x.shape)
+        ctx.shape = x.shape
+        ctx.set_materialize_grads(False)
+        return _with_skip(y.reshape(x.shape), x, with_skip)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x2, s2, mean, rstd = ctx.saved_tensors
-        dy2 = _2d(f32c(dy))
-        dx, dscale = ops.layernorm_bwd(dy2, x2, mean, rstd, scale=s2, want_dy_xhat=True)
-        return dx.reshape(dy.shape), dscale.reshape(dy.shape), dy, None
+        dy2, add = _skip_grads(dy, dskip, x2)
+        dx, dscale = ops.layernorm_bwd(dy2, x2, mean, rstd, scale=s2, want_dy_xhat=True, dx_add=add)
+        return dx.reshape(ctx.shape), dscale.reshape(ctx.shape), dy2.reshape(ctx.shape), None, None
 
 
-def layernorm_mod(x, scale, shift, eps=1e-5):
+def layernorm_mod(x, scale, shift, eps=1e-5, with_skip=False):
     if _no_grad():
         require_cuda(x, scale, shift)
-        return ops.layernorm_fwd(_2d(f32c(x)), scale=_2d(f32c(scale)), shift=_2d(f32c(shift)),
-                                 eps=eps)[0].reshape(x.shape)
-    return _LayerNormMod.apply(x, scale, shift, eps)
+        y = ops.layernorm_fwd(_2d(f32c(x)), scale=_2d(f32c(scale)), shift=_2d(f32c(shift)),
+                              eps=eps)[0].reshape(x.shape)
+        return (y, x) if with_skip else y
+    return _LayerNormMod.apply(x, scale, shift, eps, with_skip)
 
 
 class _Attention(torch.autograd.Function):
@@ -670,31 +694,34 @@ class _LayerNormModTable(torch.autograd.Function):
     """AdaLNZero with scale/shift given per POSITION: y = scale_tab[idx] * LN(x) + shift_tab[idx]."""
 
     @staticmethod
-    def forward(ctx, x, scale_tab, shift_tab, idx, offsets, rows, eps):
+    def forward(ctx, x, scale_tab, shift_tab, idx, offsets, rows, eps, with_skip=False):
         require_cuda(x, scale_tab, shift_tab)
         x2 = _2d(f32c(x))
         st = f32c(scale_tab)
         y, mean, rstd = ops.layernorm_fwd(x2, scale=st, shift=f32c(shift_tab), eps=eps, mod_idx=idx)
         ctx.save_for_backward(x2, st, mean, rstd, idx, offsets, rows)
-        return y.reshape(x.shape)
+        ctx.shape = x.shape
+        ctx.set_materialize_grads(False)
+        return _with_skip(y.reshape(x.shape), x, with_skip)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x2, st, mean, rstd, idx, offsets, rows = ctx.saved_tensors
-        dy2 = _2d(f32c(dy))
+        dy2, add = _skip_grads(dy, dskip, x2)
         dx, dscale_tok = ops.layernorm_bwd(dy2, x2, mean, rstd, scale=st, want_dy_xhat=True,
-                                           mod_idx=idx)
+                                           mod_idx=idx, dx_add=add)
         dscale = ops.segment_sum(dscale_tok, offsets, rows)
         dshift = ops.segment_sum(dy2, offsets, rows)
-        return dx.reshape(dy.shape), dscale, dshift, None, None, None, None
+        return dx.reshape(ctx.shape), dscale, dshift, None, None, None, None, None
 
 
-def layernorm_mod_table(x, scale_tab, shift_tab, cond, eps=1e-5):
+def layernorm_mod_table(x, scale_tab, shift_tab, cond, eps=1e-5, with_skip=False):
     if _no_grad():
         require_cuda(x, scale_tab, shift_tab)
-        return ops.layernorm_fwd(_2d(f32c(x)), scale=f32c(scale_tab), shift=f32c(shift_tab), eps=eps,
-                                 mod_idx=cond.idx)[0].reshape(x.shape)
-    return _LayerNormModTable.apply(x, scale_tab, shift_tab, cond.idx, cond.offsets, cond.rows, eps)
+        y = ops.layernorm_fwd(_2d(f32c(x)), scale=f32c(scale_tab), shift=f32c(shift_tab), eps=eps,
+                              mod_idx=cond.idx)[0].reshape(x.shape)
+        return (y, x) if with_skip else y
+    return _LayerNormModTable.apply(x, scale_tab, shift_tab, cond.idx, cond.offsets, cond.rows, eps, with_skip)
 
 
 class _MulTable(torch.autograd.Function):

@@ -580,12 +580,16 @@ def layernorm_fwd(x2d, gamma=None, beta=None, scale=None, shift=None, eps=1e-5, 
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x2d, mean, rstd, gamma=None, scale=None, want_dy_xhat=False, mod_idx=None):
+def layernorm_bwd(dy, x2d, mean, rstd, gamma=None, scale=None, want_dy_xhat=False, mod_idx=None,
+                  dx_add=None):
+    """dx_add (M,D): the skip connection's gradient of the same x, added into dx by the kernel."""
     M, D = x2d.shape
     dx = torch.empty_like(x2d)
     dyx = torch.empty_like(x2d) if want_dy_xhat else None
+    if dx_add is not None:
+        assert dx_add.shape == x2d.shape and dx_add.dtype == torch.float32 and dx_add.is_contiguous()
     check(_lib.load().qarig_layernorm_bwd(ptr(dy), ptr(x2d), ptr(mean), ptr(rstd), ptr(gamma),
-                                          ptr(scale), ptr(mod_idx), M, D, ptr(dx), ptr(dyx),
+                                          ptr(scale), ptr(mod_idx), M, D, ptr(dx), ptr(dyx), ptr(dx_add),
                                           stream()), "qarig_layernorm_bwd")
     return dx, dyx
 
