@@ -54,6 +54,42 @@ def test_layernorm_forms(M, D):
         assert rel_err(a, b) < 5e-6
 
 
+@pytest.mark.parametrize("M,D", [(7, 32), (300, 512), (64, 100)])
+def test_layernorm_with_skip_adds_both_gradients_of_x(M, D):
+    """with_skip nodes return (y, alias of x): the skip connection's gradient comes back into the
+    node and the LayerNorm backward kernel adds it (qarig_layernorm_bwd dx_add) -- same dx as the
+    two-consumer graph that autograd would accumulate itself; a consumer may ignore either output."""
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(M * 3 + D)
+    x = (torch.randn((M, D), generator=g) * 2 + 0.5).cuda()
+    gam, bet = torch.randn(D, generator=g).cuda(), torch.randn(D, generator=g).cuda()
+    sc, sh = torch.randn((M, D), generator=g).cuda(), torch.randn((M, D), generator=g).cuda()
+    dy, ds = torch.randn((M, D), generator=g).cuda(), torch.randn((M, D), generator=g).cuda()
+    for form in ("affine", "mod"):
+        def node(xx, with_skip):
+            if form == "affine":
+                return QF.layernorm_affine(xx, gam, bet, with_skip=with_skip)
+            return QF.layernorm_mod(xx, sc, sh, with_skip=with_skip)
+        xa = x.clone().requires_grad_(True)
+        ya = node(xa, False)
+        ((ya * dy).sum() + (xa * ds).sum()).backward()          # autograd adds the two gradients
+        xb = x.clone().requires_grad_(True)
+        yb, xs = node(xb, True)
+        assert xs.data_ptr() == xb.data_ptr() and torch.equal(ya, yb)
+        ((yb * dy).sum() + (xs * ds).sum()).backward()
+        assert rel_err(xb.grad, xa.grad) < 1e-6
+        xc = x.clone().requires_grad_(True)                     # skip output unused
+        yc, _ = node(xc, True)
+        (yc * dy).sum().backward()
+        xd = x.clone().requires_grad_(True)
+        (node(xd, False) * dy).sum().backward()
+        assert torch.equal(xc.grad, xd.grad)
+        xe = x.clone().requires_grad_(True)                     # only the skip output used
+        _, xs = node(xe, True)
+        (xs * ds).sum().backward()
+        assert rel_err(xe.grad, ds) < 1e-6
+
+
 @pytest.mark.parametrize("N,Sq,Sk,H,d,causal", [(2, 12, 12, 4, 8, True), (3, 70, 70, 2, 16, True),
                                                 (2, 256, 256, 8, 8, True), (2, 33, 5, 4, 8, False),
                                                 (1, 130, 130, 2, 64, False), (2, 9, 1, 2, 4, False),
