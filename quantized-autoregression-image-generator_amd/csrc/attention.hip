@@ -251,28 +251,34 @@ __global__ __launch_bounds__(MAXT) void attn_fwd_kernel(const float* __restrict_
                 s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 dot_rows<LP, HD>(s[u], kr + 4 * u * Geo<HD>::RS, qv);
             }
-            float sc[KS];
-#pragma unroll
-            for (int u = 0; u < NQ; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sc[4 * u + r] = s[u][r] * a.c2;
+            // raw scores; the scale (c2 > 0) enters once on the maximum and inside the exponent's fma
             if (j0 + KS > jw || (a.causal && j0 + KS - 1 > q0)) {     // wave-uniform: edge steps only
 #pragma unroll
                 for (int r = 0; r < KS; ++r)
-                    if (j0 + r >= jw || (a.causal && j0 + r > i)) sc[r] = -INFINITY;
+                    if (j0 + r >= jw || (a.causal && j0 + r > i)) s[r >> 2][r & 3] = -INFINITY;
             }
-            float mc = sc[0];
+            float mc = s[0][0];
 #pragma unroll
-            for (int r = 1; r < KS; ++r) mc = fmaxf(mc, sc[r]);
-            const float mn = fmaxf(m, mc);
+            for (int r = 1; r < KS; ++r) mc = fmaxf(mc, s[r >> 2][r & 3]);
+            const float mn = fmaxf(m, mc * a.c2);
             const float msafe = mn == -INFINITY ? 0.0f : mn;     // fully masked so far: p = 0
             const float alpha = exp2_fast(m - msafe);
             l *= alpha;
 #pragma unroll
             for (int g = 0; g < G; ++g) ov[g] *= alpha;
             float p[KS];
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 lsum = {0.0f, 0.0f};
+            const f32x2 c2v = {a.c2, a.c2}, nm = {-msafe, -msafe};
 #pragma unroll
-            for (int r = 0; r < KS; ++r) { p[r] = exp2_fast(sc[r] - msafe); l += p[r]; }
+            for (int r = 0; r < KS; r += 2) {
+                const f32x2 sv = {s[r >> 2][r & 3], s[(r + 1) >> 2][(r + 1) & 3]};
+                const f32x2 d = __builtin_elementwise_fma(sv, c2v, nm);      // v_pk_fma_f32
+                const f32x2 pv2 = {exp2_fast(d[0]), exp2_fast(d[1])};
+                p[r] = pv2[0]; p[r + 1] = pv2[1];
+                lsum += pv2;                                                  // v_pk_add_f32
+            }
+            l += lsum[0] + lsum[1];
             m = mn;
             // PV: keys ascending per output column group
 #pragma unroll
