@@ -308,6 +308,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_enqueued = time.perf_counter() - t0          # host side done; the GPU may still be running
     fence()
     dt = time.perf_counter() - t0
     loss_val = float(loss.item())
@@ -367,6 +368,7 @@ def main():
                       "dec_layers": cfg["dec_layers"], "enc_layers": cfg["enc_layers"],
                       "params": int(optim.total),
                       "parallelism": f"dp{world}", "loss": round(loss_val, 5),
+                      "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
                       "launch": "captured HIP graph replay" if args.graph else "eager stream launches"}}
     if allreduce is not None:
         out["allreduce"] = allreduce

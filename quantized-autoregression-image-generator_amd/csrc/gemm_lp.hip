@@ -166,6 +166,122 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_lp_kernel(const bf16_t* __re
 }
 
 // ---------------------------------------------------------------------------------
+// 256 x 256 x 64 tiles, 16 waves (4 x 4, each the same 64 x 64 sub-tile as above), one workgroup
+// per CU with a 2-stage ring of 64 KB stages (128 KB of LDS).  Why: the 128 x 128 kernel keeps
+// 2 x 32 KB of operands in flight per CU; at ~1 us of DMA latency that bounds it near 1 PF however
+// the loop is scheduled (slope of time against K at M = 32768: 0.137 us per k).  A 256 x 256 tile
+// does twice the MFMA work per byte, so the same 64 KB in flight covers twice the rate.
+// Operand images: NT tiles are [256 rows][64 k] (the small tile's image with more rows); TN
+// tiles [64 k][256 x] with 512-B rows, chunk c of k-row r at c ^ tn_swz(r) (the swizzle permutes
+// inside 256-B halves, which is what the transposing reads need).
+constexpr int LPB = 256;                         // tile extent
+constexpr int LPB_OP = LPB * LBK;                // bf16 elements per operand tile (32 KB)
+constexpr int LPB_STAGE = 2 * LPB_OP;            // 64 KB
+
+template <bool TN>
+__device__ __forceinline__ void lpb_stage(const bf16_t* __restrict__ P, int64_t ld, int x0, int k0,
+                                          bf16_t* tile, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = wave * 2 + i;              // 32 x 1 KiB per operand tile
+        const bf16_t* src;
+        if (!TN) {   // [x][k]: 8 rows x 128 B per instruction
+            const int r = q * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            src = P + (int64_t)(x0 + r) * ld + k0 + c * 8;
+        } else {     // [k][x]: 2 k-rows x 512 B per instruction
+            const int r = q * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ tn_swz(r);
+            src = P + (int64_t)(k0 + r) * ld + x0 + c * 8;
+        }
+        __builtin_amdgcn_global_load_lds((glb_ptr_lp)src, (lds_ptr_lp)(tile + q * 512), 16, 0, 0);
+    }
+}
+template <bool TN>
+__device__ __forceinline__ void lpb_frag(const bf16_t* tile, int x0, int ks, int lane, LpFrag<TN>& f) {
+    if constexpr (!TN) {
+        lp_frag<false>(tile, x0, ks, lane, f);   // same image, more rows
+    } else {
+        const int g = lane >> 4, w = lane & 15, q = w >> 2, p = w & 3;
+        const int ch = ((x0 + 16 * (g & 1)) >> 3) + (p >> 1);
+        const int r0 = ks * 16 + 8 * (g >> 1) + q;
+        const int r1 = r0 + 4;
+        const unsigned base = lds_addr_lp(tile) + 8 * (p & 1);
+        const unsigned a0 = base + 512 * r0 + ((ch ^ tn_swz(r0)) << 4);
+        const unsigned a1 = base + 512 * r1 + ((ch ^ tn_swz(r1)) << 4);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a1));
+    }
+}
+
+template <bool TNA, bool TNB>
+__global__ __launch_bounds__(1024, 1) void gemm_lp_big_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                              const bf16_t* __restrict__ B, int64_t ldb,
+                                                              GemmEpilogue ep, int M, int N, int K,
+                                                              int tiles_n, int splitk, float* slabs) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t ldsb[];   // 2 x 64 KB
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * LPB, n0 = tn * LPB;
+    int k_begin = 0, k_end = K;
+    if (splitk > 1) {
+        const int per = K / splitk;
+        k_begin = blockIdx.z * per;
+        k_end = k_begin + per;
+    }
+    const int nk = (k_end - k_begin) / LBK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    Acc acc;
+    acc_zero(acc);
+    if (nk > 0) {
+        lpb_stage<TNA>(A, lda, m0, k_begin, ldsb, wave, lane);
+        lpb_stage<TNB>(B, ldb, n0, k_begin, ldsb + LPB_OP, wave, lane);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int st = kt & 1;
+            if (kt + 1 < nk) {
+                const int kn = k_begin + (kt + 1) * LBK;
+                lpb_stage<TNA>(A, lda, m0, kn, ldsb + (st ^ 1) * LPB_STAGE, wave, lane);
+                lpb_stage<TNB>(B, ldb, n0, kn, ldsb + (st ^ 1) * LPB_STAGE + LPB_OP, wave, lane);
+            }
+            const bf16_t* ta = ldsb + st * LPB_STAGE;
+            const bf16_t* tb = ta + LPB_OP;
+            // two k-steps of fragments at a time (4 waves per SIMD: 128 VGPRs each)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                LpFrag<TNA> fa[2][2];
+                LpFrag<TNB> fb[2][2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        lpb_frag<TNA>(ta, wm * 64 + i * 32, 2 * h + ks, lane, fa[ks][i]);
+                        lpb_frag<TNB>(tb, wn * 64 + i * 32, 2 * h + ks, lane, fb[ks][i]);
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc.t[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                fa[ks][i].value(), fb[ks][j].value(), acc.t[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();                      // ring idle: 16 x 8 KB of epilogue staging
+    gemm_epilogue_wave(acc, ep, reinterpret_cast<float*>(ldsb) + wave * (32 * 64), m0 + wm * 64, n0 + wn * 64,
+                       M, N, splitk, slabs);
+}
+
+// ---------------------------------------------------------------------------------
 // fp8 (OCP e4m3) operands: BASELINE config 5 names the fp8 MFMA.  NT layout only (the forward
 // products x W^T): A (M,K) and B (N,K) are bytes, per-tensor scaled by the cast kernels below;
 // products on v_mfma_f32_32x32x64_f8f6f4 (64 deep per instruction, twice the bf16 rate), fp32
@@ -546,6 +662,37 @@ extern "C" int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t 
                     (unsigned short*)Cb, ldcb, (unsigned short*)Pb, ldpb,
                     gradz_is_bf16 ? (const unsigned short*)gradz : nullptr, ldz};
     hipStream_t st = (hipStream_t)stream;
+    // 256 x 256 tiles where they still give every CU a workgroup; QARIG_LP_BIG=0/1 overrides
+    static const int big_env = []() { const char* e = getenv("QARIG_LP_BIG"); return e ? atoi(e) : -1; }();
+    const long big_tiles = (long)(M / LPB) * (N / LPB) * splitk;
+    if (M % LPB == 0 && N % LPB == 0 && big_env != 0 && (big_env == 1 || big_tiles >= 224)) {
+        constexpr int BIG_LDS = 2 * LPB_STAGE * (int)sizeof(bf16_t);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_lp_big_kernel<false, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+            (void)hipFuncSetAttribute((const void*)gemm_lp_big_kernel<true, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+            (void)hipFuncSetAttribute((const void*)gemm_lp_big_kernel<false, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+            attr_set = true;
+        }
+        dim3 gridb((M / LPB) * (N / LPB), 1, splitk), blockb(1024);
+        const int tnb = N / LPB;
+        if (layout == 0)
+            hipLaunchKernelGGL((gemm_lp_big_kernel<false, false>), gridb, blockb, BIG_LDS, st, (const bf16_t*)A, lda,
+                               (const bf16_t*)B, ldb, ep, M, N, K, tnb, splitk, (float*)workspace);
+        else if (layout == 1)
+            hipLaunchKernelGGL((gemm_lp_big_kernel<true, true>), gridb, blockb, BIG_LDS, st, (const bf16_t*)A, lda,
+                               (const bf16_t*)B, ldb, ep, M, N, K, tnb, splitk, (float*)workspace);
+        else
+            hipLaunchKernelGGL((gemm_lp_big_kernel<false, true>), gridb, blockb, BIG_LDS, st, (const bf16_t*)A, lda,
+                               (const bf16_t*)B, ldb, ep, M, N, K, tnb, splitk, (float*)workspace);
+        QARIG_CHECK_LAUNCH("gemm_lp big");
+        if (splitk > 1)
+            return qarig_slab_reduce_f32((const float*)workspace, C, ldc, M, N, splitk, accumulate, stream);
+        return QARIG_OK;
+    }
     if (layout == 0)
         hipLaunchKernelGGL((gemm_lp_kernel<false, false>), grid, block, 0, st, (const bf16_t*)A, lda,
                            (const bf16_t*)B, ldb, ep, M, N, K, tiles_n, splitk, (float*)workspace);

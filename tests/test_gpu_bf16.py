@@ -41,13 +41,14 @@ def test_cast_kernels_round_to_nearest_even():
     assert torch.equal(v, x[:, :128].bfloat16().t().contiguous())
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 384, 192), (4096, 4096, 192), (2048, 512, 2048)])
 @pytest.mark.parametrize("layout", [0, 1, 2])
-def test_lp_fragment_maps_on_exact_integer_data(layout):
+def test_lp_fragment_maps_on_exact_integer_data(layout, M, N, K):
     """A = a permutation-like integer matrix, B asymmetric small integers: every product and sum
     is exact in bf16/fp32, so any wrong lane map, swizzle or transposed read shows as a wrong
-    integer (guide: 'A = I check with ASYMMETRIC B')."""
+    integer (guide: 'A = I check with ASYMMETRIC B').  4096 x 4096 reaches the 256 x 256-tile
+    kernel (>= 224 of its tiles), 2048 x 512 x 2048 reaches it through split-K."""
     from qarig import ops
-    M, N, K = 256, 384, 192
     g = torch.Generator().manual_seed(3)
     A = torch.zeros((M, K))
     A[torch.arange(M), torch.randint(0, K, (M,), generator=g)] = 1.0
@@ -66,7 +67,7 @@ def test_lp_fragment_maps_on_exact_integer_data(layout):
     assert torch.equal(C.double().cpu(), ref)
     assert torch.equal(Cb.double().cpu(), ref.bfloat16().double())
     C2 = torch.empty((M, N), device="cuda")
-    ops.gemm_lp(Ab, Bb, layout, M, N, K, C=C2, splitk=3)
+    ops.gemm_lp(Ab, Bb, layout, M, N, K, C=C2, splitk=32 if K == 2048 else 3)
     assert torch.equal(C2.double().cpu(), ref)
 
 

@@ -17,6 +17,7 @@ SHAPES = [  # (name, M, N, K, a_kcontig, b_kcontig, kwargs)
     ("fwd 512->2048 plain", M, 2048, 512, True, True, {}),
     ("dX  [M,2048]@[2048,512]", M, 512, 2048, True, False, {}),
     ("dH  [M,512]@[512,2048] *act'", M, 2048, 512, True, False, dict(gradz=True)),
+    ("dH  plain (no act' fusion)", M, 2048, 512, True, False, {}),
     ("dW  2048x512 over M (splitk)", 2048, 512, M, False, False, dict(splitk=-1)),
     ("dW  512x2048 over M (splitk)", 512, 2048, M, False, False, dict(splitk=-1)),
     ("dW  512x512 over M (splitk)", 512, 512, M, False, False, dict(splitk=-1)),
@@ -55,7 +56,7 @@ def main():
         for rnd in range(5):
             for st in sweep:
                 os.environ[sweep_env] = str(st)
-                for name, m, n, k, kw in cases[:9]:
+                for name, m, n, k, kw in cases[:10]:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ops.gemm(**kw)
                     e0.record()
@@ -64,14 +65,14 @@ def main():
                     e1.record()
                     torch.cuda.synchronize()
                     res.setdefault((name, st), []).append(2.0 * m * n * k / (e0.elapsed_time(e1) / 10) / 1e9)
-        for name, m, n, k, kw in cases[:9]:
+        for name, m, n, k, kw in cases[:10]:
             print(f"{name:36s} " + "  ".join(f"{sweep_env[-8:]}={st}: {sorted(res[(name, st)])[2]:6.1f}" for st in sweep))
         return
     if os.environ.get("SPLITS"):
         # SPLITS=0,1,2,4,8: time each shape (reduce pass included) per reduction split; 0 = the
         # library's own choice (ops.auto_splitk for the forward shapes, pick_splitk for dW)
         splits = [int(v) for v in os.environ["SPLITS"].split(",")]
-        for name, m, n, k, kw in cases[:9]:
+        for name, m, n, k, kw in cases[:10]:
             line = []
             for sk in splits:
                 kw2 = dict(kw)
