@@ -364,6 +364,65 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f8_kernel(const unsigned cha
     gemm_epilogue_wide(acc, ep, reinterpret_cast<float*>(lds), m0, n0, M, N, 1, nullptr);
 }
 
+// The e4m3 product on the 256 x 256 tile of gemm_lp_big_kernel (128 bytes deep per k-tile: the
+// same 64 KB stage images, lpb_stage<false> on the bytes).
+__global__ __launch_bounds__(1024, 1) void gemm_f8_big_kernel(const unsigned char* __restrict__ A, int64_t lda,
+                                                              const unsigned char* __restrict__ B, int64_t ldb,
+                                                              GemmEpilogue ep, int M, int N, int K, int tiles_n) {
+    constexpr int FBK = 128;
+    extern __shared__ __attribute__((aligned(16))) bf16_t ldsf[];   // 2 x 64 KB
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * LPB, n0 = tn * LPB;
+    const int nk = K / FBK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bf16_t* A2 = reinterpret_cast<const bf16_t*>(A);
+    const bf16_t* B2 = reinterpret_cast<const bf16_t*>(B);
+    const int64_t lda2 = lda / 2, ldb2 = ldb / 2;
+
+    Acc acc;
+    acc_zero(acc);
+    if (nk > 0) {
+        lpb_stage<false>(A2, lda2, m0, 0, ldsf, wave, lane);
+        lpb_stage<false>(B2, ldb2, n0, 0, ldsf + LPB_OP, wave, lane);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int st = kt & 1;
+            if (kt + 1 < nk) {
+                const int kn = (kt + 1) * (FBK / 2);
+                lpb_stage<false>(A2, lda2, m0, kn, ldsf + (st ^ 1) * LPB_STAGE, wave, lane);
+                lpb_stage<false>(B2, ldb2, n0, kn, ldsf + (st ^ 1) * LPB_STAGE + LPB_OP, wave, lane);
+            }
+            const bf16_t* ta = ldsf + st * LPB_STAGE;
+            const bf16_t* tb = ta + LPB_OP;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                F8Frag fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f8_frag(ta, wm * 64 + i * 32, ks, lane, fa[i]);
+                    f8_frag(tb, wn * 64 + i * 32, ks, lane, fb[i]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc.t[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                            fa[i].value(), fb[j].value(), acc.t[i][j], 0, 0, 0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();
+    gemm_epilogue_wave(acc, ep, reinterpret_cast<float*>(ldsf) + wave * (32 * 64), m0 + wm * 64, n0 + wn * 64,
+                       M, N, 1, nullptr);
+}
+
 // |x| maximum of a tensor as the bit pattern of a non-negative float (they order like
 // unsigned integers): *amax_bits must be zero before the launch.
 // With `bf` the bf16 copy of x (what the backward products read) is written in the same pass.
@@ -762,6 +821,21 @@ extern "C" int qarig_gemm_f8(const void* A, int64_t lda, const void* B, int64_t 
     const int tiles_m = M / BM, tiles_n = N / BN;
     GemmEpilogue ep{C, ldc, bias, residual, ldr, preact, ldp, act, nullptr, 0, 0, nullptr,
                     (unsigned short*)Cb, ldcb, (unsigned short*)Pb, ldpb, nullptr, 0, inv_a, inv_b};
+    static const int big_env = []() { const char* e = getenv("QARIG_LP_BIG"); return e ? atoi(e) : -1; }();
+    if (M % LPB == 0 && N % LPB == 0 && big_env != 0 && (big_env == 1 || (long)(M / LPB) * (N / LPB) >= 224)) {
+        constexpr int BIG_LDS = 2 * LPB_STAGE * (int)sizeof(bf16_t);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)gemm_f8_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      BIG_LDS);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_f8_big_kernel, dim3((M / LPB) * (N / LPB)), dim3(1024), BIG_LDS,
+                           (hipStream_t)stream, (const unsigned char*)A, lda, (const unsigned char*)B, ldb, ep, M,
+                           N, K, N / LPB);
+        QARIG_CHECK_LAUNCH("gemm_f8 big");
+        return QARIG_OK;
+    }
     hipLaunchKernelGGL(gemm_f8_kernel, dim3(tiles_m * tiles_n), dim3(NTHREADS), 0, (hipStream_t)stream,
                        (const unsigned char*)A, lda, (const unsigned char*)B, ldb, ep, M, N, K, tiles_n);
     QARIG_CHECK_LAUNCH("gemm_f8");

@@ -44,10 +44,11 @@ def test_cast_fp8_matches_torch_e4m3fn():
     assert int(q.max()) == 0 and float(inv) == 1.0
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 384, 512), (384, 128, 2048)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (256, 384, 512), (384, 128, 2048), (4096, 4096, 256)])
 def test_f8_fragment_map_on_exact_integer_data(M, N, K):
     """Small integers are exact in e4m3 and their products sum exactly in fp32: any slip in the
-    k order of the 32-byte fragments, the chunk swizzle or the tile map changes the result."""
+    k order of the 32-byte fragments, the chunk swizzle or the tile map changes the result.
+    (4096 x 4096 reaches the 256 x 256-tile kernel.)"""
     from qarig import ops
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randint(-4, 5, (M, K), generator=g).float()
