@@ -144,6 +144,43 @@ def test_bf16_gemm_epilogues_and_accumulate(bf16_mode):
     assert rel_err(rs, dT.double().cpu().sum(0)) < 2e-6
 
 
+def test_lp_big_tile_kernel_epilogues():
+    """The 256 x 256-tile kernel (taken from 224 of its tiles up: 4096 x 4096 here) through every
+    epilogue option, all three layouts: bias + residual + SiLU + saved pre-activation + bf16
+    copies (NT), the act' fusion on a bf16 pre-activation (NN), accumulate (TN)."""
+    from qarig import ops
+    from oracle import ref_models as rm
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 4096, 4096, 256
+    A = torch.randn((M, K), generator=g)
+    W = torch.randn((N, K), generator=g) * 0.1
+    b = torch.randn((N,), generator=g)
+    R = torch.randn((M, N), generator=g)
+    Z = torch.randn((M, N), generator=g)
+    Ab, Wb = A.cuda().bfloat16(), W.cuda().bfloat16()
+    t = _rounded(A) @ _rounded(W).t()
+    C = torch.empty((M, N), device="cuda")
+    pre = torch.empty((M, N), device="cuda")
+    Cb = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    Pb = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    ops.gemm_lp(Ab, Wb, 0, M, N, K, C=C, bias=b.cuda(), residual=R.cuda(), preact=pre, act=1, Cb=Cb, Pb=Pb)
+    tt = t + b.double() + R.double()
+    assert rel_err(pre, tt) < 3e-6
+    assert rel_err(C, rm.activation(tt, "silu")) < 5e-6
+    assert torch.equal(Cb, C.bfloat16()) and torch.equal(Pb, pre.bfloat16())
+    # NN: B reduction-major; C *= silu'(z) with z given in bf16
+    Zb = Z.cuda().bfloat16()
+    G = torch.empty((M, N), device="cuda")
+    ops.gemm_lp(Ab, Wb.t().contiguous(), 2, M, N, K, C=G, gradz=Zb, gact=1)
+    Zd = Zb.double().cpu().requires_grad_(True)
+    rm.activation(Zd, "silu").sum().backward()
+    assert rel_err(G, t * Zd.grad) < 5e-6
+    # TN: both operands reduction-major, accumulated into an existing tensor
+    acc = R.cuda().clone()
+    ops.gemm_lp(Ab.t().contiguous(), Wb.t().contiguous(), 1, M, N, K, C=acc, accumulate=True)
+    assert rel_err(acc, t + R.double()) < 3e-6
+
+
 def test_bf16_mode_falls_back_to_fp32_kernels_off_the_interior(bf16_mode):
     ops = bf16_mode
     g = torch.Generator().manual_seed(1)
