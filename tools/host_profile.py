@@ -8,9 +8,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "quantized-autoregression-image-generator_amd"))
 import bench
 sys.argv = ["bench.py", "--warmup", "2", "--no-cpu-baseline", "--no-kernel-events"] + sys.argv[1:]
+import torch
+torch.autograd.set_multithreading_enabled(False)      # backward on this thread: cProfile sees it
 pr = cProfile.Profile()
 pr.enable()
 bench.main()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(45)
