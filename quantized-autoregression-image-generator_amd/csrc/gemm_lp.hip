@@ -15,7 +15,11 @@
 // go global -> LDS by global_load_lds_dwordx4 (no VGPR staging) into a 2-stage ring, one
 // barrier per k-tile (the structure of gemm_dma_kernel).  The LDS image is lane-linear, so
 // the bank swizzles sit on the SOURCE address and on the read (guide rule 21):
-//   NT tile [128 rows][64 k]   (128-B rows):  16-B chunk c of row r at chunk c ^ (r & 7);
+//   NT tile [128 rows][64 k]   (128-B rows):  16-B chunk c of row r at chunk c ^ ((r >> 1) & 7): two
+//        rows share one 256-B bank line, and a ds_read_b128 lane group (16 lanes, NOT contiguous:
+//        rows {0-3,12-15,20-27} or {4-11,16-19,28-31} of the fragment) must land on 16 distinct
+//        16-B slots of it -- (r & 7) leaves every read 2-way conflicted (SQ_LDS_BANK_CONFLICT was
+//        44 % of the LDS cycles);
 //        fragments = one ds_read_b128 per (32-row tile, 16-deep k-step);
 //   TN tile [64 k][128 x]      (256-B rows):  chunk c of k-row r at c ^ (((r&3)<<2) | ((r>>2)&3));
 //        fragments = two ds_read_b64_tr_b16 (the hardware transpose read: 4 k-rows x 16 columns
@@ -51,7 +55,7 @@ __device__ __forceinline__ void lp_stage(const bf16_t* __restrict__ P, int64_t l
         const bf16_t* src;
         if (!TN) {   // [x][k]: 8 rows x 128 B per instruction
             const int r = q * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ (r & 7);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
             src = P + (int64_t)(x0 + r) * ld + k0 + c * 8;
         } else {     // [k][x]: 4 k-rows x 256 B per instruction
             const int r = q * 4 + (lane >> 4);
@@ -83,7 +87,7 @@ template <bool TN>
 __device__ __forceinline__ void lp_frag(const bf16_t* tile, int x0, int ks, int lane, LpFrag<TN>& f) {
     if constexpr (!TN) {
         const int r = x0 + (lane & 31);
-        const int c = (ks * 2 + (lane >> 5)) ^ (r & 7);
+        const int c = (ks * 2 + (lane >> 5)) ^ ((r >> 1) & 7);
         const unsigned a = lds_addr_lp(tile) + r * 128 + (c << 4);
         asm volatile("ds_read_b128 %0, %1" : "=v"(f.v) : "v"(a));
     } else {
@@ -187,7 +191,7 @@ __device__ __forceinline__ void lpb_stage(const bf16_t* __restrict__ P, int64_t 
         const bf16_t* src;
         if (!TN) {   // [x][k]: 8 rows x 128 B per instruction
             const int r = q * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ (r & 7);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
             src = P + (int64_t)(x0 + r) * ld + k0 + c * 8;
         } else {     // [k][x]: 2 k-rows x 512 B per instruction
             const int r = q * 2 + (lane >> 5);
@@ -302,7 +306,7 @@ __device__ __forceinline__ void f8_frag(const bf16_t* tile, int x0, int ks, int 
     const int r = x0 + (lane & 31);
     const int c0 = ks * 4 + (lane >> 5) * 2;
     const unsigned base = lds_addr_lp(tile) + r * 128;
-    const unsigned a0 = base + (((c0) ^ (r & 7)) << 4), a1 = base + (((c0 + 1) ^ (r & 7)) << 4);
+    const unsigned a0 = base + (((c0) ^ ((r >> 1) & 7)) << 4), a1 = base + (((c0 + 1) ^ ((r >> 1) & 7)) << 4);
     asm volatile("ds_read_b128 %0, %1" : "=v"(f.lo) : "v"(a0));
     asm volatile("ds_read_b128 %0, %1" : "=v"(f.hi) : "v"(a1));
 }
