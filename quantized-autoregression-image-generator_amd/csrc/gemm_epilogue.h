@@ -40,8 +40,36 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 // residual, gradz, slabs) is a 16-B-per-lane, 256-B-per-row dwordx4 instead of 4x as many
 // 4-B accesses (the epilogue is store-issue bound otherwise).  `lds`: >= 32 KB, free.
 // General form: the wave's tile starts at (mb, nb); `stage` = this wave's 32 x 64 floats of LDS.
-template <int NJ = 2>
-__device__ __forceinline__ void gemm_epilogue_wave(const Acc& acc, const GemmEpilogue& ep, float* stage,
+// Accumulators of a wave's 64x64 sub-tile as 4x4 tiles of 16x16 (v_mfma_f32_16x16x32_bf16: lane l
+// holds rows 4 (l >> 4) + r, r = 0..3, of column l & 15); the epilogue only differs in how a
+// 32-row half is written to the staging buffer.
+struct Acc16 {
+    f32x4 t[4][4];   // [16-row tile][16-column tile]
+};
+template <int NJ>
+__device__ __forceinline__ void acc_stage_half(const Acc& acc, int i, float* stage, int lane) {
+    constexpr int EL = 32 * NJ;
+    const int cl = lane & 31;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            stage[acc_row(r, lane) * EL + j * 32 + cl] = acc.t[i][j][r];
+}
+template <int NJ>
+__device__ __forceinline__ void acc_stage_half(const Acc16& acc, int i, float* stage, int lane) {
+    static_assert(NJ == 2, "16x16 accumulators cover the full 64 columns");
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                stage[(h * 16 + 4 * (lane >> 4) + r) * 64 + tj * 16 + (lane & 15)] = acc.t[2 * i + h][tj][r];
+}
+
+template <int NJ = 2, class AccT = Acc>
+__device__ __forceinline__ void gemm_epilogue_wave(const AccT& acc, const GemmEpilogue& ep, float* stage,
                                                    int mb, int nb, int M, int N, int splitk,
                                                    float* slabs, int i_begin = 0, int i_end = 2);
 
@@ -65,8 +93,8 @@ __device__ __forceinline__ float act_grad_t(float x, int act) {
         return sg * (1.0f + x * (1.0f - sg));
     } else return 1.0f;
 }
-template <int NJ, int A, int GA>
-__device__ __forceinline__ void gemm_epilogue_wave_t(const Acc& acc, const GemmEpilogue& ep, float* stage,
+template <int NJ, int A, int GA, class AccT>
+__device__ __forceinline__ void gemm_epilogue_wave_t(const AccT& acc, const GemmEpilogue& ep, float* stage,
                                                      int mb, int nb, int M, int N, int splitk,
                                                      float* slabs, int i_begin, int i_end);
 
@@ -81,27 +109,26 @@ __device__ __forceinline__ void gemm_epilogue_wide(const Acc& acc, const GemmEpi
 
 // [i_begin, i_end): which 32-row halves of the wave's tile this call stores (wave-uniform; the
 // paired kernel gives each of its two waves per tile one half).
-template <int NJ>
-__device__ __forceinline__ void gemm_epilogue_wave(const Acc& acc, const GemmEpilogue& ep, float* stage,
+template <int NJ, class AccT>
+__device__ __forceinline__ void gemm_epilogue_wave(const AccT& acc, const GemmEpilogue& ep, float* stage,
                                                    int mb, int nb, int M, int N, int splitk,
                                                    float* slabs, int i_begin, int i_end) {
     const bool grad = ep.gradz != nullptr || ep.gradzb != nullptr;
     if (ep.act == ACT_NONE && !grad)
-        gemm_epilogue_wave_t<NJ, ACT_NONE, ACT_NONE>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
+        gemm_epilogue_wave_t<NJ, ACT_NONE, ACT_NONE, AccT>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
     else if (ep.act == ACT_SILU && !grad)
-        gemm_epilogue_wave_t<NJ, ACT_SILU, ACT_NONE>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
+        gemm_epilogue_wave_t<NJ, ACT_SILU, ACT_NONE, AccT>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
     else if (ep.act == ACT_NONE && ep.gact == ACT_SILU)
-        gemm_epilogue_wave_t<NJ, ACT_NONE, ACT_SILU>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
+        gemm_epilogue_wave_t<NJ, ACT_NONE, ACT_SILU, AccT>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
     else
-        gemm_epilogue_wave_t<NJ, ACT_RUNTIME, ACT_RUNTIME>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
+        gemm_epilogue_wave_t<NJ, ACT_RUNTIME, ACT_RUNTIME, AccT>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
 }
 
-template <int NJ, int A, int GA>
-__device__ __forceinline__ void gemm_epilogue_wave_t(const Acc& acc, const GemmEpilogue& ep, float* stage,
+template <int NJ, int A, int GA, class AccT>
+__device__ __forceinline__ void gemm_epilogue_wave_t(const AccT& acc, const GemmEpilogue& ep, float* stage,
                                                      int mb, int nb, int M, int N, int splitk,
                                                      float* slabs, int i_begin, int i_end) {
     const int lane = threadIdx.x & 63;
-    const int cl = lane & 31;
     // unpadded rows are conflict-free for both the b32 writes (half-waves hit different rows)
     // and the b128 reads.  The wave's tile is 64 rows x 32*NJ columns (NJ = 1: accumulators t[i][0])
     constexpr int EL = 32 * NJ;
@@ -114,11 +141,7 @@ __device__ __forceinline__ void gemm_epilogue_wave_t(const Acc& acc, const GemmE
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         if (i < i_begin || i >= i_end) continue;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stage[acc_row(r, lane) * EL + j * 32 + cl] = acc.t[i][j][r];
+        acc_stage_half<NJ>(acc, i, stage, lane);
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 4 * NJ; ++it) {
