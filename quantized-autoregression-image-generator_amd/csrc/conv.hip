@@ -196,6 +196,61 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_mma_kernel(SrcKContig sa, Co
     }
 }
 
+// ConvTranspose2d(4,2,1) forward, both column-parity classes of one row parity in one workgroup:
+// the same 128 x 128 (channels x logical pixels) tile is contracted twice -- class px = 0 with
+// its packed weights and tap offset, then px = 1 -- into two accumulator sets, and the epilogue
+// stores the pair (2b, 2b+1) of output columns as one 8-B value per lane: 256 contiguous bytes
+// per 32 lanes.  One class per launch writes 4 B at an 8-B stride instead (every line of the
+// output visited by two launches, half used each time): 61.8 TF on the 512 -> 256 layer.
+template <class SB, bool FAST>
+__global__ __launch_bounds__(NTHREADS, 2) void convt_pair_kernel(SrcKContig sa, ConvGeom g, ConvOut o,
+                                                                 int tiles_p, int64_t class_stride) {
+    __shared__ __attribute__((aligned(16))) float lds[GEMM_LDS_FLOATS];
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tc = tile / tiles_p, tp = tile - tc * tiles_p;
+    const int c0 = tc * BM, p0 = tp * BN;
+    const int py = blockIdx.y;               // row parity: both in one launch (twice the workgroups)
+    g.oy0 = py;                              // tap th reads input row a + py - th
+    o.py = py;
+    Acc acc[2];
+#pragma unroll
+    for (int px = 0; px < 2; ++px) {
+        SB sb;
+        sb.g = g;
+        sb.g.ox0 = px;                       // tap tw reads input column b + px - tw
+        sb.init(p0, threadIdx.x);
+        SrcKContig sw = sa;
+        sw.p = sa.p + (py * 2 + px) * class_stride;
+        acc_zero(acc[px]);
+        contract_loop<FAST>(acc[px], sw, sb, c0, p0, 0, g.K, lds);
+        __syncthreads();                     // the tiles of this class are done with the LDS
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, cl = lane & 31;
+    const int per = g.Ho * g.Wo;
+    const int64_t plane = (int64_t)o.HoP * o.WoP;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = p0 + wn * 64 + j * 32 + cl;
+        if (p >= g.P) continue;
+        const int n = p / per, rem = p - n * per;
+        const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+        const int64_t pix = (int64_t)(oy * 2 + o.py) * o.WoP + ox * 2;     // even: 8-B aligned
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = c0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if (co >= o.Cout) continue;
+                float t0 = acc[0].t[i][j][r], t1 = acc[1].t[i][j][r];
+                if (o.bias) { const float bv = o.bias[co]; t0 += bv; t1 += bv; }
+                const int64_t idx = ((int64_t)n * o.Cout + co) * plane + pix;
+                if (o.preact) *reinterpret_cast<float2*>(o.preact + idx) = make_float2(t0, t1);
+                *reinterpret_cast<float2*>(o.y + idx) = make_float2(act_fwd(t0, o.act), act_fwd(t1, o.act));
+            }
+    }
+}
+
 // Direct kernel for very few output channels (COUT <= 8): lane per logical pixel.
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvGeom g, const float* __restrict__ w,
@@ -696,6 +751,38 @@ extern "C" int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H,
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(convt_pack_kernel, dim3(blocks), dim3(256), 0, st, w, Cin, Cout, packed);
     QARIG_CHECK_LAUNCH("conv_transpose2d pack");
+    // both column parities per launch (8-B stores) where the MFMA kernel applies and y / preact
+    // rows are 8-B aligned; QARIG_CONVT_PAIR=0 restores one class per launch
+    static const bool pair_on = []() { const char* e = getenv("QARIG_CONVT_PAIR"); return !(e && e[0] == '0'); }();
+    // ... and where one class per launch would leave the chip half empty (< 512 workgroups per class:
+    // the 512 -> 256 layer at 16 images ran 61.7 TF that way, 88.4 TF paired; at 32 images one class
+    // per launch is the faster form, 94.6 against 90.9 TF for the whole decoder)
+    const long class_wgs = (long)((Cout + BM - 1) / BM) * (((long)N * H * W + BN - 1) / BN);
+    const bool pair = pair_on && Cout > 8 && class_wgs < 512 && (((uintptr_t)y | (uintptr_t)preact) & 7) == 0;
+    if (pair) {
+        const int K = Cin * 4, P = N * H * W;
+        const int tiles_c = (Cout + BM - 1) / BM, tiles_p = (P + BN - 1) / BN;
+        const dim3 grid(tiles_c * tiles_p, 2), block(NTHREADS);      // y = row parity
+        {
+            ConvGeom g{x, N, Cin, H, W, H, W, 1, 2, 2, 0, -1, 0, -1, K, P};
+            ConvOut o{y, preact, bias, Cout, 2 * H, 2 * W, 2, 0, 0, act};
+            const float* wmat = packed;
+            SrcKContig sa{wmat, (int64_t)K, Cout, K, 1.0f, (((uintptr_t)wmat & 15) == 0) && K % 4 == 0};
+            const bool rowvec = W % 4 == 0 && K < 65536;
+            const bool fast = sa.vec4 && Cout % BM == 0 && K % BK == 0 && P % BN == 0;
+            const int64_t cs = (int64_t)Cout * K;
+            if (rowvec && fast)
+                hipLaunchKernelGGL((convt_pair_kernel<SrcIm2colRow, true>), grid, block, 0, st, sa, g, o, tiles_p, cs);
+            else if (rowvec)
+                hipLaunchKernelGGL((convt_pair_kernel<SrcIm2colRow, false>), grid, block, 0, st, sa, g, o, tiles_p, cs);
+            else if (fast)
+                hipLaunchKernelGGL((convt_pair_kernel<SrcIm2col, true>), grid, block, 0, st, sa, g, o, tiles_p, cs);
+            else
+                hipLaunchKernelGGL((convt_pair_kernel<SrcIm2col, false>), grid, block, 0, st, sa, g, o, tiles_p, cs);
+            QARIG_CHECK_LAUNCH("conv_transpose2d pair");
+        }
+        return QARIG_OK;
+    }
     for (int cls = 0; cls < 4; ++cls) {
         const int py = cls >> 1, px = cls & 1;
         // oy = 2a+py: tap th uses kh = 1-py+2th and input row a + (py + 1 - kh)/2 = a + py - th
