@@ -11,3 +11,7 @@ for e in QARIG_LP_BIG=0 QARIG_LP_MFMA16=0 "QARIG_LP_BIG=1 QARIG_LP_MFMA16=0" "QA
     echo "== $e"
     env $e timeout -k 10 300 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_fp8.py -x -q 2>&1 | tail -1
 done
+for e in QARIG_CONVT_PAIR=0 QARIG_CONVT_PAIR=1; do
+    echo "== $e"
+    env $e timeout -k 10 300 python -m pytest tests/test_gpu_conv.py -x -q 2>&1 | tail -1
+done
