@@ -159,6 +159,11 @@ int qarig_gather_rows(const int64_t* ids, int64_t R, int D, int K, const float* 
 int qarig_som_weights_fwd(const int64_t* bmu, int64_t R, int K, float two_var, float* g,
                           void* stream);
 
+/* The same neighbourhood without the (R,K) matrix: out[j] = sum_{|j-b| <= reach} exp(-(j-b)^2 / two_var) in[b]
+ * over a (K,D) table.  models/Codebook.py:112-130's product equals gather_rows(bmu, band(codebook)) and its
+ * codebook gradient band(embedding_bwd(bmu, dq)); `reach` bounds the dropped weights (host: < 2^-40). */
+int qarig_som_band(const float* in, int K, int D, float two_var, int reach, float* out, void* stream);
+
 /* counts (int64 [K]) += histogram of ids -- the per-unit BMU usage count of
  * prune_codebook.py:129-142. */
 int qarig_index_histogram(const int64_t* ids, int64_t n, int K, int64_t* counts, int* bad_flag,

@@ -80,6 +80,28 @@ __global__ void som_weights_kernel(const int64_t* __restrict__ bmu, int64_t R, i
     }
 }
 
+// out[j][:] = sum over b in [j - reach, j + reach] of exp(-(j-b)^2 / two_var) * in[b][:], b ascending.
+// The Gaussian neighbourhood of models/Codebook.py:112-130 depends on the row only through its BMU,
+// so (R,K) weights @ (K,D) codebook == gather of this (K,D) table at the BMUs, and its transpose
+// product == this band over the per-code sums of the incoming gradient: R*K*D flops and an R x K
+// matrix become K*(2 reach + 1)*D flops and two K x D tables.  Weights use the expression of
+// som_weights_kernel; terms beyond `reach` are below 2^-40 of the centre weight (host picks it).
+__global__ __launch_bounds__(256) void som_band_kernel(const float* __restrict__ in, int K, int D,
+                                                       float two_var, int reach, float* __restrict__ out) {
+    const int64_t total = (int64_t)K * D;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx / D), c = (int)(idx - (int64_t)j * D);
+        const int lo = j - reach < 0 ? 0 : j - reach, hi = j + reach > K - 1 ? K - 1 : j + reach;
+        float acc = 0.0f;
+        for (int b = lo; b <= hi; ++b) {
+            const int64_t d = j - b;
+            acc = fmaf(expf(-((float)(d * d) / two_var)), in[(int64_t)b * D + c], acc);
+        }
+        out[idx] = acc;
+    }
+}
+
 // counts[id] += 1 over a stream of BMU indices (prune_codebook.py:129-142 keeps a Python
 // dict; here a device histogram).  Integer atomics: exact and order-independent.
 __global__ void histogram_kernel(const int64_t* __restrict__ ids, int64_t n, int K,
@@ -168,6 +190,19 @@ extern "C" int qarig_som_weights_fwd(const int64_t* bmu, int64_t R, int K, float
     hipLaunchKernelGGL(som_weights_kernel, cb_grid(R * K), dim3(256), 0, (hipStream_t)stream, bmu, R,
                        K, two_var, g);
     QARIG_CHECK_LAUNCH("som_weights");
+    return QARIG_OK;
+}
+
+// The Gaussian neighbourhood applied to a (K,D) table along the code axis (see som_band_kernel):
+// forward quantised rows = gather_rows(bmu, band(codebook)); codebook gradient = band(embedding_bwd(bmu, dq)).
+extern "C" int qarig_som_band(const float* in, int K, int D, float two_var, int reach, float* out,
+                              void* stream) {
+    QARIG_CHECK_ARG(in && out && in != out && K > 0 && D > 0 && two_var > 0 && reach >= 0,
+                    "som_band: bad arguments");
+    QARIG_CHECK_DIMS("som_band", K, D);
+    hipLaunchKernelGGL(som_band_kernel, cb_grid((int64_t)K * D), dim3(256), 0, (hipStream_t)stream, in, K,
+                       D, two_var, reach, out);
+    QARIG_CHECK_LAUNCH("som_band");
     return QARIG_OK;
 }
 

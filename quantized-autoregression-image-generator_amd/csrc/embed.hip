@@ -93,6 +93,58 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __res
     }
 }
 
+// Narrow tables (D <= 64: codebook rows): one workgroup per CPW consecutive table rows, its four
+// waves scan one quarter of the id stream each -- 8 x 64 ids in flight per wave, every 64 ids
+// answer CPW ballots -- and the four partial sums are added in stream order (fixed: deterministic).
+template <int CPW>
+__global__ __launch_bounds__(256) void embedding_bwd_narrow_kernel(const int64_t* __restrict__ ids, int M,
+                                                                   int D, int V,
+                                                                   const float* __restrict__ dy,
+                                                                   float* __restrict__ dtable) {
+    __shared__ float part[4][CPW][64];
+    const int v0 = blockIdx.x * CPW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // quarters in units of 64 ids
+    const int groups = (M + 63) / 64;
+    const int g_per = (groups + 3) / 4;
+    const int g_begin = wave * g_per, g_end = min(groups, g_begin + g_per);
+    float acc[CPW];
+#pragma unroll
+    for (int s = 0; s < CPW; ++s) acc[s] = 0.0f;
+    constexpr int U = 8;
+    for (int g0 = g_begin; g0 < g_end; g0 += U) {
+        int64_t id[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = (g0 + u) * 64 + lane;
+            id[u] = (g0 + u < g_end && m < M) ? ids[m] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rel = (int)(id[u] - v0);      // ids outside the table never match (v0 + s < V)
+            const bool mine = id[u] >= v0 && id[u] < v0 + CPW;
+            if (!__any(mine)) continue;
+#pragma unroll
+            for (int s = 0; s < CPW; ++s) {
+                unsigned long long hit = __ballot(mine && rel == s);
+                while (hit) {
+                    const int b = __ffsll((long long)hit) - 1;
+                    hit &= hit - 1;
+                    if (lane < D) acc[s] += dy[(int64_t)((g0 + u) * 64 + b) * D + lane];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < CPW; ++s) part[wave][s][lane] = acc[s];
+    __syncthreads();
+    for (int i = threadIdx.x; i < CPW * 64; i += 256) {
+        const int s = i >> 6, c = i & 63;
+        if (c < D && v0 + s < V)
+            dtable[(int64_t)(v0 + s) * D + c] = ((part[0][s][c] + part[1][s][c]) + part[2][s][c]) + part[3][s][c];
+    }
+}
+
 }  // namespace qarig
 
 using namespace qarig;
@@ -135,8 +187,15 @@ extern "C" int qarig_embedding_bwd(const int64_t* ids, int M, int D, int V, cons
     QARIG_CHECK_ARG(ids && dy && dtable && M > 0 && D > 0 && V > 0, "embedding_bwd: bad arguments");
     QARIG_CHECK_DIMS("embedding_bwd", M, D);
     QARIG_CHECK_DIMS("embedding_bwd", V, D);
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, M, D,
-                       dy, dtable);
+    if (D <= 64 && V >= 4096)
+        hipLaunchKernelGGL(embedding_bwd_narrow_kernel<8>, dim3((V + 7) / 8), dim3(256), 0, (hipStream_t)stream,
+                           ids, M, D, V, dy, dtable);
+    else if (D <= 64)
+        hipLaunchKernelGGL(embedding_bwd_narrow_kernel<1>, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, M,
+                           D, V, dy, dtable);
+    else
+        hipLaunchKernelGGL(embedding_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, M, D,
+                           dy, dtable);
     QARIG_CHECK_LAUNCH("embedding_bwd");
     return QARIG_OK;
 }

@@ -11,23 +11,41 @@ from qarig import ops
 from ._loading import load_matching
 
 
+def _som_dense():
+    """QARIG_SOM_DENSE=1: the reference's literal form, an (rows x K) weight matrix through the GEMM."""
+    import os
+    return os.environ.get("QARIG_SOM_DENSE", "0") == "1"
+
+
 class _SomQuantize(torch.autograd.Function):
-    """quant = g @ W with g the (constant) Gaussian index-neighbourhood weights;
-    gradient reaches the codebook only (reference Codebook.py:112-130)."""
+    """quant = g @ W with g the (constant) Gaussian index-neighbourhood weights; gradient reaches
+    the codebook only (reference Codebook.py:112-130).  g[r][j] depends on r only through bmu[r]:
+    quant = band(W)[bmu] and dW = band(per-code sums of dq), band = the Gaussian along the code axis
+    over the indices whose weight is >= 2^-40 (csrc/codebook.hip som_band_kernel) -- no (rows x K) matrix."""
 
     @staticmethod
     def forward(ctx, weight, bmu, two_var):
-        g = ops.som_weights(bmu, weight.shape[0], two_var)
-        ctx.save_for_backward(g)
-        return ops.gemm(g, weight, a_kcontig=True, b_kcontig=False)
+        ctx.two_var = two_var
+        if _som_dense():
+            g = ops.som_weights(bmu, weight.shape[0], two_var)
+            ctx.save_for_backward(g)
+            ctx.dense = True
+            return ops.gemm(g, weight, a_kcontig=True, b_kcontig=False)
+        ctx.dense = False
+        ctx.K = weight.shape[0]
+        ctx.save_for_backward(bmu)
+        return ops.gather_rows(bmu, ops.som_band(weight.detach(), two_var))
 
     @staticmethod
     def backward(ctx, dq):
-        (g,) = ctx.saved_tensors
         dq = dq.contiguous()
-        R, K = g.shape
-        return ops.gemm(g, dq, a_kcontig=False, b_kcontig=False,
-                        splitk=ops.pick_splitk(K, dq.shape[1], R)), None, None
+        if ctx.dense:
+            (g,) = ctx.saved_tensors
+            R, K = g.shape
+            return ops.gemm(g, dq, a_kcontig=False, b_kcontig=False,
+                            splitk=ops.pick_splitk(K, dq.shape[1], R)), None, None
+        (bmu,) = ctx.saved_tensors
+        return ops.som_band(ops.embedding_bwd(bmu, dq, ctx.K), ctx.two_var), None, None
 
 
 class _HardQuantize(torch.autograd.Function):

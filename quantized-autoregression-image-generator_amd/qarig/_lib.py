@@ -48,6 +48,7 @@ SIGNATURES = {
     "qarig_codebook_gather_image": (I, [P, I, I, I, I, I, I, P, I, P, P, P]),
     "qarig_gather_rows": (I, [P, L, I, I, P, P, P, P]),
     "qarig_som_weights_fwd": (I, [P, L, I, F, P, P]),
+    "qarig_som_band": (I, [P, I, I, F, I, P, P]),
     "qarig_index_histogram": (I, [P, L, I, P, P, P]),
     "qarig_posemb_fwd": (I, [P, I, I, P, P, P]),
     "qarig_assemble_tokens": (I, [P, I, P, I, I, I, I, I, P, I, P, P, P, P]),

@@ -489,6 +489,25 @@ def som_weights(bmu_idx, K, two_var):
     return g
 
 
+def som_reach(two_var):
+    """Index distance beyond which exp(-d^2 / two_var) < 2^-40: what som_band drops."""
+    import math
+    return int(math.ceil(math.sqrt(40.0 * math.log(2.0) * float(two_var))))
+
+
+def som_band(table, two_var, reach=None):
+    """out[j] = sum_{|j-b| <= reach} exp(-(j-b)^2 / two_var) table[b] (reference Codebook.py:112-130
+    folded onto the code axis: see csrc/codebook.hip som_band_kernel)."""
+    require_cuda(table)
+    table = f32c(table)
+    K, D = table.shape
+    out = torch.empty_like(table)
+    reach = som_reach(two_var) if reach is None else int(reach)
+    check(_lib.load().qarig_som_band(ptr(table), K, D, float(two_var), min(reach, K), ptr(out), stream()),
+          "qarig_som_band")
+    return out
+
+
 # ------------------------------------------------------------------- transformer
 _freq_cache = {}
 

@@ -71,3 +71,58 @@ def test_gather_out_of_range_is_reported():
     cb.get_quantized_image(bad.cuda())
     with pytest.raises(IndexError):
         ops.check_index_flag(torch.device("cuda", 0), "gather")
+
+
+@pytest.mark.parametrize("K,D,R,rng", [(512, 16, 8192, 256), (512, 16, 4099, 1.0), (512, 4, 2048, 37),
+                                       (8192, 4, 32768, 4096), (48, 16, 100, 4), (7, 3, 5, 256)])
+def test_som_quantise_band_form_vs_fp64_and_dense(K, D, R, rng, monkeypatch):
+    """The Gaussian neighbourhood as a band over the code axis (no rows x K matrix): forward rows and
+    the codebook gradient against an fp64 evaluation of the reference expression
+    (Codebook.py:112-130) over ALL K codes, and against the literal matrix form (QARIG_SOM_DENSE=1).
+    Dropped weights are < 2^-40 of the centre weight: the bound is the fp32 summation's own."""
+    import math
+
+    from models.Codebook import _SomQuantize
+    from qarig import ops
+    g = torch.Generator().manual_seed(K + D + R)
+    w = ((torch.rand((K, D), generator=g) * 2 - 1) / K).cuda()
+    bmu = torch.randint(0, K, (R,), generator=g).cuda()
+    bmu[0], bmu[-1] = 0, K - 1          # both clipped ends of the band
+    dq = torch.randn((R, D), generator=g).cuda()
+    two_var = 2 * -(rng / (2 * math.log(0.1)))
+    assert ops.som_reach(two_var) ** 2 / two_var >= 40 * math.log(2)
+
+    def run():
+        wl = w.clone().requires_grad_(True)
+        q = _SomQuantize.apply(wl, bmu, two_var)
+        (q * dq).sum().backward()
+        return q.detach(), wl.grad
+
+    q, dw = run()
+    j = torch.arange(K, dtype=torch.float64)
+    # the reference's weights are fp32 values (int64 squared / python float -> fp32, exp in fp32)
+    d2 = ((j[None, :] - bmu.cpu().double()[:, None]) ** 2).float()
+    gw = torch.exp(-(d2 / two_var)).double()
+    assert rel_err(q, gw @ w.cpu().double()) < 2e-6
+    assert grad_err(dw, gw.t() @ dq.cpu().double()) < 1e-5
+    if R * K <= (1 << 24):
+        monkeypatch.setenv("QARIG_SOM_DENSE", "1")
+        qd, dwd = run()
+        assert rel_err(q, qd) < 2e-6 and grad_err(dw, dwd) < 1e-5
+
+
+@pytest.mark.parametrize("V,D,M", [(48, 16, 100), (512, 16, 65536), (512, 64, 1000), (4099, 4, 32768 + 17),
+                                   (8192, 4, 63), (1024, 3, 64 * 32 + 1)])
+def test_embedding_bwd_narrow_tables(V, D, M):
+    """Per-code sums of gradient rows (nn.Embedding backward, Codebook.py:132; the band form's
+    gradient) on the narrow-table kernel: vs an fp64 index_add, and deterministic."""
+    from qarig import ops
+    g = torch.Generator().manual_seed(V + D + M)
+    ids = torch.randint(0, V, (M,), generator=g)
+    ids[0], ids[-1] = V - 1, 0
+    dy = torch.randn((M, D), generator=g)
+    want = torch.zeros((V, D), dtype=torch.float64).index_add_(0, ids, dy.double())
+    a = ops.embedding_bwd(ids.cuda(), dy.cuda(), V)
+    assert grad_err(a, want) < 2e-6
+    assert torch.equal(a, ops.embedding_bwd(ids.cuda(), dy.cuda(), V))
+    assert torch.equal(a[want.abs().sum(1) == 0].cpu(), torch.zeros_like(a[want.abs().sum(1) == 0].cpu()))
