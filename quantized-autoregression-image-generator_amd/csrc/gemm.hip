@@ -302,13 +302,166 @@ __device__ __forceinline__ void frags_mma(Acc& acc, const Frags8& f) {
     }
 }
 
+// The fp32 MFMA and the vector ALU do not overlap on this chip, so every address
+// computation inside the k-loop is paid in full.  The loop below is unrolled over the 4 = lcm(2
+// register sets, 4 stages) tiles of a period: every LDS address is (per-lane base VGPR, computed
+// once) + an instruction immediate, every global address (uniform base advanced on the scalar
+// unit) + (per-lane 32-bit offset, computed once).
+struct FragBase {
+    unsigned a0, a1, b0, b1;   // KC: the two 16-B chunks of this lane's row; XC: sub-tiles 0 and 1
+};
+template <int OFF>
+__device__ __forceinline__ void rd_kc(unsigned c0, unsigned c1, f32x4& lo, f32x4& hi) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lo) : "v"(c0), "n"(OFF));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(hi) : "v"(c1), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void rd_xc(unsigned base, f32x4& lo, f32x4& hi) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    static_assert(OFF % 256 == 0 && OFF / 256 + 14 < 256, "ds_read2st64 offsets are 8-bit units of 256 B");
+    constexpr int U = OFF / 256;
+    f32x2 p0, p1, p2, p3;
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(p0) : "v"(base), "n"(U), "n"(U + 2));
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(p1) : "v"(base), "n"(U + 4), "n"(U + 6));
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(p2) : "v"(base), "n"(U + 8), "n"(U + 10));
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(p3) : "v"(base), "n"(U + 12), "n"(U + 14));
+    lo = f32x4{p0.x, p0.y, p1.x, p1.y};
+    hi = f32x4{p2.x, p2.y, p3.x, p3.y};
+}
+template <bool AKC, bool BKC, int S>
+__device__ __forceinline__ void frags_read_s(Frags8& f, const FragBase& fb) {
+    constexpr int OA = S * DMA_STAGE_FLOATS * 4, OB = OA + DMA_OP_FLOATS * 4;
+    if (AKC) rd_kc<OA>(fb.a0, fb.a1, f.a0l, f.a0h); else rd_xc<OA>(fb.a0, f.a0l, f.a0h);
+    if (BKC) rd_kc<OB>(fb.b0, fb.b1, f.b0l, f.b0h); else rd_xc<OB>(fb.b0, f.b0l, f.b0h);
+    if (AKC) rd_kc<OA + 32 * 64>(fb.a0, fb.a1, f.a1l, f.a1h); else rd_xc<OA>(fb.a1, f.a1l, f.a1h);
+    if (BKC) rd_kc<OB + 32 * 64>(fb.b0, fb.b1, f.b1l, f.b1h); else rd_xc<OB>(fb.b1, f.b1l, f.b1h);
+}
+template <bool KC>
+__device__ __forceinline__ void frag_bases(const float* lds, int wq, int x, int h, unsigned& p0, unsigned& p1) {
+    if (KC) {
+        const int row = wq * 64 + x, sw = (row >> 2) & 3;
+        const unsigned base = lds_addr(lds + row * 16);
+        p0 = base + (((2 * h) ^ sw) << 4);
+        p1 = base + (((2 * h + 1) ^ sw) << 4);
+    } else {
+        p0 = lds_addr(lds + (8 * h) * 128 + wq * 64 + x);
+        p1 = p0 + 32 * 4;
+    }
+}
+// per-lane byte offset of DMA instruction q (of 8) of an operand tile from the tile's first element
+template <bool KC>
+__device__ __forceinline__ unsigned dma_lane_off(int64_t ld, int q, int lane) {
+    if (KC) {
+        const int r = 16 * q + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 2) & 3);
+        return (unsigned)((r * ld + 4 * c) * 4);
+    }
+    const int k = 2 * q + (lane >> 5);
+    return (unsigned)((k * ld + (lane & 31) * 4) * 4);
+}
+
+// One LDS-DMA instruction in its (scalar base + 32-bit lane offset) form: the k advance of the
+// base stays on the scalar unit.  (The builtin takes a 64-bit vector address: one 64-bit vector add
+// per instruction.)  M0 = LDS destination of lane 0; s_nop: the M0-write -> LDS-DMA wait state.
+// M0 is not declared clobbered (a reserved register): nothing else in these kernels lives in it.
+__device__ __forceinline__ void dma16_saddr(const char* base, unsigned lane_off, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(lane_off), "s"(base), "s"(lds_dst) : "memory");
+}
+
+constexpr int PF_STAGES = 4;
+// The k-loop of the prefetch kernels: tiles [0, nk) of BK from k_begin, of the 128 x 128 block at
+// (m0, n0), through the 4-stage ring at `lds` (64 KB); `tt` = thread index among the ring's 256.
+// Contains workgroup barriers: every wave of the workgroup runs it with the same nk.
+template <bool AKC, bool BKC>
+__device__ __forceinline__ void pf_ring(Acc& acc, float& rs, const bool do_rs, float* lds,
+                                        const float* __restrict__ A, int64_t lda,
+                                        const float* __restrict__ B, int64_t ldb, int m0, int n0,
+                                        int k_begin, int nk, int wave, int lane, int tt) {
+    const int wm = wave >> 1, wn = wave & 1;
+    const int x = lane & 31, h = lane >> 5;
+    const int last = k_begin + (nk - 1) * BK;
+    // uniform tile origins; the k advance is k (KC) or k * ld (XC) elements
+    const float* a_org = AKC ? A + (int64_t)m0 * lda : A + m0;
+    const float* b_org = BKC ? B + (int64_t)n0 * ldb : B + n0;
+    const unsigned oa0 = dma_lane_off<AKC>(lda, wave * 2, lane), oa1 = dma_lane_off<AKC>(lda, wave * 2 + 1, lane);
+    const unsigned ob0 = dma_lane_off<BKC>(ldb, wave * 2, lane), ob1 = dma_lane_off<BKC>(ldb, wave * 2 + 1, lane);
+    const unsigned my_dma_addr = __builtin_amdgcn_readfirstlane(lds_addr(lds + wave * 512));   // this wave's two 1-KB slots
+    auto issue = [&](int t, int stage) {             // DMA of tile t (clamped: a harmless re-load past the end)
+        const int k = min(k_begin + t * BK, last);
+        const char* ak = reinterpret_cast<const char*>(AKC ? a_org + k : a_org + (int64_t)k * lda);
+        const char* bk = reinterpret_cast<const char*>(BKC ? b_org + k : b_org + (int64_t)k * ldb);
+        const unsigned dst = my_dma_addr + stage * (DMA_STAGE_FLOATS * 4);
+        dma16_saddr(ak, oa0, dst);
+        dma16_saddr(ak, oa1, dst + 1024);
+        dma16_saddr(bk, ob0, dst + DMA_OP_FLOATS * 4);
+        dma16_saddr(bk, ob1, dst + DMA_OP_FLOATS * 4 + 1024);
+    };
+    // sum_k A(m0 + tid, k) of the tile in stage S, k ascending (A is [k][x] here)
+    const unsigned rs_base = lds_addr(lds + tt);
+#define QARIG_PF_ROWSUM(S)                                                                         \
+    {                                                                                              \
+        f32x4 r0, r1, r2, r3;                                                                      \
+        rd_xc<(S) * DMA_STAGE_FLOATS * 4>(rs_base, r0, r1);                                        \
+        rd_xc<(S) * DMA_STAGE_FLOATS * 4 + 8 * 128 * 4>(rs_base, r2, r3);                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) rs += r0[q];                                 \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) rs += r1[q];                                 \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) rs += r2[q];                                 \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) rs += r3[q];                                 \
+    }
+    if (nk > 0) {
+        FragBase fb;
+        frag_bases<AKC>(lds, wm, x, h, fb.a0, fb.a1);
+        frag_bases<BKC>(lds, wn, x, h, fb.b0, fb.b1);
+        issue(0, 0);
+        issue(1, 1);
+        issue(2, 2);
+        issue(3, 3);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // tile 0 landed (1, 2, 3 in flight)
+        __builtin_amdgcn_s_barrier();
+        Frags8 P, Q;
+        frags_read_s<AKC, BKC, 0>(P, fb);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_rs) QARIG_PF_ROWSUM(0)
+        int t = 0;
+        // body for tile t (stage S = t % 4) with its fragments in CUR; leaves tile t+1's in NXT
+#define QARIG_PF_BODY(CUR, NXT, S)                                                                \
+        {                                                                                         \
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   /* tile t+1 landed; t+2, t+3 in flight */ \
+            __builtin_amdgcn_s_barrier();      /* ... for everyone; all reads of tile t retired */  \
+            issue(t + 4, S);                   /* into the stage tile t has just vacated */        \
+            frags_read_s<AKC, BKC, (S + 1) % 4>(NXT, fb);                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            frags_mma(acc, CUR);                                                                  \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            if (do_rs && t + 1 < nk) QARIG_PF_ROWSUM((S + 1) % 4)                                 \
+            ++t;                                                                                  \
+        }
+        while (t + 4 <= nk) {
+            QARIG_PF_BODY(P, Q, 0)
+            QARIG_PF_BODY(Q, P, 1)
+            QARIG_PF_BODY(P, Q, 2)
+            QARIG_PF_BODY(Q, P, 3)
+        }
+        if (t < nk) QARIG_PF_BODY(P, Q, 0)
+        if (t < nk) QARIG_PF_BODY(Q, P, 1)
+        if (t < nk) QARIG_PF_BODY(P, Q, 2)
+#undef QARIG_PF_BODY
+#undef QARIG_PF_ROWSUM
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_pf_kernel(const float* __restrict__ A, int64_t lda,
                                                                   const float* __restrict__ B, int64_t ldb,
                                                                   GemmEpilogue ep, int M, int N, int K,
                                                                   int tiles_n, int splitk, float* slabs) {
-    constexpr int ST = 3;
-    __shared__ __attribute__((aligned(16))) float lds[ST * DMA_STAGE_FLOATS];   // 48 KB
+    __shared__ __attribute__((aligned(16))) float lds[PF_STAGES * DMA_STAGE_FLOATS];   // 64 KB: two workgroups per CU
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -321,72 +474,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_pf_kernel(const float* _
     const int nk = (k_end - k_begin) / BK;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int x = lane & 31, h = lane >> 5;
-    const int last = k_begin + (nk - 1) * BK;
 
     Acc acc;
     acc_zero(acc);
     float rs = 0.0f;
     const bool do_rs = !AKC && ep.rowsum != nullptr && tn == 0 && tid < 128;
-    auto stage_of = [](int t) { return t % ST; };
-    auto issue = [&](int t) {            // DMA of tile t (clamped: a harmless re-load past the end)
-        const int k = min(k_begin + t * BK, last);
-        float* dst = lds + stage_of(t) * DMA_STAGE_FLOATS;
-        dma_tile<AKC>(A, lda, m0, k, dst, wave, lane);
-        dma_tile<BKC>(B, ldb, n0, k, dst + DMA_OP_FLOATS, wave, lane);
-    };
-    auto rowsum_tile = [&](int t) {      // sum_k A(m0 + tid, k) of tile t, k ascending
-        f32x4 r0, r1, r2, r3;
-        const float* ta = lds + stage_of(t) * DMA_STAGE_FLOATS;
-        frag_read<false>(ta, tid, 0, r0, r1);
-        frag_read<false>(ta, tid, 1, r2, r3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rs += r0[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rs += r1[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rs += r2[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rs += r3[q];
-    };
-    if (nk > 0) {
-        issue(0);
-        issue(1);
-        issue(2);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // tile 0 landed (1, 2 in flight)
-        __builtin_amdgcn_s_barrier();
-        Frags8 P, Q;
-        frags_read<AKC, BKC>(P, lds, lds + DMA_OP_FLOATS, wm, wn, x, h);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (do_rs) rowsum_tile(0);
-        int t = 0;
-        // body for tile t with its fragments in CUR; leaves tile t+1's in NXT
-#define QARIG_PF_BODY(CUR, NXT)                                                                   \
-        {                                                                                         \
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   /* tile t+1 landed, t+2 in flight */ \
-            __builtin_amdgcn_s_barrier();      /* ... for everyone; all reads of tile t retired */  \
-            issue(t + 3);                      /* into the stage tile t has just vacated */        \
-            const float* na = lds + stage_of(t + 1) * DMA_STAGE_FLOATS;                           \
-            frags_read<AKC, BKC>(NXT, na, na + DMA_OP_FLOATS, wm, wn, x, h);                      \
-            __builtin_amdgcn_sched_barrier(0);                                                    \
-            frags_mma(acc, CUR);                                                                  \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                    \
-            __builtin_amdgcn_sched_barrier(0);                                                    \
-            if (do_rs && t + 1 < nk) rowsum_tile(t + 1);                                          \
-            ++t;                                                                                  \
-        }
-        while (t + 2 <= nk) {
-            QARIG_PF_BODY(P, Q)
-            QARIG_PF_BODY(Q, P)
-        }
-        if (t < nk) QARIG_PF_BODY(P, Q)
-#undef QARIG_PF_BODY
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    pf_ring<AKC, BKC>(acc, rs, do_rs, lds, A, lda, B, ldb, m0, n0, k_begin, nk, wave, lane, tid);
     if (do_rs) ep.rowsum[(int64_t)blockIdx.z * M + m0 + tid] = rs;
     __syncthreads();                      // ring no longer in use: the epilogue stages through it
     gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, slabs);
@@ -398,7 +491,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_pf_kernel(const float* _
 // 128x128 tiles or fewer the kernels above leave one wave per SIMD, and a lone wave exposes
 // every barrier and DMA wait.  Here a workgroup is 8 waves = two 4-wave teams on the SAME tile:
 // team 0 reduces the first half of the block's k-range, team 1 the second, each through its own
-// 3-stage ring (96 KB of LDS), so every SIMD holds two waves at different points of the k-loop
+// 4-stage ring (128 KB of LDS), so every SIMD holds two waves at different points of the k-loop
 // without a second slab in HBM.  At the end the teams swap halves of their accumulators through
 // LDS: wave (team h, tile position w) keeps the 32-row half h of its 64x64 tile, adds its
 // partner's partial (low-k + high-k, a fixed order) and runs the epilogue on those 32 rows.
@@ -407,9 +500,8 @@ __global__ __launch_bounds__(2 * NTHREADS, 1) void gemm_dma_pf2_kernel(const flo
                                                                        const float* __restrict__ B, int64_t ldb,
                                                                        GemmEpilogue ep, int M, int N, int K,
                                                                        int tiles_n, int splitk, float* slabs) {
-    constexpr int ST = 3;
-    constexpr int RING = ST * DMA_STAGE_FLOATS;                      // 48 KB per team
-    extern __shared__ __attribute__((aligned(16))) float lds2[];    // 2 rings = 96 KB
+    constexpr int RING = PF_STAGES * DMA_STAGE_FLOATS;               // 64 KB per team
+    extern __shared__ __attribute__((aligned(16))) float lds2[];    // 2 rings = 128 KB
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -425,73 +517,14 @@ __global__ __launch_bounds__(2 * NTHREADS, 1) void gemm_dma_pf2_kernel(const flo
     const int tt = tid & 255;                                        // thread index inside the team
     const int nk = (k_end - k_begin) / BK / 2;                       // k-tiles per team (host: even split)
     k_begin += team * nk * BK;
-    float* lds = lds2 + team * RING;
     const int wm = wave >> 1, wn = wave & 1;
-    const int x = lane & 31, h = lane >> 5;
-    const int last = k_begin + (nk - 1) * BK;
 
     Acc acc;
     acc_zero(acc);
     float rs = 0.0f;
     const bool do_rs = !AKC && ep.rowsum != nullptr && tn == 0 && tt < 128;
-    auto stage_of = [](int t) { return t % ST; };
-    auto issue = [&](int t) {
-        const int k = min(k_begin + t * BK, last);
-        float* dst = lds + stage_of(t) * DMA_STAGE_FLOATS;
-        dma_tile<AKC>(A, lda, m0, k, dst, wave, lane);
-        dma_tile<BKC>(B, ldb, n0, k, dst + DMA_OP_FLOATS, wave, lane);
-    };
-    auto rowsum_tile = [&](int t) {
-        f32x4 r0, r1, r2, r3;
-        const float* ta = lds + stage_of(t) * DMA_STAGE_FLOATS;
-        frag_read<false>(ta, tt, 0, r0, r1);
-        frag_read<false>(ta, tt, 1, r2, r3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rs += r0[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rs += r1[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rs += r2[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rs += r3[q];
-    };
-    // both teams run the same number of k-tiles, so the workgroup-wide barriers pair up
-    {
-        issue(0);
-        issue(1);
-        issue(2);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        Frags8 P, Q;
-        frags_read<AKC, BKC>(P, lds, lds + DMA_OP_FLOATS, wm, wn, x, h);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (do_rs) rowsum_tile(0);
-        int t = 0;
-#define QARIG_PF_BODY(CUR, NXT)                                                                   \
-        {                                                                                         \
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                      \
-            __builtin_amdgcn_s_barrier();                                                         \
-            issue(t + 3);                                                                         \
-            const float* na = lds + stage_of(t + 1) * DMA_STAGE_FLOATS;                           \
-            frags_read<AKC, BKC>(NXT, na, na + DMA_OP_FLOATS, wm, wn, x, h);                      \
-            __builtin_amdgcn_sched_barrier(0);                                                    \
-            frags_mma(acc, CUR);                                                                  \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                    \
-            __builtin_amdgcn_sched_barrier(0);                                                    \
-            if (do_rs && t + 1 < nk) rowsum_tile(t + 1);                                          \
-            ++t;                                                                                  \
-        }
-        while (t + 2 <= nk) {
-            QARIG_PF_BODY(P, Q)
-            QARIG_PF_BODY(Q, P)
-        }
-        if (t < nk) QARIG_PF_BODY(P, Q)
-#undef QARIG_PF_BODY
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // both teams run the same number of k-tiles, so the workgroup-wide barriers inside pair up
+    pf_ring<AKC, BKC>(acc, rs, do_rs, lds2 + team * RING, A, lda, B, ldb, m0, n0, k_begin, nk, wave, lane, tt);
     __syncthreads();                      // both rings idle: exchange + epilogue staging reuse them
     // ---- swap accumulator halves: this wave sends its partial of the 32-row half it does NOT keep
     float* xch = lds2;                    // [8 waves][8 x f32x4][64 lanes]: 64 KB
@@ -759,13 +792,9 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
                         ok4(gradz, ldz) && ok4(slabs, 4);
     // LDS-DMA kernel: interior shapes, 16-B epilogue, no row-sum hook; QARIG_GEMM_DMA=0 disables
     static const bool dma_on = []() { const char* e = getenv("QARIG_GEMM_DMA"); return !(e && e[0] == '0'); }();
-    // measured (tools/gemm_bench.py): the DMA kernel wins on long reductions and narrow outputs
-    // (+5..10 %), the register-staged one on K=512 x N=2048 (its epilogue overlaps better
-    // there), so pick per shape
-    static const bool dma_all = []() { const char* e = getenv("QARIG_GEMM_DMA_ALL"); return e && e[0] == '1'; }();
-    // (kc, kc) short-K wide outputs (the 512 -> 2048 forward) joined the ring's shapes once the
-    // epilogue was specialised: 120.4 vs 118.1 TF; its (kc, xc) gradient stays register-staged (103.8 vs 115.0)
-    const bool dma_shape = dma_all || per >= 1024 || N <= 512 || (a_kcontig && b_kcontig);
+    // every interior shape: since the ring's k-loop carries no vector-ALU address arithmetic it beats
+    // the register-staged kernel on the short-K wide outputs too (dH 512 -> 2048: 131.9 vs 121.8 TF)
+    const bool dma_shape = true;
     // stagger (units of 8128-cycle sleeps per wave slot) only where the grid spans more than
     // one dispatch round of ~4 workgroups per CU; QARIG_GEMM_STAGGER overrides (0 = off)
     const char* stagger_e = getenv("QARIG_GEMM_STAGGER");
@@ -782,19 +811,18 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
         if (stages == 3) hipLaunchKernelGGL((gemm_dma_kernel<AK, BK_, 3>), __VA_ARGS__);      \
         else hipLaunchKernelGGL((gemm_dma_kernel<AK, BK_, 2>), __VA_ARGS__);                  \
     } while (0)
-    // fragment-prefetch form of the ring on the shapes the DMA kernel serves (+2..5 % there,
-    // -4..-13 % on K = 512 x N = 2048, which stays on the register-staged kernel);
-    // QARIG_GEMM_PF=0 restores the 2-stage kernel, =1 forces the prefetch form on every shape
+    // fragment-prefetch form of the ring (4 stages, addresses off the vector ALU: gemm_dma_pf_kernel);
+    // QARIG_GEMM_PF=0 restores the plain 2/3-stage ring
     const char* pf_e = getenv("QARIG_GEMM_PF");
     const bool pf = pf_e ? pf_e[0] == '1' || (pf_e[0] != '0' && dma_shape) : (dma_on && dma_shape);
-    // paired form (two 4-wave teams per tile, 96 KB of LDS): launches that would leave one
+    // paired form (two 4-wave teams per tile, 128 KB of LDS): launches that would leave one
     // workgroup per CU; QARIG_GEMM_PAIR=0 disables, =1 forces it wherever it is eligible
     static const int pair_env = []() { const char* e = getenv("QARIG_GEMM_PAIR"); return e ? atoi(e) : -1; }();
     const int nk_block = per / BK;
     const bool pair_ok = dma_on && fast && vec_epi && !(a_rowsum && a_kcontig) && !(!a_kcontig && b_kcontig) &&
                          nk_block % 2 == 0 && nk_block >= 4;
     if (pair_ok && pair_env != 0 && (pair_env == 1 || (long)grid.x * grid.z <= 256)) {
-        constexpr int PAIR_LDS = 2 * 3 * DMA_STAGE_FLOATS * (int)sizeof(float);
+        constexpr int PAIR_LDS = 2 * PF_STAGES * DMA_STAGE_FLOATS * (int)sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)gemm_dma_pf2_kernel<true, true>,
