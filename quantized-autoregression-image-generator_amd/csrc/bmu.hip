@@ -252,7 +252,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_mma_kernel(PatchGeom g,
     __shared__ __attribute__((aligned(16))) float lds[GEMM_LDS_FLOATS];
     __shared__ float norms[256];   // [0,128): |w|^2 of the code tile, [128,256): |x|^2 of the rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, cl = lane & 31;
+    const int wm = wave >> 1;
     const int p0 = blockIdx.x * BN;  // first patch row of this block
 
     SrcKContig sa{w, (int64_t)g.D, K, g.D, -2.0f,
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_small_kernel(PatchGeom g,
     float* TB = lds;
     float* TA = lds + NKT * TILE_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, cl = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
     const int p0 = blockIdx.x * BN;
 
     SrcKContig sa{w, (int64_t)g.D, K, g.D, -2.0f,
@@ -1165,7 +1165,7 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
         else {
             static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once
             if (!attr_set) {
-                hipFuncSetAttribute((const void*)bmu_small_kernel<4, 8>,
+                (void)hipFuncSetAttribute((const void*)bmu_small_kernel<4, 8>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
                 attr_set = true;
             }

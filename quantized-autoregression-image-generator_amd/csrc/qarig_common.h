@@ -174,8 +174,13 @@ struct SrcKContig {
     __device__ __forceinline__ void store(const float (&r)[STAGE], float* T, int tid) const {
         const int x = tid >> 1;
         const int k = (tid & 1) * 8;
+        if (scale == 1.0f) {   // uniform: no multiplies beside the fp32 MFMAs where there is nothing to scale
 #pragma unroll
-        for (int j = 0; j < 8; ++j) T[(k + j) * LDT + x] = r[j] * scale;
+            for (int j = 0; j < 8; ++j) T[(k + j) * LDT + x] = r[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) T[(k + j) * LDT + x] = r[j] * scale;
+        }
     }
 };
 
@@ -234,8 +239,12 @@ __device__ __forceinline__ void mma_tile(Acc& acc, const float* TA, const float*
                                          int wn, int lane) {
     const int x = lane & 31;
     const int h = lane >> 5;
-    const float* pa = TA + h * LDT + wm * 64 + x;
-    const float* pb = TB + h * LDT + wn * 64 + x;
+    // volatile: one ds_read_b32 with a 16-bit immediate offset per value.  Left to itself hipcc pairs
+    // the reads into ds_read2_b32, whose 8-bit offsets do not reach the next k row (132 floats), and
+    // pays one vector add per pair for a new base -- vector-ALU cycles the fp32 MFMA does not hide.
+    typedef const volatile __attribute__((address_space(3))) float* lds_cvf_t;
+    lds_cvf_t pa = (lds_cvf_t)(TA + h * LDT + wm * 64 + x);
+    lds_cvf_t pb = (lds_cvf_t)(TB + h * LDT + wn * 64 + x);
     // fragment reads run one k-step ahead of the MFMAs that consume them
     float a0 = pa[0], a1 = pa[32], b0 = pb[0], b1 = pb[32];
 #pragma unroll
