@@ -577,6 +577,29 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
     }
 }
 
+// The weight-gradient case in one launch: blocks [0, nb) reduce the slabs into C as above, the
+// blocks behind them the per-split row sums (bias gradient) into rs_out.
+__global__ void slab_reduce_rowsum_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                          int64_t ldc, int M, int N, int nslab, int accumulate, int nb,
+                                          const float* __restrict__ rs_part, float* __restrict__ rs_out) {
+    if ((int)blockIdx.x >= nb) {
+        const int m = ((int)blockIdx.x - nb) * blockDim.x + threadIdx.x;
+        if (m < M) {
+            float s = 0.0f;
+            for (int z = 0; z < nslab; ++z) s += rs_part[(int64_t)z * M + m];
+            rs_out[m] = accumulate ? rs_out[m] + s : s;
+        }
+        return;
+    }
+    const int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)nb * blockDim.x) {
+        float s = 0.0f;
+        for (int z = 0; z < nslab; ++z) s += slabs[(int64_t)z * total + i];
+        const int64_t row = i / N, col = i - row * N;
+        out[row * ldc + col] = accumulate ? out[row * ldc + col] + s : s;
+    }
+}
+
 // Split-K reduce with the full GEMM epilogue: skinny-M GEMMs (autoregressive decode:
 // M = a few dozen rows) have too few output tiles to fill the chip, so their reduction
 // is split over grid.z and bias / residual / activation are applied here.
@@ -883,6 +906,15 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
 #undef QARIG_LAUNCH_GEMM
     }
     QARIG_CHECK_LAUNCH("gemm");
+    if (a_rowsum && splitk > 1 && plain) {   // both reductions of a weight-gradient GEMM in one launch
+        const int64_t total = (int64_t)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(slab_reduce_rowsum_kernel, dim3(blocks + (M + 255) / 256), dim3(256), 0, st, slabs, C,
+                           ldc, M, N, splitk, accumulate, blocks, rs_part, a_rowsum);
+        QARIG_CHECK_LAUNCH("gemm slab + rowsum reduce");
+        return QARIG_OK;
+    }
     if (a_rowsum) {   // a_rowsum[m] (+)= sum over splits, fixed order
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, st, rs_part,
                            a_rowsum, (int64_t)M, 1, M, splitk, accumulate);
