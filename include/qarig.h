@@ -290,6 +290,14 @@ int qarig_scale_by(const float* x, const float* s, float* y, int64_t n, void* st
 int qarig_conv2d_fwd(const float* x, int N, int Cin, int H, int W, const float* w,
                      const float* bias, int Cout, int k, int stride, int pad, int act, float* y,
                      float* preact, void* stream);
+/* The same with a scratch buffer for a tap-major copy of the weights: the 3x3 / stride 1 / padding 1
+ * layers whose tiles are whole (Cin % 16, Cout % 128, N*H*W % 128, W % 4 == 0, input < 2 GB) then run on
+ * the LDS-DMA ring kernel; every other geometry takes the path of qarig_conv2d_fwd.  Results differ
+ * by the summation order only (tap-major instead of channel-major). */
+size_t qarig_conv2d_fwd_workspace_bytes(int Cin, int Cout, int k);
+int qarig_conv2d_fwd_ws(const float* x, int N, int Cin, int H, int W, const float* w,
+                        const float* bias, int Cout, int k, int stride, int pad, int act, float* y,
+                        float* preact, void* workspace, size_t ws_bytes, void* stream);
 
 /* nn.ConvTranspose2d(4, stride 2, padding 1) + bias + activation -- UpsampleConvLayer,
  * models/layers.py:188-207.  x (N,Cin,H,W); w (Cin,Cout,4,4); y (N,Cout,2H,2W). */

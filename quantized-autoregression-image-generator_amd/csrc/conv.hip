@@ -15,6 +15,7 @@
 //  * Cout <= 8 (the 256->3 / 512->4 output layers): a direct VALU kernel, one lane per
 //    pixel, weights through the scalar cache -- an MFMA tile would be >90 % padding.
 #include "qarig_common.h"
+#include "ring_common.h"
 
 namespace qarig {
 
@@ -629,6 +630,200 @@ __global__ __launch_bounds__(1024) void channel_sum_kernel(const float* __restri
     if (threadIdx.x == 0) out[c] = red[0];
 }
 
+// ---------------------------------------------------------------------------------
+// 3x3 / stride 1 / padding 1 convolution on the GEMM's LDS-DMA ring (gemm.hip pf_ring): the same
+// 128 x 128 x 16 tiles, 4 stages, fragments of tile t+1 read while tile t's MFMAs issue, and a
+// k-loop whose vector-ALU work is ~10 instructions per 32 MFMAs instead of ~100 (the fp32 MFMA and
+// the vector ALU do not overlap on this chip: the im2col index arithmetic of conv_mma_kernel --
+// magic-number divisions, 64-bit address adds, border compares, a guarded per-element path for the
+// first and last group of every image row -- is what holds that kernel at 95-105 TF).
+//   * reduction order is TAP-MAJOR: k = tap * C + channel.  A k-tile is 16 channels of ONE tap, so
+//     tap, channel base and the input offset of the tile advance on the scalar unit.
+//   * A = weights re-packed [M][9][C] (conv_pack_tap_kernel; the flip of the data gradient is
+//     applied there, so the kernel only knows offset = tap - 1): k-contiguous rows -> LDS-DMA.
+//   * B = im2col(x): lane (k row, 4 consecutive pixels of an image row) issues ONE 16-B buffer
+//     load per k row at byte offset lane_const + tile_scalar.  The buffer resource spans exactly
+//     the tensor, so a negative or past-the-end offset returns zeros and cannot fault: rows above /
+//     below the image are redirected to offset ~0u (one v_cndmask), the element left of column 0 /
+//     right of column W-1 is zeroed with one v_cndmask; the 16-B load that would START one float
+//     before column 0 is issued one float later and its elements shifted (hardware range-checks a
+//     wrapped offset as out of range for all four dwords).  Registers -> ds_write_b128 into the
+//     stage's [k][128] image, which is the GEMM's tile-contiguous operand layout.
+// Results differ from conv_mma_kernel only by the summation order.
+__global__ void conv_pack_tap_kernel(const float* __restrict__ w, int M, int C, int64_t sm, int64_t sc,
+                                     int flip, float* __restrict__ packed) {
+    const int64_t total = (int64_t)M * 9 * C;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const int64_t t = idx / C;
+        const int tap = (int)(t % 9), m = (int)(t / 9);
+        packed[idx] = w[m * sm + c * sc + (flip ? 8 - tap : tap)];
+    }
+}
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 buffer_load16(unsigned voff, u32x4_t rsrc) {
+    f32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* __restrict__ wp, ConvGeom g,
+                                                                   ConvOut o, int tiles_p, unsigned x_bytes) {
+    __shared__ __attribute__((aligned(16))) float lds[PF_STAGES * DMA_STAGE_FLOATS];   // 64 KB
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tc = tile / tiles_p, tp = tile - tc * tiles_p;   // pixel tile fastest
+    const int c0m = tc * BM, p0 = tp * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int x = lane & 31, h = lane >> 5;
+    const int C = g.C, H = g.H, W = g.W;
+    const int nk = g.K / BK;                 // 9 * C / 16 tiles
+    const int64_t lda = g.K;
+
+    // ---- A: this wave's two DMA instructions per tile (as pf_ring)
+    const float* a_org = wp + (int64_t)c0m * lda;
+    const unsigned oa0 = dma_lane_off<true>(lda, wave * 2, lane), oa1 = dma_lane_off<true>(lda, wave * 2 + 1, lane);
+    const unsigned my_dma_addr = __builtin_amdgcn_readfirstlane(lds_addr(lds + wave * 512));
+    auto issue_a = [&](int t, int stage) {
+        const int k = min(t, nk - 1) * BK;   // clamped: a harmless re-load past the end
+        const char* ak = reinterpret_cast<const char*>(a_org + k);
+        const unsigned dst = my_dma_addr + stage * (DMA_STAGE_FLOATS * 4);
+        dma16_saddr(ak, oa0, dst);
+        dma16_saddr(ak, oa1, dst + 1024);
+    };
+    // ---- B: lane constants.  Thread = (k row kr = tid >> 5 and kr + 8, pixel group tid & 31)
+    const int kr = tid >> 5, grp = tid & 31;
+    const int p = p0 + grp * 4;              // first of this lane's 4 pixels (same image row: W % 4 == 0)
+    const int per = H * W;
+    const int n = p / per, rem = p - n * per;
+    const int oy = rem / W, ox = rem - oy * W;
+    const unsigned lane_off = (unsigned)((((int64_t)n * C + kr) * H + oy) * W + ox) * 4u;   // host: x_bytes < 2^31
+    const unsigned row8 = (unsigned)(8 * per) * 4u;                                        // k row + 8
+    const bool top = oy == 0, bottom = oy == H - 1, left = ox == 0, right = ox + 4 == W;
+    // raw buffer descriptor: base, stride 0, num_records = bytes, 32-bit untyped data format
+    const uint64_t xa = reinterpret_cast<uint64_t>(g.x);
+    const u32x4_t rsrc = {(unsigned)xa, (unsigned)(xa >> 32) & 0xffffu, x_bytes, 0x00020000u};
+    const unsigned b_dst = lds_addr(lds + DMA_OP_FLOATS + kr * 128 + grp * 4);
+    // scalar state of the tile whose B loads are issued next: tap (ty, tx), channel base cb
+    int ty = 0, tx = 0, cb = 0;
+    struct BRegs { f32x4 r0, r1; int tx; };   // one tile's two k rows in flight + the tap column they were loaded for
+    auto load_b = [&](BRegs& br) {           // issues the two loads of tile (ty, tx, cb), then advances the state
+        const int soff = ((cb * H + (ty - 1)) * W + (tx - 1)) * 4;
+        const bool rinv = (ty == 0 && top) || (ty == 2 && bottom);
+        unsigned v0 = lane_off + (unsigned)soff + ((tx == 0 && left) ? 4u : 0u);   // see above: start at column 0
+        unsigned v1 = v0 + row8;
+        v0 = rinv ? 0xFFFFFFF0u : v0;       // beyond num_records, no wrap: all four dwords read as 0
+        v1 = rinv ? 0xFFFFFFF0u : v1;
+        br.r0 = buffer_load16(v0, rsrc);
+        br.r1 = buffer_load16(v1, rsrc);
+        br.tx = tx;
+        cb += 16;
+        if (cb == C) { cb = 0; ++tx; if (tx == 3) { tx = 0; ++ty; } }
+        if (ty == 3) { ty = 2; tx = 2; cb = C - 16; }   // past the end: repeat the last tile (never used)
+    };
+    auto store_b = [&](BRegs& br, int stage) {   // border selects, then the two k rows into the stage's [k][128] image
+        if (br.tx != 1) {                    // uniform
+            const bool shl = br.tx == 0 && left, zr = br.tx == 2 && right;
+            const f32x4 c0 = br.r0, c1 = br.r1;
+            br.r0 = f32x4{shl ? 0.f : c0[0], shl ? c0[0] : c0[1], shl ? c0[1] : c0[2], shl ? c0[2] : (zr ? 0.f : c0[3])};
+            br.r1 = f32x4{shl ? 0.f : c1[0], shl ? c1[0] : c1[1], shl ? c1[1] : c1[2], shl ? c1[2] : (zr ? 0.f : c1[3])};
+        }
+        const unsigned d = b_dst + stage * (DMA_STAGE_FLOATS * 4);
+        asm volatile("ds_write_b128 %0, %1" :: "v"(d), "v"(br.r0) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:4096" :: "v"(d), "v"(br.r1) : "memory");   // k row + 8
+    };
+
+    Acc acc;
+    acc_zero(acc);
+    FragBase fb;
+    frag_bases<true>(lds, wm, x, h, fb.a0, fb.a1);
+    frag_bases<false>(lds, wn, x, h, fb.b0, fb.b1);
+    // prologue: B tiles 0 and 1 written; then, in the order of every body, B(2) | A(3) | B(3): at the top of
+    // body t the queue holds B(t+2) A(t+3)... see the waits below
+    issue_a(0, 0);
+    issue_a(1, 1);
+    issue_a(2, 2);
+    BRegs U, V;
+    load_b(U);
+    load_b(V);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(U.r0), "+v"(U.r1), "+v"(V.r0), "+v"(V.r1) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    store_b(U, 0);
+    store_b(V, 1);
+    load_b(U);                                               // tile 2: written at the top of body 0
+    issue_a(3, 3);
+    load_b(V);                                               // tile 3: written at the top of body 1
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frags8 P, Q;
+    frags_read_s<true, false, 0>(P, fb);
+    frags_wait(P);
+    __builtin_amdgcn_sched_barrier(0);
+    int t = 0;
+    // Body for tile t (stage S = t % 4), fragments in CUR.  BW holds tile t+2 (loaded two bodies ago), the
+    // other register set tile t+3.  Queue at the top, oldest first: [A(t+2) x2,] B(t+2) x2, A(t+3) x2,
+    // B(t+3) x2: B(t+2) (and every older A) has landed at vmcnt(4).
+#define QARIG_CV_BODY(CUR, NXT, S, BW)                                                             \
+    {                                                                                              \
+        /* the registers pass THROUGH the wait: their selects cannot be placed above it */         \
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(BW.r0), "+v"(BW.r1) :: "memory");                 \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        store_b(BW, (S + 2) % 4);                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        __builtin_amdgcn_s_barrier();          /* B(t+2) published; all reads of tile t retired */   \
+        issue_a(t + 4, S);                     /* into the stage tile t has just vacated */        \
+        load_b(BW);                            /* tile t+4 into the registers just written out */  \
+        frags_read_s<true, false, (S + 1) % 4>(NXT, fb);                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        frags_mma(acc, CUR);                                                                       \
+        frags_wait(NXT);                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        ++t;                                                                                       \
+    }
+    while (t + 4 <= nk) {
+        QARIG_CV_BODY(P, Q, 0, U)
+        QARIG_CV_BODY(Q, P, 1, V)
+        QARIG_CV_BODY(P, Q, 2, U)
+        QARIG_CV_BODY(Q, P, 3, V)
+    }
+    if (t < nk) QARIG_CV_BODY(P, Q, 0, U)
+    if (t < nk) QARIG_CV_BODY(Q, P, 1, V)
+    if (t < nk) QARIG_CV_BODY(P, Q, 2, U)
+#undef QARIG_CV_BODY
+    // The last bodies' B loads (tiles past the end) are never stored, but they are still in flight: their
+    // destination registers pass through this wait so that the compiler cannot hand them to the epilogue's
+    // address arithmetic before the loads have landed (it believes an asm load completes where it is issued;
+    // without the tie a late load overwrote an output address: a memory fault at Cin = 256).
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(U.r0), "+v"(U.r1), "+v"(V.r0), "+v"(V.r1) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+
+    // epilogue: as conv_mma_kernel (32 consecutive pixels of one output channel per store instruction)
+    const int cl = lane & 31;
+    const int64_t plane = (int64_t)o.HoP * o.WoP;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pp = p0 + wn * 64 + j * 32 + cl;
+        const int nn = pp / per, rr = pp - nn * per;
+        const int yy = rr / W, xx = rr - yy * W;
+        const int64_t pix = (int64_t)yy * o.WoP + xx;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = c0m + wm * 64 + i * 32 + acc_row(r, lane);
+                float v = acc.t[i][j][r];
+                if (o.bias) v += o.bias[co];
+                const int64_t idx = ((int64_t)nn * o.Cout + co) * plane + pix;
+                if (o.preact) o.preact[idx] = v;
+                o.y[idx] = act_fwd(v, o.act);
+            }
+    }
+}
+
 // Backward-data weight packing for Conv2d: for output-parity class (ry,rx) of dx,
 // packed[ci][(co,ty,tx)] = W[co][ci][kh0y + s*ty][kh0x + s*tx].
 __global__ void conv_bwd_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int k, int s,
@@ -697,12 +892,38 @@ static int launch_conv(const float* wmat, const ConvGeom& g, const ConvOut& o, h
     return QARIG_OK;
 }
 
+// 3x3 / stride 1 / padding 1 on the LDS-DMA ring (conv3x3_ring_kernel) where its tiles are whole:
+// M (output channels of this product) % 128, C (reduced channels) % 16, pixels % 128, W % 4, the
+// input below 2 GB (32-bit buffer offsets).  w element (m, c, tap) at w[m * sm + c * sc + tap];
+// flip: the data gradient's tap order.  `packed`: M * 9 * C floats.  QARIG_CONV_RING=0 disables.
+static bool conv3x3_ring_ok(int N, int C, int H, int W, int M, const void* x, const void* packed) {
+    const char* ring_e = getenv("QARIG_CONV_RING");     // read per call: tools/conv_bench.py --ab alternates it
+    const bool on = !(ring_e && ring_e[0] == '0');
+    const int64_t P = (int64_t)N * H * W, xb = P * C * 4;
+    return on && packed && C % 16 == 0 && C >= 16 && M % BM == 0 && P % BN == 0 && W % 4 == 0 && xb < (1LL << 31) &&
+           (int64_t)9 * C < (1 << 20) && (((uintptr_t)x | (uintptr_t)packed) & 15) == 0;
+}
+static int launch_conv3x3_ring(const float* w, int64_t sm, int64_t sc, int flip, const float* x, int N, int C,
+                               int H, int W, int M, const ConvOut& o, float* packed, hipStream_t st) {
+    const int64_t total = (int64_t)M * 9 * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_pack_tap_kernel, dim3(blocks), dim3(256), 0, st, w, M, C, sm, sc, flip, packed);
+    QARIG_CHECK_LAUNCH("conv3x3 pack");
+    ConvGeom g{x, N, C, H, W, H, W, 1, 3, 3, -1, 1, -1, 1, 9 * C, N * H * W};
+    const int tiles_c = M / BM, tiles_p = g.P / BN;
+    hipLaunchKernelGGL(conv3x3_ring_kernel, dim3(tiles_c * tiles_p), dim3(NTHREADS), 0, st, packed, g, o, tiles_p,
+                       (unsigned)((int64_t)N * C * H * W * 4));
+    QARIG_CHECK_LAUNCH("conv3x3 ring");
+    return QARIG_OK;
+}
+
 // nn.Conv2d(Cin, Cout, k, stride, padding) + bias + activation, NCHW fp32.
 // x (N,Cin,H,W); w (Cout,Cin,k,k); y (N,Cout,Ho,Wo), Ho = (H + 2p - k)/s + 1.
 // preact (same shape as y) receives the pre-activation when non-null.
-extern "C" int qarig_conv2d_fwd(const float* x, int N, int Cin, int H, int W, const float* w,
-                                const float* bias, int Cout, int k, int stride, int pad, int act,
-                                float* y, float* preact, void* stream) {
+static int conv2d_fwd_impl(const float* x, int N, int Cin, int H, int W, const float* w,
+                           const float* bias, int Cout, int k, int stride, int pad, int act,
+                           float* y, float* preact, void* workspace, size_t ws_bytes, void* stream) {
     QARIG_CHECK_ARG(x && w && y, "conv2d: null pointer");
     QARIG_CHECK_ARG(N > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv2d: bad extents");
     QARIG_CHECK_ARG(k >= 1 && k <= 4 && stride >= 1 && stride <= 4 && pad >= 0 && pad <= 4,
@@ -719,7 +940,31 @@ extern "C" int qarig_conv2d_fwd(const float* x, int N, int Cin, int H, int W, co
                     "conv2d: too large");
     ConvGeom g{x, N, Cin, H, W, Ho, Wo, stride, k, k, -pad, 1, -pad, 1, Cin * k * k, N * Ho * Wo};
     ConvOut o{y, preact, bias, Cout, Ho, Wo, 1, 0, 0, act};
+    if (k == 3 && stride == 1 && pad == 1 && workspace &&
+        ws_bytes >= (size_t)Cout * 9 * Cin * sizeof(float) &&
+        conv3x3_ring_ok(N, Cin, H, W, Cout, x, workspace))
+        return launch_conv3x3_ring(w, (int64_t)Cin * 9, 9, 0, x, N, Cin, H, W, Cout, o, (float*)workspace,
+                                   (hipStream_t)stream);
     return launch_conv(w, g, o, (hipStream_t)stream);
+}
+
+extern "C" int qarig_conv2d_fwd(const float* x, int N, int Cin, int H, int W, const float* w,
+                                const float* bias, int Cout, int k, int stride, int pad, int act,
+                                float* y, float* preact, void* stream) {
+    return conv2d_fwd_impl(x, N, Cin, H, W, w, bias, Cout, k, stride, pad, act, y, preact, nullptr, 0, stream);
+}
+
+// The same with a scratch buffer (Cout * Cin * k * k floats) for a re-ordered copy of the weights:
+// enables the LDS-DMA ring kernel on the 3x3 / stride 1 / padding 1 layers (conv3x3_ring_kernel).
+extern "C" size_t qarig_conv2d_fwd_workspace_bytes(int Cin, int Cout, int k) {
+    if (Cin < 1 || Cout < 1 || k < 1 || k > 4 || Cin > (1 << 20) || Cout > (1 << 20)) return 0;
+    return (size_t)Cin * Cout * k * k * sizeof(float);
+}
+extern "C" int qarig_conv2d_fwd_ws(const float* x, int N, int Cin, int H, int W, const float* w,
+                                   const float* bias, int Cout, int k, int stride, int pad, int act,
+                                   float* y, float* preact, void* workspace, size_t ws_bytes, void* stream) {
+    return conv2d_fwd_impl(x, N, Cin, H, W, w, bias, Cout, k, stride, pad, act, y, preact, workspace, ws_bytes,
+                           stream);
 }
 
 extern "C" size_t qarig_conv_transpose2d_workspace_bytes(int Cin, int Cout) {
@@ -820,6 +1065,12 @@ extern "C" int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, i
     hipStream_t st = (hipStream_t)stream;
     float* packed = (float*)workspace;
     const int s = stride;
+    if (k == 3 && s == 1 && pad == 1 && Ho == H && Wo == W && conv3x3_ring_ok(N, Cout, H, W, Cin, dT, packed)) {
+        // dx[ci] = sum_{co, tap} dT[co] at offset (1 - tap) * w[co][ci][tap]: a 3x3 conv over dT with M = Cin,
+        // C = Cout and the taps flipped
+        ConvOut o{dx, nullptr, nullptr, Cin, H, W, 1, 0, 0, ACT_NONE};
+        return launch_conv3x3_ring(w, 9, (int64_t)Cin * 9, 1, dT, N, Cout, H, W, Cin, o, packed, st);
+    }
     for (int ry = 0; ry < s; ++ry)
         for (int rx = 0; rx < s; ++rx) {
             const int gh = (H - ry + s - 1) / s, gw = (W - rx + s - 1) / s;

@@ -765,8 +765,10 @@ def conv2d_fwd(x, weight, bias, stride, pad, act, want_preact=False):
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if want_preact else None
-    check(_lib.load().qarig_conv2d_fwd(ptr(x), N, Cin, H, W, ptr(weight), ptr(bias), Cout, k, stride,
-                                       pad, act, ptr(y), ptr(pre), stream()), "qarig_conv2d_fwd")
+    lib = _lib.load()
+    ws = workspace(lib.qarig_conv2d_fwd_workspace_bytes(Cin, Cout, k), x.device, "convfwd")
+    check(lib.qarig_conv2d_fwd_ws(ptr(x), N, Cin, H, W, ptr(weight), ptr(bias), Cout, k, stride,
+                                  pad, act, ptr(y), ptr(pre), ptr(ws), ws.numel(), stream()), "qarig_conv2d_fwd_ws")
     return (y, pre) if want_preact else y
 
 

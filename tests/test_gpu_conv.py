@@ -240,3 +240,39 @@ def test_conv_autograd_node_accepts_non_contiguous_input():
         res.append((xin.grad.contiguous().clone(), w.grad.clone(), b.grad.clone()))
     for a, c in zip(*res):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,act", [
+    (8, 16, 4, 4, 128, 0),        # every group is both first and last of its row; a pixel tile spans 8 images
+    (2, 32, 8, 8, 128, 1),        # two groups per row
+    (1, 48, 16, 24, 256, 2),      # W not a power of two
+    (2, 256, 32, 32, 256, 1),     # README residual block
+    (3, 16, 128, 4, 128, 3),      # tall, 4 wide
+    (2, 128, 8, 8, 48, 1),        # forward on the gather kernel, input gradient (128 x 48) on the ring
+])
+def test_conv3x3_ring_kernel_fwd_bwd_vs_fp64(N, Cin, H, W, Cout, act):
+    """The 3x3 / stride 1 / padding 1 layers whose tiles are whole run on csrc/conv.hip
+    conv3x3_ring_kernel (tap-major reduction, weights by LDS-DMA, im2col by range-checked buffer loads with
+    the image border handled by selects): forward, input gradient (the same kernel on flipped weights when
+    Cout % 16 == 0 and Cin % 128 == 0) and weight gradient against fp64, at the tolerances of the other
+    conv tests."""
+    from conftest import grad_err
+    from qarig import functional as QF
+    from oracle import ref_models as rm
+    g = torch.Generator().manual_seed(N + Cin + H + W + Cout)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    name = {0: None, 1: "silu", 2: "tanh", 3: "sigmoid"}[act]
+    a = [t.double().requires_grad_(True) for t in (x, w, b)]
+    ya = rm.activation(torch.nn.functional.conv2d(a[0], a[1], a[2], stride=1, padding=1), name)
+    dy = torch.randn(ya.shape, generator=g)
+    (ya * dy.double()).sum().backward()
+    c = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    yc = QF.conv2d_act(c[0], c[1], c[2], 1, 1, act)
+    assert rel_err(yc, ya) < 4e-6
+    (yc * dy.cuda()).sum().backward()
+    for p, q in zip(c, a):
+        assert grad_err(p.grad, q.grad) < 1e-5
+    # deterministic
+    assert torch.equal(QF.conv2d_act(c[0], c[1], c[2], 1, 1, act), yc)

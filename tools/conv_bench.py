@@ -80,5 +80,56 @@ def train():
           f"({dt * 1e3:.1f} ms/step)")
 
 
+def ab():
+    """Ring kernel on / off, interleaved in one process (the clock state of the box moves run to run by more
+    than the difference): median of 7 alternating rounds per case."""
+    import statistics
+    from models.Autoencoder import Autoencoder
+    from qarig import functional as QF
+    from qarig.optim import FlatAdam
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    cases = []
+    N = 16
+    for cin, cout, hw in ((512, 512, 32), (256, 256, 128), (512, 512, 64)):
+        x = torch.randn(N, cin, hw, hw, device=dev)
+        w = torch.randn(cout, cin, 3, 3, device=dev) * 0.02
+        b = torch.zeros(cout, device=dev)
+        fl = 2.0 * N * cout * cin * 9 * hw * hw
+        cases.append((f"conv {cin}->{cout} @{hw} fwd", (lambda x=x, w=w, b=b: ops.conv2d_fwd(x, w, b, 1, 1, 1)), fl, "TF"))
+    m = Autoencoder(num_layers=2, image_channel=3, min_channel=256, max_channel=512, latent_channel=4).to(dev)
+    opt = FlatAdam(m.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    xi = torch.rand(N, 3, 128, 128, device=dev) * 2 - 1
+
+    def step():
+        opt.zero_grad()
+        QF.mse_loss(m(xi), xi).backward()
+        opt.step()
+    cases.append(("autoencoder train step N=16", step, 3 * (27.64 + 53.41) * N * 1e9, "TF"))
+    with torch.no_grad():
+        enc, dec = m.fc_encoder, m.fc_decoder
+        z = torch.randn(32, 4, 32, 32, device=dev)
+        x32 = torch.randn(32, 3, 128, 128, device=dev)
+        cases.append(("decoder N=32", (lambda: dec(z)), 27.64e9 * 32, "TF"))
+        cases.append(("encoder N=32", (lambda: enc(x32)), 53.41e9 * 32, "TF"))
+    for name, fn, fl, unit in cases:
+        res = {"1": [], "0": []}
+        grad = torch.enable_grad() if "train" in name else torch.no_grad()
+        with grad:
+            for rnd in range(7):
+                for mode in ("1", "0"):
+                    os.environ["QARIG_CONV_RING"] = mode
+                    res[mode].append(timeit(fn, reps=3))
+        a, b_ = statistics.median(res["1"]), statistics.median(res["0"])
+        print(f"{name:32s} ring {a * 1e3:8.3f} ms {fl / a / 1e12:6.1f} {unit}   gather kernel {b_ * 1e3:8.3f} ms "
+              f"{fl / b_ / 1e12:6.1f} {unit}   ({b_ / a:.3f}x)", flush=True)
+    os.environ.pop("QARIG_CONV_RING", None)
+
+
 if __name__ == "__main__":
-    train() if "--train" in sys.argv else main()
+    if "--ab" in sys.argv:
+        ab()
+    elif "--train" in sys.argv:
+        train()
+    else:
+        main()

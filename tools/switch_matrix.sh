@@ -15,3 +15,7 @@ for e in QARIG_CONVT_PAIR=0 QARIG_CONVT_PAIR=1; do
     echo "== $e"
     env $e timeout -k 10 300 python -m pytest tests/test_gpu_conv.py -x -q 2>&1 | tail -1
 done
+for e in QARIG_CONV_RING=0; do
+    echo "== $e"
+    env $e timeout -k 10 300 python -m pytest tests/test_gpu_conv.py tests/test_gpu_cli.py -x -q 2>&1 | tail -1
+done
