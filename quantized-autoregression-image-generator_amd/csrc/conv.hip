@@ -824,6 +824,143 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* 
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Weight gradient of the 3x3 / stride 1 / padding 1 layers on the same ring:
+//   dw[cg][cx][tap] = sum over pixels b of G[cg][b + sG] * X[cx][b + sX],
+// a 128 (cg) x 128 (cx) output tile PER TAP, reduced over 16 consecutive base pixels of one image
+// row per k-tile.  Both operands are pixel-contiguous rows ([channel][16 pixels], the GEMM's
+// reduction-contiguous layout), both come in by range-checked LDS-DMA (buffer_load ... lds: voffset
+// = the lane's row/chunk, soffset = the tile, a scalar), so the k-loop has NO vector-ALU work.
+// The tap offset (dy, dx) = (ty-1, tx-1) is split so that every shift is non-negative -- the
+// hardware range check treats a negative offset as out of range for the whole 16 bytes --:
+// sG = (max(0,-dy), max(0,-dx)) on the gradient, sX = (max(0,dy), max(0,dx)) on the input.  What
+// falls off the image: a row below the last one = a zero tile (its soffset is pushed out of range:
+// the DMA writes zeros), the column right of the last one = element 15 of the row's last k-tile,
+// overwritten with 0 in LDS by the wave that DMA'd the row.  Split over pixels across grid.z into
+// slabs in dw's own layout; qarig_slab_reduce_f32 sums them.
+__global__ __launch_bounds__(NTHREADS, 2) void conv3x3_wgrad_ring_kernel(WgradGeom g, int tiles_cx, int per,
+                                                                         int ktiles, unsigned g_bytes,
+                                                                         unsigned x_bytes, float* __restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) float lds[PF_STAGES * DMA_STAGE_FLOATS];   // 64 KB
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tap = tile % 9, tmn = tile / 9;                 // the 9 taps of an output tile share its operand panels
+    const int tcx = tmn % tiles_cx, tcg = tmn / tiles_cx;
+    const int cg0 = tcg * BM, cx0 = tcx * BN;
+    const int ty = tap / 3, tx = tap - ty * 3;
+    const int sGy = ty == 0, sGx = tx == 0, sXy = ty == 2, sXx = tx == 2;
+    const int k_begin = blockIdx.z * per;
+    const int nk = min(per, ktiles - k_begin);               // k-tiles of this split (host: > 0)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int x = lane & 31, h = lane >> 5;
+    const int H = g.H, W = g.W, HW = H * W;
+    const int tiles_row = W / BK;                             // k-tiles per image row
+
+    const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.G), 0, g_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X), 0, x_bytes, 0x00020000);
+    const unsigned o0 = dma_lane_off<true>(HW, wave * 2, lane), o1 = dma_lane_off<true>(HW, wave * 2 + 1, lane);
+    float* const my_dma = lds + wave * 512;                   // this wave's two 1-KB slots of an operand tile
+    // position of the tile issued next: image n, row y, first column xs; tile index ti in the split
+    int ti = 0;
+    int n, y, xs;
+    {
+        const int row = k_begin / tiles_row;                  // (n, y) flattened
+        xs = (k_begin - row * tiles_row) * BK;
+        n = row / H;
+        y = row - n * H;
+    }
+    auto issue = [&](int stage) {
+        const bool zg = y + sGy >= H, zx = y + sXy >= H;     // the shifted row is below the image
+        const unsigned sg = zg ? 0x80000000u : (unsigned)((((n * g.Cg + cg0) * H + y + sGy) * W + xs + sGx) * 4);
+        const unsigned sx = zx ? 0x80000000u : (unsigned)((((n * g.Cx + cx0) * H + y + sXy) * W + xs + sXx) * 4);
+        float* dst = my_dma + stage * DMA_STAGE_FLOATS;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (lds_ptr_t)dst, 16, o0, sg, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (lds_ptr_t)(dst + 256), 16, o1, sg, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_t)(dst + DMA_OP_FLOATS), 16, o0, sx, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_t)(dst + DMA_OP_FLOATS + 256), 16, o1, sx, 0, 0);
+        if (ti + 1 < nk) {                                    // past the end: the last tile again (never used)
+            ++ti;
+            xs += BK;
+            if (xs == W) { xs = 0; ++y; if (y == H) { y = 0; ++n; } }
+        }
+    };
+    // border fix: element 15 of this wave's 32 rows of the operand that is shifted by one column, in the
+    // k-tile that ends at the last column.  fx = first column of the tile to be fixed next.
+    const bool fix_a = sGx != 0, fix_any = sGx != 0 || sXx != 0;
+    int fx = (k_begin % tiles_row) * BK;
+    const int frow = wave * 32 + (lane & 31);
+    const unsigned fix_addr = lds_addr(lds + (fix_a ? 0 : DMA_OP_FLOATS) + frow * 16) + ((3 ^ ((frow >> 2) & 3)) << 4) + 12;
+    const float zero = 0.0f;
+#define QARIG_WG_FIX(S)                                                                            \
+    {                                                                                              \
+        if (fix_any && fx == W - BK && lane < 32)                                                   \
+            asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(fix_addr), "v"(zero), "n"((S) * DMA_STAGE_FLOATS * 4) : "memory"); \
+        fx += BK;                                                                                  \
+        if (fx == W) fx = 0;                                                                       \
+    }
+
+    Acc acc;
+    acc_zero(acc);
+    FragBase fb;
+    frag_bases<true>(lds, wm, x, h, fb.a0, fb.a1);
+    frag_bases<true>(lds, wn, x, h, fb.b0, fb.b1);
+    issue(0);
+    issue(1);
+    issue(2);
+    issue(3);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");         // tile 0 landed (1, 2, 3 in flight)
+    QARIG_WG_FIX(0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frags8 P, Q;
+    frags_read_s<true, true, 0>(P, fb);
+    frags_wait(P);
+    __builtin_amdgcn_sched_barrier(0);
+    int t = 0;
+#define QARIG_WG_BODY(CUR, NXT, S)                                                                 \
+    {                                                                                              \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   /* tile t+1 landed; t+2, t+3 in flight */ \
+        QARIG_WG_FIX((S + 1) % 4)                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        __builtin_amdgcn_s_barrier();                                                              \
+        issue(S);                              /* tile t+4 into the stage tile t has just vacated */ \
+        frags_read_s<true, true, (S + 1) % 4>(NXT, fb);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        frags_mma(acc, CUR);                                                                       \
+        frags_wait(NXT);                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        ++t;                                                                                       \
+    }
+    while (t + 4 <= nk) {
+        QARIG_WG_BODY(P, Q, 0)
+        QARIG_WG_BODY(Q, P, 1)
+        QARIG_WG_BODY(P, Q, 2)
+        QARIG_WG_BODY(Q, P, 3)
+    }
+    if (t < nk) QARIG_WG_BODY(P, Q, 0)
+    if (t < nk) QARIG_WG_BODY(Q, P, 1)
+    if (t < nk) QARIG_WG_BODY(P, Q, 2)
+#undef QARIG_WG_BODY
+#undef QARIG_WG_FIX
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int cl = lane & 31;
+    float* out = slabs + (int64_t)blockIdx.z * g.Cg * g.K2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cx = cx0 + wn * 64 + j * 32 + cl;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cg = cg0 + wm * 64 + i * 32 + acc_row(r, lane);
+                out[(int64_t)cg * g.K2 + cx * 9 + tap] = acc.t[i][j][r];
+            }
+    }
+}
+
 // Backward-data weight packing for Conv2d: for output-parity class (ry,rx) of dx,
 // packed[ci][(co,ty,tx)] = W[co][ci][kh0y + s*ty][kh0x + s*tx].
 __global__ void conv_bwd_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int k, int s,
@@ -1240,6 +1377,23 @@ extern "C" int qarig_conv_wgrad(const float* G, int N, int Cg, int Gh, int Gw, c
         return qarig_slab_reduce_f32((const float*)workspace, dw, g.K2, Cg, g.K2, ns, 0, stream);
     }
     const int splits = wgrad_splits(Cg, g.K2, g.P);
+    {   // 3x3 / stride 1 / padding 1 with whole tiles: the ring kernel (QARIG_CONV_RING=0 disables)
+        const char* ring_e = getenv("QARIG_CONV_RING");
+        const int64_t gb = (int64_t)N * Cg * Gh * Gw * 4, xb = (int64_t)N * Cx * H * W * 4;
+        if (!(ring_e && ring_e[0] == '0') && k == 3 && stride == 1 && pad == 1 && Gh == H && Gw == W && W % BK == 0 &&
+            Cg % BM == 0 && Cx % BN == 0 && gb < (1LL << 31) && xb < (1LL << 31) && (int64_t)H * W < (1 << 22) &&
+            ((((uintptr_t)G | (uintptr_t)X)) & 15) == 0) {
+            const int ktiles = g.P / BK;
+            const int perk = (ktiles + splits - 1) / splits;
+            const int nz = (ktiles + perk - 1) / perk;
+            const int tiles_cx = Cx / BN;
+            const dim3 rgrid((Cg / BM) * tiles_cx * 9, 1, nz), rblock(NTHREADS);
+            hipLaunchKernelGGL(conv3x3_wgrad_ring_kernel, rgrid, rblock, 0, (hipStream_t)stream, g, tiles_cx, perk,
+                               ktiles, (unsigned)gb, (unsigned)xb, (float*)workspace);
+            QARIG_CHECK_LAUNCH("conv_wgrad ring");
+            return qarig_slab_reduce_f32((const float*)workspace, dw, g.K2, Cg, g.K2, nz, 0, stream);
+        }
+    }
     const int per = ((g.P + splits - 1) / splits + BK - 1) / BK * BK;
     const int nsp = (g.P + per - 1) / per;
     const int tiles_m = (Cg + BM - 1) / BM, tiles_n = (g.K2 + BN - 1) / BN;

@@ -249,6 +249,9 @@ def test_conv_autograd_node_accepts_non_contiguous_input():
     (2, 256, 32, 32, 256, 1),     # README residual block
     (3, 16, 128, 4, 128, 3),      # tall, 4 wide
     (2, 128, 8, 8, 48, 1),        # forward on the gather kernel, input gradient (128 x 48) on the ring
+    (2, 128, 16, 16, 128, 0),     # weight gradient on the ring too: one k-tile per image row (every tile meets the border)
+    (1, 128, 8, 48, 128, 1),      # three k-tiles per row
+    (3, 128, 16, 32, 256, 1),     # pixel splits that do not divide evenly
 ])
 def test_conv3x3_ring_kernel_fwd_bwd_vs_fp64(N, Cin, H, W, Cout, act):
     """The 3x3 / stride 1 / padding 1 layers whose tiles are whole run on csrc/conv.hip
