@@ -371,6 +371,24 @@ __global__ void convt_pack_kernel(const float* __restrict__ w, int Cin, int Cout
     }
 }
 
+// The same classes with the reduction tap-major, packed[cls][co][(th, tw)][ci], for the ring kernel.
+__global__ void convt_pack_tap_kernel(const float* __restrict__ w, int Cin, int Cout,
+                                      float* __restrict__ packed) {
+    const int64_t total = (int64_t)4 * Cout * 4 * Cin;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % Cin);
+        int64_t t = idx / Cin;
+        const int tw = (int)(t & 1), th = (int)((t >> 1) & 1);
+        t >>= 2;
+        const int co = (int)(t % Cout);
+        const int cls = (int)(t / Cout);
+        const int py = cls >> 1, px = cls & 1;
+        const int kh = 1 - py + 2 * th, kw = 1 - px + 2 * tw;
+        packed[idx] = w[(((int64_t)ci * Cout + co) * 4 + kh) * 4 + kw];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Backward: weight gradient.  dW[cg][(cx,kh,kw)] = sum over pixels p=(n,gy,gx) of
 //   G[n][cg][gy][gx] * X[n][cx][gy*s + kh - pad][gx*s + kw - pad]
@@ -669,18 +687,22 @@ __device__ __forceinline__ f32x4 buffer_load16(unsigned voff, u32x4_t rsrc) {
     return v;
 }
 
-__global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* __restrict__ wp, ConvGeom g,
-                                                                   ConvOut o, int tiles_p, unsigned x_bytes) {
-    __shared__ __attribute__((aligned(16))) float lds[PF_STAGES * DMA_STAGE_FLOATS];   // 64 KB
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tc = tile / tiles_p, tp = tile - tc * tiles_p;   // pixel tile fastest
-    const int c0m = tc * BM, p0 = tp * BN;
+// One pass of the ring over the whole reduction (taps x channels) of one 128 x 128 tile into `acc`.
+// Taps: g.nty x g.ntx, tap (ty, tx) reads the input at (+ g.oy0 + g.oys * ty, + g.ox0 + g.oxs * tx), every
+// offset in {-1, 0, +1}: the 3x3 convolution (oy0 = ox0 = -1, oys = oxs = 1) and the 2x2-tap parity classes
+// of ConvTranspose2d(4, 2, 1) (oy0 = py, oys = -1, ...).  wp: this product's weights [M][taps][C].
+// T3: the 3x3 geometry as compile-time constants (the general form costs ~4 % there).
+template <bool T3>
+__device__ __forceinline__ void conv_ring_pass(Acc& acc, float* lds, const float* __restrict__ wp, const ConvGeom& g,
+                                               int c0m, int p0, unsigned x_bytes) {
+    const int nty = T3 ? 3 : g.nty, ntx = T3 ? 3 : g.ntx;
+    const int oy0 = T3 ? -1 : g.oy0, oys = T3 ? 1 : g.oys, ox0 = T3 ? -1 : g.ox0, oxs = T3 ? 1 : g.oxs;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int x = lane & 31, h = lane >> 5;
     const int C = g.C, H = g.H, W = g.W;
-    const int nk = g.K / BK;                 // 9 * C / 16 tiles
+    const int nk = g.K / BK;                 // taps * C / 16 tiles
     const int64_t lda = g.K;
 
     // ---- A: this wave's two DMA instructions per tile (as pf_ring)
@@ -709,24 +731,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* 
     const unsigned b_dst = lds_addr(lds + DMA_OP_FLOATS + kr * 128 + grp * 4);
     // scalar state of the tile whose B loads are issued next: tap (ty, tx), channel base cb
     int ty = 0, tx = 0, cb = 0;
-    struct BRegs { f32x4 r0, r1; int tx; };   // one tile's two k rows in flight + the tap column they were loaded for
-    auto load_b = [&](BRegs& br) {           // issues the two loads of tile (ty, tx, cb), then advances the state
-        const int soff = ((cb * H + (ty - 1)) * W + (tx - 1)) * 4;
-        const bool rinv = (ty == 0 && top) || (ty == 2 && bottom);
-        unsigned v0 = lane_off + (unsigned)soff + ((tx == 0 && left) ? 4u : 0u);   // see above: start at column 0
+    struct BRegs { f32x4 r0, r1; };          // one tile's two k rows in flight
+    int U_dx = 0, V_dx = 0;                   // ... and the column offset they were loaded for (scalars: kept apart from the vectors)
+    auto load_b = [&](BRegs& br, int& br_dx) {   // issues the two loads of tile (ty, tx, cb), then advances the state
+        const int dy = oy0 + oys * ty, dx = ox0 + oxs * tx;
+        const int soff = ((cb * H + dy) * W + dx) * 4;
+        const bool rinv = (dy < 0 && top) || (dy > 0 && bottom);
+        unsigned v0 = lane_off + (unsigned)soff + ((dx < 0 && left) ? 4u : 0u);   // see above: start at column 0
         unsigned v1 = v0 + row8;
         v0 = rinv ? 0xFFFFFFF0u : v0;       // beyond num_records, no wrap: all four dwords read as 0
         v1 = rinv ? 0xFFFFFFF0u : v1;
         br.r0 = buffer_load16(v0, rsrc);
         br.r1 = buffer_load16(v1, rsrc);
-        br.tx = tx;
+        br_dx = dx;
         cb += 16;
-        if (cb == C) { cb = 0; ++tx; if (tx == 3) { tx = 0; ++ty; } }
-        if (ty == 3) { ty = 2; tx = 2; cb = C - 16; }   // past the end: repeat the last tile (never used)
+        if (cb == C) { cb = 0; ++tx; if (tx == ntx) { tx = 0; ++ty; } }
+        if (ty == nty) { ty = nty - 1; tx = ntx - 1; cb = C - 16; }   // past the end: repeat the last tile (never used)
     };
-    auto store_b = [&](BRegs& br, int stage) {   // border selects, then the two k rows into the stage's [k][128] image
-        if (br.tx != 1) {                    // uniform
-            const bool shl = br.tx == 0 && left, zr = br.tx == 2 && right;
+    auto store_b = [&](BRegs& br, int br_dx, int stage) {   // border selects, then the two k rows into the stage's [k][128] image
+        if (br_dx != 0) {                    // uniform
+            const bool shl = br_dx < 0 && left, zr = br_dx > 0 && right;
             const f32x4 c0 = br.r0, c1 = br.r1;
             br.r0 = f32x4{shl ? 0.f : c0[0], shl ? c0[0] : c0[1], shl ? c0[1] : c0[2], shl ? c0[2] : (zr ? 0.f : c0[3])};
             br.r1 = f32x4{shl ? 0.f : c1[0], shl ? c1[0] : c1[1], shl ? c1[1] : c1[2], shl ? c1[2] : (zr ? 0.f : c1[3])};
@@ -736,8 +760,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* 
         asm volatile("ds_write_b128 %0, %1 offset:4096" :: "v"(d), "v"(br.r1) : "memory");   // k row + 8
     };
 
-    Acc acc;
-    acc_zero(acc);
     FragBase fb;
     frag_bases<true>(lds, wm, x, h, fb.a0, fb.a1);
     frag_bases<false>(lds, wn, x, h, fb.b0, fb.b1);
@@ -747,15 +769,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* 
     issue_a(1, 1);
     issue_a(2, 2);
     BRegs U, V;
-    load_b(U);
-    load_b(V);
+    load_b(U, U_dx);
+    load_b(V, V_dx);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(U.r0), "+v"(U.r1), "+v"(V.r0), "+v"(V.r1) :: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    store_b(U, 0);
-    store_b(V, 1);
-    load_b(U);                                               // tile 2: written at the top of body 0
+    store_b(U, U_dx, 0);
+    store_b(V, V_dx, 1);
+    load_b(U, U_dx);                                         // tile 2: written at the top of body 0
     issue_a(3, 3);
-    load_b(V);                                               // tile 3: written at the top of body 1
+    load_b(V, V_dx);                                         // tile 3: written at the top of body 1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     Frags8 P, Q;
@@ -771,11 +793,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* 
         /* the registers pass THROUGH the wait: their selects cannot be placed above it */         \
         asm volatile("s_waitcnt vmcnt(4)" : "+v"(BW.r0), "+v"(BW.r1) :: "memory");                 \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        store_b(BW, (S + 2) % 4);                                                                  \
+        store_b(BW, BW##_dx, (S + 2) % 4);                                                                \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
         __builtin_amdgcn_s_barrier();          /* B(t+2) published; all reads of tile t retired */   \
         issue_a(t + 4, S);                     /* into the stage tile t has just vacated */        \
-        load_b(BW);                            /* tile t+4 into the registers just written out */  \
+        load_b(BW, BW##_dx);                   /* tile t+4 into the registers just written out */  \
         frags_read_s<true, false, (S + 1) % 4>(NXT, fb);                                           \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         frags_mma(acc, CUR);                                                                       \
@@ -799,28 +821,76 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* 
     // without the tie a late load overwrote an output address: a memory fault at Cin = 256).
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(U.r0), "+v"(U.r1), "+v"(V.r0), "+v"(V.r1) :: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
+    __syncthreads();                         // every wave is done with the ring: the caller may start another pass
+}
 
-    // epilogue: as conv_mma_kernel (32 consecutive pixels of one output channel per store instruction)
-    const int cl = lane & 31;
+// PAIR = false: one product per workgroup (3x3 / stride 1 / padding 1 forward and input gradient).
+// PAIR = true: ConvTranspose2d(4, 2, 1) forward: blockIdx.y = row parity py, the two column-parity classes px of
+// the same 128 x 128 (channels x logical pixels) tile are reduced one after the other into two accumulator
+// sets and stored as 8-B pairs of output columns (as convt_pair_kernel); class weights at wp + cls * class_stride.
+template <bool PAIR>
+__global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* __restrict__ wp, ConvGeom g,
+                                                                   ConvOut o, int tiles_p, unsigned x_bytes,
+                                                                   int64_t class_stride) {
+    __shared__ __attribute__((aligned(16))) float lds[PF_STAGES * DMA_STAGE_FLOATS];   // 64 KB
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tc = tile / tiles_p, tp = tile - tc * tiles_p;   // pixel tile fastest
+    const int c0m = tc * BM, p0 = tp * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, cl = lane & 31;
+    const int per = g.H * g.W, W = g.W;
     const int64_t plane = (int64_t)o.HoP * o.WoP;
+    if constexpr (!PAIR) {
+        Acc acc;
+        acc_zero(acc);
+        conv_ring_pass<true>(acc, lds, wp, g, c0m, p0, x_bytes);
+        // epilogue: as conv_mma_kernel (32 consecutive pixels of one output channel per store instruction)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pp = p0 + wn * 64 + j * 32 + cl;
-        const int nn = pp / per, rr = pp - nn * per;
-        const int yy = rr / W, xx = rr - yy * W;
-        const int64_t pix = (int64_t)yy * o.WoP + xx;
+        for (int j = 0; j < 2; ++j) {
+            const int pp = p0 + wn * 64 + j * 32 + cl;
+            const int nn = pp / per, rr = pp - nn * per;
+            const int yy = rr / W, xx = rr - yy * W;
+            const int64_t pix = (int64_t)yy * o.WoP + xx;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = c0m + wm * 64 + i * 32 + acc_row(r, lane);
-                float v = acc.t[i][j][r];
-                if (o.bias) v += o.bias[co];
-                const int64_t idx = ((int64_t)nn * o.Cout + co) * plane + pix;
-                if (o.preact) o.preact[idx] = v;
-                o.y[idx] = act_fwd(v, o.act);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int co = c0m + wm * 64 + i * 32 + acc_row(r, lane);
+                    float v = acc.t[i][j][r];
+                    if (o.bias) v += o.bias[co];
+                    const int64_t idx = ((int64_t)nn * o.Cout + co) * plane + pix;
+                    if (o.preact) o.preact[idx] = v;
+                    o.y[idx] = act_fwd(v, o.act);
+                }
+        }
+    } else {
+        const int py = blockIdx.y;
+        g.oy0 = py;                              // tap th reads input row a + py - th
+        Acc acc[2];
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            g.ox0 = px;                          // tap tw reads input column b + px - tw
+            acc_zero(acc[px]);
+            conv_ring_pass<false>(acc[px], lds, wp + (py * 2 + px) * class_stride, g, c0m, p0, x_bytes);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pp = p0 + wn * 64 + j * 32 + cl;
+            const int nn = pp / per, rr = pp - nn * per;
+            const int yy = rr / W, xx = rr - yy * W;
+            const int64_t pix = (int64_t)(yy * 2 + py) * o.WoP + xx * 2;     // even: 8-B aligned
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = c0m + wm * 64 + i * 32 + acc_row(r, lane);
+                    float t0 = acc[0].t[i][j][r], t1 = acc[1].t[i][j][r];
+                    if (o.bias) { const float bv = o.bias[co]; t0 += bv; t1 += bv; }
+                    const int64_t idx = ((int64_t)nn * o.Cout + co) * plane + pix;
+                    if (o.preact) *reinterpret_cast<float2*>(o.preact + idx) = make_float2(t0, t1);
+                    *reinterpret_cast<float2*>(o.y + idx) = make_float2(act_fwd(t0, o.act), act_fwd(t1, o.act));
+                }
+        }
     }
 }
 
@@ -1049,8 +1119,8 @@ static int launch_conv3x3_ring(const float* w, int64_t sm, int64_t sc, int flip,
     QARIG_CHECK_LAUNCH("conv3x3 pack");
     ConvGeom g{x, N, C, H, W, H, W, 1, 3, 3, -1, 1, -1, 1, 9 * C, N * H * W};
     const int tiles_c = M / BM, tiles_p = g.P / BN;
-    hipLaunchKernelGGL(conv3x3_ring_kernel, dim3(tiles_c * tiles_p), dim3(NTHREADS), 0, st, packed, g, o, tiles_p,
-                       (unsigned)((int64_t)N * C * H * W * 4));
+    hipLaunchKernelGGL((conv3x3_ring_kernel<false>), dim3(tiles_c * tiles_p), dim3(NTHREADS), 0, st, packed, g, o,
+                       tiles_p, (unsigned)((int64_t)N * C * H * W * 4), (int64_t)0);
     QARIG_CHECK_LAUNCH("conv3x3 ring");
     return QARIG_OK;
 }
@@ -1131,6 +1201,19 @@ extern "C" int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H,
     const int64_t total = (int64_t)16 * Cin * Cout;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
+    // the four parity classes as 2x2-tap stride-1 products on the LDS-DMA ring, two column parities per workgroup
+    if (conv3x3_ring_ok(N, Cin, H, W, Cout, x, packed) && (((uintptr_t)y | (uintptr_t)preact) & 7) == 0) {
+        hipLaunchKernelGGL(convt_pack_tap_kernel, dim3(blocks), dim3(256), 0, st, w, Cin, Cout, packed);
+        QARIG_CHECK_LAUNCH("conv_transpose2d pack");
+        const int K = Cin * 4, P = N * H * W;
+        ConvGeom g{x, N, Cin, H, W, H, W, 1, 2, 2, 0, -1, 0, -1, K, P};
+        ConvOut o{y, preact, bias, Cout, 2 * H, 2 * W, 2, 0, 0, act};
+        const int tiles_p = P / BN;
+        hipLaunchKernelGGL((conv3x3_ring_kernel<true>), dim3((Cout / BM) * tiles_p, 2), dim3(NTHREADS), 0, st, packed, g,
+                           o, tiles_p, (unsigned)((int64_t)N * Cin * H * W * 4), (int64_t)Cout * K);
+        QARIG_CHECK_LAUNCH("conv_transpose2d ring");
+        return QARIG_OK;
+    }
     hipLaunchKernelGGL(convt_pack_kernel, dim3(blocks), dim3(256), 0, st, w, Cin, Cout, packed);
     QARIG_CHECK_LAUNCH("conv_transpose2d pack");
     // both column parities per launch (8-B stores) where the MFMA kernel applies and y / preact

@@ -279,3 +279,22 @@ def test_conv3x3_ring_kernel_fwd_bwd_vs_fp64(N, Cin, H, W, Cout, act):
         assert grad_err(p.grad, q.grad) < 1e-5
     # deterministic
     assert torch.equal(QF.conv2d_act(c[0], c[1], c[2], 1, 1, act), yc)
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout", [(8, 16, 4, 4, 128), (2, 32, 8, 8, 128), (1, 48, 16, 24, 256),
+                                            (3, 64, 32, 4, 128)])
+def test_conv_transpose2d_ring_kernel_vs_fp64(N, Cin, H, W, Cout):
+    """ConvTranspose2d(4, 2, 1) forward as four 2x2-tap stride-1 products on the ring kernel (two column
+    parities per workgroup, 8-B stores): narrow images (every pixel group touches a border), tiles spanning
+    images, channel counts that leave a remainder of ring bodies; saved pre-activation included."""
+    from qarig import ops
+    g = torch.Generator().manual_seed(N * 7 + Cin + H + W + Cout)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cin, Cout, 4, 4), generator=g) / (4 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    y, pre = ops.conv_transpose2d_fwd(x.cuda(), w.cuda(), b.cuda(), 1, want_preact=True)
+    assert y.shape == ref.shape
+    assert rel_err(pre, ref) < 2e-6
+    assert rel_err(y, torch.nn.functional.silu(ref)) < 4e-6
+    assert torch.equal(ops.conv_transpose2d_fwd(x.cuda(), w.cuda(), b.cuda(), 1), y)

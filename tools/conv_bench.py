@@ -97,6 +97,12 @@ def ab():
         b = torch.zeros(cout, device=dev)
         fl = 2.0 * N * cout * cin * 9 * hw * hw
         cases.append((f"conv {cin}->{cout} @{hw} fwd", (lambda x=x, w=w, b=b: ops.conv2d_fwd(x, w, b, 1, 1, 1)), fl, "TF"))
+    for cin, cout, hw in ((512, 256, 32), (256, 256, 64)):
+        x = torch.randn(N, cin, hw, hw, device=dev)
+        w = torch.randn(cin, cout, 4, 4, device=dev) * 0.02
+        b = torch.zeros(cout, device=dev)
+        fl = 2.0 * N * cout * cin * 16 * hw * hw
+        cases.append((f"convT {cin}->{cout} @{hw} fwd", (lambda x=x, w=w, b=b: ops.conv_transpose2d_fwd(x, w, b, 1)), fl, "TF"))
     m = Autoencoder(num_layers=2, image_channel=3, min_channel=256, max_channel=512, latent_channel=4).to(dev)
     opt = FlatAdam(m.parameters(), lr=1e-4, betas=(0.5, 0.999))
     xi = torch.rand(N, 3, 128, 128, device=dev) * 2 - 1
