@@ -54,6 +54,7 @@ for name, (res, args) in sorted(_lib.SIGNATURES.items()):
 # well-formed README-shaped calls of the hot entry points: validation passes, the dispatch /
 # workspace / grid arithmetic runs, the launch fails for want of a device
 X = 0x7f0000000000
+X2 = 0x7f1000000000          # a second fake device address (entries that refuse aliased in/out)
 def call(name, *a):
     global calls
     r = getattr(lib, name)(*a)
@@ -82,6 +83,15 @@ for (N, Cin, H, W, Cout, k, st) in ((4, 3, 128, 128, 256, 3, 1), (4, 256, 128, 1
     call("qarig_conv2d_fwd", X, N, Cin, H, W, X, X, Cout, k, st, 1, 1, X, X, None)
     call("qarig_conv_wgrad", X, N, Cout, H // st, W // st, X, Cin, H, W, k, st, 1, X, X, 1 << 40, None)
 call("qarig_conv_transpose2d_fwd", X, 4, 512, 32, 32, X, X, 256, 1, X, X, X, 1 << 40, None)
+# the ring kernels' launch geometry: 3x3 forward with a scratch buffer, its input gradient, ConvTranspose at a
+# batch of 16, the band form of the Gaussian neighbourhood
+for (N, Cin, H, W, Cout) in ((16, 256, 128, 128, 256), (16, 512, 32, 32, 512), (1, 48, 16, 24, 256), (2, 130, 12, 10, 140)):
+    call("qarig_conv2d_fwd_ws", X, N, Cin, H, W, X, X, Cout, 3, 1, 1, 1, X, X, X, 1 << 40, None)
+    call("qarig_conv2d_bwd_data", X, N, Cout, H, W, X, Cin, 3, 1, 1, H, W, X, X, 1 << 40, None)
+    call("qarig_conv_wgrad", X, N, Cout, H, W, X, Cin, H, W, 3, 1, 1, X, X, 1 << 40, None)
+call("qarig_conv_transpose2d_fwd", X, 16, 256, 64, 64, X, X, 256, 1, X, X, X, 1 << 40, None)
+call("qarig_som_band", X, 8192, 4, 1779.0, 222, X2, None)
+call("qarig_som_band", X, 512, 16, 0.43, 4, X2, None)
 buf = ctypes.create_string_buffer(8)          # a too-short buffer must be respected
 lib.qarig_last_error.argtypes = [ctypes.c_char_p, Z]
 lib.qarig_last_error(buf, 8)
