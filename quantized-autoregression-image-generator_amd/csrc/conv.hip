@@ -831,7 +831,7 @@ __device__ __forceinline__ void conv_ring_pass(Acc& acc, float* lds, const float
 template <bool PAIR>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* __restrict__ wp, ConvGeom g,
                                                                    ConvOut o, int tiles_p, unsigned x_bytes,
-                                                                   int64_t class_stride) {
+                                                                   int64_t class_stride, int mode) {
     __shared__ __attribute__((aligned(16))) float lds[PF_STAGES * DMA_STAGE_FLOATS];   // 64 KB
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tc = tile / tiles_p, tp = tile - tc * tiles_p;   // pixel tile fastest
@@ -864,14 +864,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* 
                 }
         }
     } else {
+        // mode 0: ConvTranspose2d(4, 2, 1) forward, class (py, px) = 2 x 2 taps at offsets (py - th, px - tw), class
+        // weights class_stride apart.  mode 1: input gradient of Conv2d(3, stride 2, padding 1), class (ry, rx) of
+        // dx = (1 + ry) x (1 + rx) taps at offsets (ry - ty, rx - tx) over dT; classes packed back to back
+        // ([M][taps][C] each: 1, 2, 2, 4 taps).
         const int py = blockIdx.y;
-        g.oy0 = py;                              // tap th reads input row a + py - th
+        g.oy0 = py;
+        if (mode == 1) g.nty = 1 + py;
         Acc acc[2];
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
-            g.ox0 = px;                          // tap tw reads input column b + px - tw
+            g.ox0 = px;
+            int64_t woff = (py * 2 + px) * class_stride;
+            if (mode == 1) {
+                g.ntx = 1 + px;
+                g.K = g.C * g.nty * g.ntx;
+                const int cls = py * 2 + px;
+                woff = (int64_t)o.Cout * g.C * (cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5)));
+            }
             acc_zero(acc[px]);
-            conv_ring_pass<false>(acc[px], lds, wp + (py * 2 + px) * class_stride, g, c0m, p0, x_bytes);
+            conv_ring_pass<false>(acc[px], lds, wp + woff, g, c0m, p0, x_bytes);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1031,6 +1043,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_wgrad_ring_kernel(WgradGe
     }
 }
 
+// Conv2d(3, stride 2, padding 1) input gradient on the ring: the four output-parity classes of dx, tap-major,
+// back to back: class (ry, rx) has (1 + ry) x (1 + rx) taps, packed[off(cls) + (ci * taps + ty * ntx + tx) * Cout + co]
+// = W[co][ci][ky0 + 2 ty][kx0 + 2 tx], ky0 = (ry + 1) % 2; off = Cin * Cout * {0, 1, 3, 5}.
+__global__ void conv_s2_dgrad_pack_tap_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                              float* __restrict__ packed) {
+    const int64_t total = (int64_t)9 * Cin * Cout;
+    const int64_t mc = (int64_t)Cin * Cout;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int cls = idx < mc ? 0 : (idx < 3 * mc ? 1 : (idx < 5 * mc ? 2 : 3));
+        const int ry = cls >> 1, rx = cls & 1;
+        const int nty = 1 + ry, ntx = 1 + rx, taps = nty * ntx;
+        const int64_t r = idx - mc * (cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5)));
+        const int co = (int)(r % Cout);
+        const int64_t t = r / Cout;
+        const int tap = (int)(t % taps), ci = (int)(t / taps);
+        const int ty = tap / ntx, tx = tap - ty * ntx;
+        const int ky = (ry + 1) % 2 + 2 * ty, kx = (rx + 1) % 2 + 2 * tx;
+        packed[idx] = w[(((int64_t)co * Cin + ci) * 3 + ky) * 3 + kx];
+    }
+}
+
 // Backward-data weight packing for Conv2d: for output-parity class (ry,rx) of dx,
 // packed[ci][(co,ty,tx)] = W[co][ci][kh0y + s*ty][kh0x + s*tx].
 __global__ void conv_bwd_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int k, int s,
@@ -1120,7 +1154,7 @@ static int launch_conv3x3_ring(const float* w, int64_t sm, int64_t sc, int flip,
     ConvGeom g{x, N, C, H, W, H, W, 1, 3, 3, -1, 1, -1, 1, 9 * C, N * H * W};
     const int tiles_c = M / BM, tiles_p = g.P / BN;
     hipLaunchKernelGGL((conv3x3_ring_kernel<false>), dim3(tiles_c * tiles_p), dim3(NTHREADS), 0, st, packed, g, o,
-                       tiles_p, (unsigned)((int64_t)N * C * H * W * 4), (int64_t)0);
+                       tiles_p, (unsigned)((int64_t)N * C * H * W * 4), (int64_t)0, 0);
     QARIG_CHECK_LAUNCH("conv3x3 ring");
     return QARIG_OK;
 }
@@ -1210,7 +1244,7 @@ extern "C" int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H,
         ConvOut o{y, preact, bias, Cout, 2 * H, 2 * W, 2, 0, 0, act};
         const int tiles_p = P / BN;
         hipLaunchKernelGGL((conv3x3_ring_kernel<true>), dim3((Cout / BM) * tiles_p, 2), dim3(NTHREADS), 0, st, packed, g,
-                           o, tiles_p, (unsigned)((int64_t)N * Cin * H * W * 4), (int64_t)Cout * K);
+                           o, tiles_p, (unsigned)((int64_t)N * Cin * H * W * 4), (int64_t)Cout * K, 0);
         QARIG_CHECK_LAUNCH("conv_transpose2d ring");
         return QARIG_OK;
     }
@@ -1290,6 +1324,24 @@ extern "C" int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, i
         // C = Cout and the taps flipped
         ConvOut o{dx, nullptr, nullptr, Cin, H, W, 1, 0, 0, ACT_NONE};
         return launch_conv3x3_ring(w, 9, (int64_t)Cin * 9, 1, dT, N, Cout, H, W, Cin, o, packed, st);
+    }
+    if (k == 3 && s == 2 && pad == 1 && H == 2 * Ho && W == 2 * Wo && conv3x3_ring_ok(N, Cout, Ho, Wo, Cin, dT, packed) &&
+        ((uintptr_t)dx & 7) == 0) {
+        // the four output-parity classes of dx as (1 + ry) x (1 + rx)-tap stride-1 products over dT on the ring,
+        // two column parities per workgroup (8-B stores), both row parities in one launch
+        const int64_t total = (int64_t)9 * Cin * Cout;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv_s2_dgrad_pack_tap_kernel, dim3(blocks), dim3(256), 0, st, w, Cout, Cin, packed);
+        QARIG_CHECK_LAUNCH("conv2d_bwd_data pack");
+        const int P = N * Ho * Wo;
+        ConvGeom g{dT, N, Cout, Ho, Wo, Ho, Wo, 1, 1, 1, 0, -1, 0, -1, Cout, P};
+        ConvOut o{dx, nullptr, nullptr, Cin, H, W, 2, 0, 0, ACT_NONE};
+        const int tiles_p = P / BN;
+        hipLaunchKernelGGL((conv3x3_ring_kernel<true>), dim3((Cin / BM) * tiles_p, 2), dim3(NTHREADS), 0, st, packed, g,
+                           o, tiles_p, (unsigned)((int64_t)N * Cout * Ho * Wo * 4), (int64_t)0, 1);
+        QARIG_CHECK_LAUNCH("conv2d_bwd_data ring");
+        return QARIG_OK;
     }
     for (int ry = 0; ry < s; ++ry)
         for (int rx = 0; rx < s; ++rx) {

@@ -298,3 +298,26 @@ def test_conv_transpose2d_ring_kernel_vs_fp64(N, Cin, H, W, Cout):
     assert rel_err(pre, ref) < 2e-6
     assert rel_err(y, torch.nn.functional.silu(ref)) < 4e-6
     assert torch.equal(ops.conv_transpose2d_fwd(x.cuda(), w.cuda(), b.cuda(), 1), y)
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout", [(2, 128, 16, 16, 32), (8, 128, 8, 8, 16), (1, 256, 32, 48, 48),
+                                            (2, 256, 32, 32, 512)])
+def test_conv2d_stride2_input_gradient_ring_vs_fp64(N, Cin, H, W, Cout):
+    """Input gradient of Conv2d(3, stride 2, padding 1) as four parity classes of 1 / 2 / 2 / 4 taps on the ring
+    kernel (csrc/conv.hip conv3x3_ring_kernel<PAIR>, mode 1), with every gradient of the layer against fp64."""
+    from conftest import grad_err
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(N + Cin + H + W + Cout + 2)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    a = [t.double().requires_grad_(True) for t in (x, w, b)]
+    ya = torch.nn.functional.silu(torch.nn.functional.conv2d(a[0], a[1], a[2], stride=2, padding=1))
+    dy = torch.randn(ya.shape, generator=g)
+    (ya * dy.double()).sum().backward()
+    c = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    yc = QF.conv2d_act(c[0], c[1], c[2], 2, 1, 1)
+    assert rel_err(yc, ya) < 4e-6
+    (yc * dy.cuda()).sum().backward()
+    for p, q in zip(c, a):
+        assert grad_err(p.grad, q.grad) < 1e-5
