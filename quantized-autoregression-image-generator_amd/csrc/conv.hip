@@ -692,7 +692,15 @@ __device__ __forceinline__ f32x4 buffer_load16(unsigned voff, u32x4_t rsrc) {
 // offset in {-1, 0, +1}: the 3x3 convolution (oy0 = ox0 = -1, oys = oxs = 1) and the 2x2-tap parity classes
 // of ConvTranspose2d(4, 2, 1) (oy0 = py, oys = -1, ...).  wp: this product's weights [M][taps][C].
 // T3: the 3x3 geometry as compile-time constants (the general form costs ~4 % there).
-template <bool T3>
+// S2: the input is read with stride 2 (Conv2d(3, stride 2, padding 1) forward; H = 2 Ho, W = 2 Wo): a lane's 4
+// output pixels read every other input column -- four 4-B buffer loads per k row instead of one 16-B load.
+template <int OFF>
+__device__ __forceinline__ float buffer_load4(unsigned voff, u32x4_t rsrc) {
+    float v;
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%3" : "=v"(v) : "v"(voff), "s"(rsrc), "n"(OFF) : "memory");
+    return v;
+}
+template <bool T3, bool S2 = false>
 __device__ __forceinline__ void conv_ring_pass(Acc& acc, float* lds, const float* __restrict__ wp, const ConvGeom& g,
                                                int c0m, int p0, unsigned x_bytes) {
     const int nty = T3 ? 3 : g.nty, ntx = T3 ? 3 : g.ntx;
@@ -719,12 +727,14 @@ __device__ __forceinline__ void conv_ring_pass(Acc& acc, float* lds, const float
     // ---- B: lane constants.  Thread = (k row kr = tid >> 5 and kr + 8, pixel group tid & 31)
     const int kr = tid >> 5, grp = tid & 31;
     const int p = p0 + grp * 4;              // first of this lane's 4 pixels (same image row: W % 4 == 0)
-    const int per = H * W;
+    const int Hq = S2 ? g.Ho : H, Wq = S2 ? g.Wo : W;          // the pixel grid (= the input's unless strided)
+    constexpr int ST = S2 ? 2 : 1;
+    const int per = Hq * Wq;
     const int n = p / per, rem = p - n * per;
-    const int oy = rem / W, ox = rem - oy * W;
-    const unsigned lane_off = (unsigned)((((int64_t)n * C + kr) * H + oy) * W + ox) * 4u;   // host: x_bytes < 2^31
-    const unsigned row8 = (unsigned)(8 * per) * 4u;                                        // k row + 8
-    const bool top = oy == 0, bottom = oy == H - 1, left = ox == 0, right = ox + 4 == W;
+    const int oy = rem / Wq, ox = rem - oy * Wq;
+    const unsigned lane_off = (unsigned)((((int64_t)n * C + kr) * H + oy * ST) * W + ox * ST) * 4u;   // host: x_bytes < 2^31
+    const unsigned row8 = (unsigned)(8 * H * W) * 4u;                                     // k row + 8
+    const bool top = oy == 0, bottom = oy == Hq - 1, left = ox == 0, right = ox + 4 == Wq;
     // raw buffer descriptor: base, stride 0, num_records = bytes, 32-bit untyped data format
     const uint64_t xa = reinterpret_cast<uint64_t>(g.x);
     const u32x4_t rsrc = {(unsigned)xa, (unsigned)(xa >> 32) & 0xffffu, x_bytes, 0x00020000u};
@@ -736,20 +746,30 @@ __device__ __forceinline__ void conv_ring_pass(Acc& acc, float* lds, const float
     auto load_b = [&](BRegs& br, int& br_dx) {   // issues the two loads of tile (ty, tx, cb), then advances the state
         const int dy = oy0 + oys * ty, dx = ox0 + oxs * tx;
         const int soff = ((cb * H + dy) * W + dx) * 4;
-        const bool rinv = (dy < 0 && top) || (dy > 0 && bottom);
-        unsigned v0 = lane_off + (unsigned)soff + ((dx < 0 && left) ? 4u : 0u);   // see above: start at column 0
+        // strided: rows 2 oy + dy, dy in {-1, 0, 1 (, 2)}: only dy = -1 at the top and dy = 2 at the bottom fall outside
+        const bool rinv = S2 ? ((dy < 0 && top) || (dy > 1 && bottom)) : ((dy < 0 && top) || (dy > 0 && bottom));
+        unsigned v0 = lane_off + (unsigned)soff + ((!S2 && dx < 0 && left) ? 4u : 0u);   // see above: start at column 0
         unsigned v1 = v0 + row8;
-        v0 = rinv ? 0xFFFFFFF0u : v0;       // beyond num_records, no wrap: all four dwords read as 0
-        v1 = rinv ? 0xFFFFFFF0u : v1;
-        br.r0 = buffer_load16(v0, rsrc);
-        br.r1 = buffer_load16(v1, rsrc);
+        v0 = rinv ? 0xFFFFFF00u : v0;       // beyond num_records, no wrap: every dword reads as 0
+        v1 = rinv ? 0xFFFFFF00u : v1;
+        if constexpr (S2) {
+            br.r0 = f32x4{buffer_load4<0>(v0, rsrc), buffer_load4<8>(v0, rsrc), buffer_load4<16>(v0, rsrc), buffer_load4<24>(v0, rsrc)};
+            br.r1 = f32x4{buffer_load4<0>(v1, rsrc), buffer_load4<8>(v1, rsrc), buffer_load4<16>(v1, rsrc), buffer_load4<24>(v1, rsrc)};
+        } else {
+            br.r0 = buffer_load16(v0, rsrc);
+            br.r1 = buffer_load16(v1, rsrc);
+        }
         br_dx = dx;
         cb += 16;
         if (cb == C) { cb = 0; ++tx; if (tx == ntx) { tx = 0; ++ty; } }
         if (ty == nty) { ty = nty - 1; tx = ntx - 1; cb = C - 16; }   // past the end: repeat the last tile (never used)
     };
     auto store_b = [&](BRegs& br, int br_dx, int stage) {   // border selects, then the two k rows into the stage's [k][128] image
-        if (br_dx != 0) {                    // uniform
+        if (S2) {                            // column 2 ox + dx: only dx = -1 at the left edge (dx = 2 at the right) is outside
+            const bool zl = br_dx < 0 && left, zr = br_dx > 1 && right;
+            br.r0[0] = zl ? 0.f : br.r0[0]; br.r1[0] = zl ? 0.f : br.r1[0];
+            br.r0[3] = zr ? 0.f : br.r0[3]; br.r1[3] = zr ? 0.f : br.r1[3];
+        } else if (br_dx != 0) {             // uniform
             const bool shl = br_dx < 0 && left, zr = br_dx > 0 && right;
             const f32x4 c0 = br.r0, c1 = br.r1;
             br.r0 = f32x4{shl ? 0.f : c0[0], shl ? c0[0] : c0[1], shl ? c0[1] : c0[2], shl ? c0[2] : (zr ? 0.f : c0[3])};
@@ -787,11 +807,11 @@ __device__ __forceinline__ void conv_ring_pass(Acc& acc, float* lds, const float
     int t = 0;
     // Body for tile t (stage S = t % 4), fragments in CUR.  BW holds tile t+2 (loaded two bodies ago), the
     // other register set tile t+3.  Queue at the top, oldest first: [A(t+2) x2,] B(t+2) x2, A(t+3) x2,
-    // B(t+3) x2: B(t+2) (and every older A) has landed at vmcnt(4).
+    // B(t+3) x2 (x8 each in the strided form): B(t+2) (and every older A) has landed at vmcnt(4) (vmcnt(10)).
 #define QARIG_CV_BODY(CUR, NXT, S, BW)                                                             \
     {                                                                                              \
         /* the registers pass THROUGH the wait: their selects cannot be placed above it */         \
-        asm volatile("s_waitcnt vmcnt(4)" : "+v"(BW.r0), "+v"(BW.r1) :: "memory");                 \
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(BW.r0), "+v"(BW.r1) : "n"(S2 ? 10 : 4) : "memory"); \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         store_b(BW, BW##_dx, (S + 2) % 4);                                                                \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
@@ -828,7 +848,7 @@ __device__ __forceinline__ void conv_ring_pass(Acc& acc, float* lds, const float
 // PAIR = true: ConvTranspose2d(4, 2, 1) forward: blockIdx.y = row parity py, the two column-parity classes px of
 // the same 128 x 128 (channels x logical pixels) tile are reduced one after the other into two accumulator
 // sets and stored as 8-B pairs of output columns (as convt_pair_kernel); class weights at wp + cls * class_stride.
-template <bool PAIR>
+template <bool PAIR, bool S2 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* __restrict__ wp, ConvGeom g,
                                                                    ConvOut o, int tiles_p, unsigned x_bytes,
                                                                    int64_t class_stride, int mode) {
@@ -838,12 +858,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* 
     const int c0m = tc * BM, p0 = tp * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, cl = lane & 31;
-    const int per = g.H * g.W, W = g.W;
+    const int per = S2 ? g.Ho * g.Wo : g.H * g.W, W = S2 ? g.Wo : g.W;   // the pixel grid
     const int64_t plane = (int64_t)o.HoP * o.WoP;
     if constexpr (!PAIR) {
         Acc acc;
         acc_zero(acc);
-        conv_ring_pass<true>(acc, lds, wp, g, c0m, p0, x_bytes);
+        conv_ring_pass<true, S2>(acc, lds, wp, g, c0m, p0, x_bytes);
         // epilogue: as conv_mma_kernel (32 consecutive pixels of one output channel per store instruction)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1186,6 +1206,27 @@ static int conv2d_fwd_impl(const float* x, int N, int Cin, int H, int W, const f
         conv3x3_ring_ok(N, Cin, H, W, Cout, x, workspace))
         return launch_conv3x3_ring(w, (int64_t)Cin * 9, 9, 0, x, N, Cin, H, W, Cout, o, (float*)workspace,
                                    (hipStream_t)stream);
+    {   // stride 2: the same kernel with a strided im2col (four 4-B loads per k row)
+        const char* ring_e = getenv("QARIG_CONV_RING");
+        const int64_t P = (int64_t)N * Ho * Wo, xb = (int64_t)N * Cin * H * W * 4;
+        if (!(ring_e && ring_e[0] == '0') && k == 3 && stride == 2 && pad == 1 && H == 2 * Ho && W == 2 * Wo && workspace &&
+            ws_bytes >= (size_t)Cout * 9 * Cin * sizeof(float) && Cin % 16 == 0 && Cout % BM == 0 && P % BN == 0 &&
+            Wo % 4 == 0 && xb < (1LL << 31) && (((uintptr_t)x | (uintptr_t)workspace) & 15) == 0) {
+            hipStream_t st = (hipStream_t)stream;
+            float* packed = (float*)workspace;
+            const int64_t total = (int64_t)Cout * 9 * Cin;
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(conv_pack_tap_kernel, dim3(blocks), dim3(256), 0, st, w, Cout, Cin, (int64_t)Cin * 9,
+                               (int64_t)9, 0, packed);
+            QARIG_CHECK_LAUNCH("conv3x3 pack");
+            const int tiles_p = (int)(P / BN);
+            hipLaunchKernelGGL((conv3x3_ring_kernel<false, true>), dim3((Cout / BM) * tiles_p), dim3(NTHREADS), 0, st,
+                               packed, g, o, tiles_p, (unsigned)xb, (int64_t)0, 0);
+            QARIG_CHECK_LAUNCH("conv3x3 stride-2 ring");
+            return QARIG_OK;
+        }
+    }
     return launch_conv(w, g, o, (hipStream_t)stream);
 }
 

@@ -321,3 +321,22 @@ def test_conv2d_stride2_input_gradient_ring_vs_fp64(N, Cin, H, W, Cout):
     (yc * dy.cuda()).sum().backward()
     for p, q in zip(c, a):
         assert grad_err(p.grad, q.grad) < 1e-5
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout,act", [(8, 16, 8, 8, 128, 0), (2, 32, 16, 16, 128, 1), (1, 48, 32, 48, 256, 2),
+                                                (2, 256, 64, 64, 512, 1)])
+def test_conv2d_stride2_forward_ring_vs_fp64(N, Cin, H, W, Cout, act):
+    """Conv2d(3, stride 2, padding 1) forward on the ring kernel with the strided im2col (four 4-B buffer
+    loads per k row; only the top row / left column of the padding can be touched): output and saved
+    pre-activation against fp64, narrow and non-power-of-two widths, tiles spanning images."""
+    from qarig import ops
+    from oracle import ref_models as rm
+    g = torch.Generator().manual_seed(N + Cin + H + W + Cout + 11)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (3 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    y, pre = ops.conv2d_fwd(x.cuda(), w.cuda(), b.cuda(), 2, 1, act, want_preact=True)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    assert rel_err(pre, ref) < 2e-6
+    assert rel_err(y, rm.activation(ref, {0: None, 1: "silu", 2: "tanh", 3: "sigmoid"}[act])) < 4e-6
+    assert torch.equal(ops.conv2d_fwd(x.cuda(), w.cuda(), b.cuda(), 2, 1, act), y)

@@ -97,6 +97,12 @@ def ab():
         b = torch.zeros(cout, device=dev)
         fl = 2.0 * N * cout * cin * 9 * hw * hw
         cases.append((f"conv {cin}->{cout} @{hw} fwd", (lambda x=x, w=w, b=b: ops.conv2d_fwd(x, w, b, 1, 1, 1)), fl, "TF"))
+    for cin, cout, hw in ((256, 512, 128), (512, 512, 64)):
+        x = torch.randn(N, cin, hw, hw, device=dev)
+        w = torch.randn(cout, cin, 3, 3, device=dev) * 0.02
+        b = torch.zeros(cout, device=dev)
+        fl = 2.0 * N * cout * cin * 9 * (hw // 2) * (hw // 2)
+        cases.append((f"conv {cin}->{cout} @{hw} stride 2 fwd", (lambda x=x, w=w, b=b: ops.conv2d_fwd(x, w, b, 2, 1, 1)), fl, "TF"))
     for cin, cout, hw in ((512, 256, 32), (256, 256, 64)):
         x = torch.randn(N, cin, hw, hw, device=dev)
         w = torch.randn(cin, cout, 4, 4, device=dev) * 0.02
