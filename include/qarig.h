@@ -313,6 +313,10 @@ int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, int Wo, cons
                           size_t ws_bytes, void* stream);
 int qarig_conv_transpose2d_bwd_data(const float* dT, int N, int Cout, int H, int W, const float* w,
                                     int Cin, float* dx, void* stream);
+/* ... with a scratch buffer (16 * Cin * Cout floats) for tap-major weights: whole-tile layers on the strided ring
+ * kernel, every other geometry as above. */
+int qarig_conv_transpose2d_bwd_data_ws(const float* dT, int N, int Cout, int H, int W, const float* w,
+                                       int Cin, float* dx, void* workspace, size_t ws_bytes, void* stream);
 /* G (N,Cg,Gh,Gw) correlated with im2col_{k,stride,pad}(X (N,Cx,H,W)) -> dw (Cg, Cx*k*k).
  * Conv2d: G=dT, X=input.  ConvTranspose2d(4,2,1): G=input, X=dT, k=4, stride=2, pad=1. */
 size_t qarig_conv_wgrad_workspace_bytes(int Cg, int K2, int P);

@@ -669,14 +669,14 @@ __global__ __launch_bounds__(1024) void channel_sum_kernel(const float* __restri
 //     stage's [k][128] image, which is the GEMM's tile-contiguous operand layout.
 // Results differ from conv_mma_kernel only by the summation order.
 __global__ void conv_pack_tap_kernel(const float* __restrict__ w, int M, int C, int64_t sm, int64_t sc,
-                                     int flip, float* __restrict__ packed) {
-    const int64_t total = (int64_t)M * 9 * C;
+                                     int flip, float* __restrict__ packed, int ntaps = 9) {
+    const int64_t total = (int64_t)M * ntaps * C;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % C);
         const int64_t t = idx / C;
-        const int tap = (int)(t % 9), m = (int)(t / 9);
-        packed[idx] = w[m * sm + c * sc + (flip ? 8 - tap : tap)];
+        const int tap = (int)(t % ntaps), m = (int)(t / ntaps);
+        packed[idx] = w[m * sm + c * sc + (flip ? ntaps - 1 - tap : tap)];
     }
 }
 
@@ -848,7 +848,7 @@ __device__ __forceinline__ void conv_ring_pass(Acc& acc, float* lds, const float
 // PAIR = true: ConvTranspose2d(4, 2, 1) forward: blockIdx.y = row parity py, the two column-parity classes px of
 // the same 128 x 128 (channels x logical pixels) tile are reduced one after the other into two accumulator
 // sets and stored as 8-B pairs of output columns (as convt_pair_kernel); class weights at wp + cls * class_stride.
-template <bool PAIR, bool S2 = false>
+template <bool PAIR, bool S2 = false, bool T3K = true>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* __restrict__ wp, ConvGeom g,
                                                                    ConvOut o, int tiles_p, unsigned x_bytes,
                                                                    int64_t class_stride, int mode) {
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* 
     if constexpr (!PAIR) {
         Acc acc;
         acc_zero(acc);
-        conv_ring_pass<true, S2>(acc, lds, wp, g, c0m, p0, x_bytes);
+        conv_ring_pass<T3K, S2>(acc, lds, wp, g, c0m, p0, x_bytes);
         // epilogue: as conv_mma_kernel (32 consecutive pixels of one output channel per store instruction)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1409,8 +1409,20 @@ extern "C" int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, i
 // d(input) of ConvTranspose2d(4,2,1): dT (N,Cout,2H,2W) -> dx (N,Cin,H,W) is a
 // Conv2d(k=4, stride 2, pad 1) over dT whose weight matrix [Cin][Cout*16] is the
 // ConvTranspose weight exactly as stored.
+static int convt_bwd_data_impl(const float* dT, int N, int Cout, int H, int W, const float* w, int Cin, float* dx,
+                               void* workspace, size_t ws_bytes, void* stream);
 extern "C" int qarig_conv_transpose2d_bwd_data(const float* dT, int N, int Cout, int H, int W,
                                                const float* w, int Cin, float* dx, void* stream) {
+    return convt_bwd_data_impl(dT, N, Cout, H, W, w, Cin, dx, nullptr, 0, stream);
+}
+// The same with a scratch buffer (16 * Cin * Cout floats) for a tap-major copy of the weights: the strided
+// ring kernel then serves the layers whose tiles are whole (Cout % 16, Cin % 128, N*H*W % 128, W % 4 == 0).
+extern "C" int qarig_conv_transpose2d_bwd_data_ws(const float* dT, int N, int Cout, int H, int W, const float* w,
+                                                  int Cin, float* dx, void* workspace, size_t ws_bytes, void* stream) {
+    return convt_bwd_data_impl(dT, N, Cout, H, W, w, Cin, dx, workspace, ws_bytes, stream);
+}
+static int convt_bwd_data_impl(const float* dT, int N, int Cout, int H, int W, const float* w, int Cin, float* dx,
+                               void* workspace, size_t ws_bytes, void* stream) {
     QARIG_CHECK_ARG(dT && w && dx, "conv_transpose2d_bwd_data: null pointer");
     QARIG_CHECK_ARG(qarig_dims_ok({N, Cout, H, W, 4}, 1LL << 20, 1LL << 31), "conv_transpose2d_bwd_data: extents too large");
     QARIG_CHECK_ARG(qarig_dims_ok({N, Cin, H, W}, 1LL << 20, 1LL << 31), "conv_transpose2d_bwd_data: extents too large");
@@ -1418,6 +1430,28 @@ extern "C" int qarig_conv_transpose2d_bwd_data(const float* dT, int N, int Cout,
 
     ConvGeom g{dT, N, Cout, 2 * H, 2 * W, H, W, 2, 4, 4, -1, 1, -1, 1, Cout * 16, N * H * W};
     ConvOut o{dx, nullptr, nullptr, Cin, H, W, 1, 0, 0, ACT_NONE};
+    {   // Conv2d(4, stride 2, padding 1) over dT on the strided ring: 16 taps at offsets -1 .. 2
+        const char* ring_e = getenv("QARIG_CONV_RING");
+        const int64_t P = (int64_t)N * H * W, xb = (int64_t)N * Cout * 4 * H * W * 4;
+        if (!(ring_e && ring_e[0] == '0') && workspace && ws_bytes >= (size_t)16 * Cin * Cout * sizeof(float) &&
+            Cout % 16 == 0 && Cin % BM == 0 && P % BN == 0 && W % 4 == 0 && xb < (1LL << 31) &&
+            (((uintptr_t)dT | (uintptr_t)workspace) & 15) == 0) {
+            hipStream_t st = (hipStream_t)stream;
+            float* packed = (float*)workspace;
+            const int64_t total = (int64_t)Cin * 16 * Cout;
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            // w (Cin, Cout, 4, 4): element (m = ci, c = co, tap) at ci * Cout * 16 + co * 16 + tap
+            hipLaunchKernelGGL(conv_pack_tap_kernel, dim3(blocks), dim3(256), 0, st, w, Cin, Cout, (int64_t)Cout * 16,
+                               (int64_t)16, 0, packed, 16);
+            QARIG_CHECK_LAUNCH("conv_transpose2d_bwd_data pack");
+            const int tiles_p = (int)(P / BN);
+            hipLaunchKernelGGL((conv3x3_ring_kernel<false, true, false>), dim3((Cin / BM) * tiles_p), dim3(NTHREADS), 0,
+                               st, packed, g, o, tiles_p, (unsigned)xb, (int64_t)0, 0);
+            QARIG_CHECK_LAUNCH("conv_transpose2d_bwd_data ring");
+            return QARIG_OK;
+        }
+    }
     return launch_conv(w, g, o, (hipStream_t)stream);
 }
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "qarig_conv2d_bwd_data_workspace_bytes": (Z, [I, I, I]),
     "qarig_conv2d_bwd_data": (I, [P, I, I, I, I, P, I, I, I, I, I, I, P, P, Z, P]),
     "qarig_conv_transpose2d_bwd_data": (I, [P, I, I, I, I, P, I, P, P]),
+    "qarig_conv_transpose2d_bwd_data_ws": (I, [P, I, I, I, I, P, I, P, P, Z, P]),
     "qarig_conv_wgrad_workspace_bytes": (Z, [I, I, I]),
     "qarig_conv_wgrad": (I, [P, I, I, I, I, P, I, I, I, I, I, I, P, P, Z, P]),
     "qarig_conv_bias_grad": (I, [P, I, I, I, P, P]),

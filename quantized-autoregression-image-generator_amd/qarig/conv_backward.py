@@ -63,9 +63,11 @@ def conv_transpose2d_bwd(ctx, dy, x, weight, pre, act, has_bias):
     dx = dw = db = None
     if ctx.needs_input_grad[0]:
         dx = torch.empty_like(x)
-        check(_lib.load().qarig_conv_transpose2d_bwd_data(ptr(dT), N, Cout, H, W, ptr(weight), Cin,
-                                                          ptr(dx), stream()),
-              "qarig_conv_transpose2d_bwd_data")
+        lib = _lib.load()
+        ws = workspace(lib.qarig_conv_transpose2d_workspace_bytes(Cin, Cout), x.device, "convbwd")
+        check(lib.qarig_conv_transpose2d_bwd_data_ws(ptr(dT), N, Cout, H, W, ptr(weight), Cin, ptr(dx), ptr(ws),
+                                                     ws.numel(), stream()),
+              "qarig_conv_transpose2d_bwd_data_ws")
     if ctx.needs_input_grad[1]:
         dw = _wgrad(x, dT, 4, 2, 1, weight.shape)
     if has_bias and ctx.needs_input_grad[2]:

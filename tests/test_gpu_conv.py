@@ -340,3 +340,25 @@ def test_conv2d_stride2_forward_ring_vs_fp64(N, Cin, H, W, Cout, act):
     assert rel_err(pre, ref) < 2e-6
     assert rel_err(y, rm.activation(ref, {0: None, 1: "silu", 2: "tanh", 3: "sigmoid"}[act])) < 4e-6
     assert torch.equal(ops.conv2d_fwd(x.cuda(), w.cuda(), b.cuda(), 2, 1, act), y)
+
+
+@pytest.mark.parametrize("N,Cin,H,W,Cout", [(8, 128, 4, 4, 16), (1, 128, 16, 24, 48), (2, 256, 8, 8, 32)])
+def test_conv_transpose2d_input_gradient_ring_vs_fp64(N, Cin, H, W, Cout):
+    """Input gradient of ConvTranspose2d(4, 2, 1) = Conv2d(4, stride 2, padding 1) over dT: 16 taps at offsets
+    -1 .. 2 on the strided ring kernel (rows / columns past the far edge included), all gradients vs fp64."""
+    from conftest import grad_err
+    from qarig import functional as QF
+    g = torch.Generator().manual_seed(N + Cin * 3 + H + W + Cout)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cin, Cout, 4, 4), generator=g) / (4 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    a = [t.double().requires_grad_(True) for t in (x, w, b)]
+    ya = torch.nn.functional.silu(torch.nn.functional.conv_transpose2d(a[0], a[1], a[2], stride=2, padding=1))
+    dy = torch.randn(ya.shape, generator=g)
+    (ya * dy.double()).sum().backward()
+    c = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    yc = QF.conv_transpose2d_act(c[0], c[1], c[2], 1)
+    assert rel_err(yc, ya) < 4e-6
+    (yc * dy.cuda()).sum().backward()
+    for p, q in zip(c, a):
+        assert grad_err(p.grad, q.grad) < 1e-5
