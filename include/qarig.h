@@ -73,6 +73,27 @@ int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const float* B, i
                    const float* gradz, int64_t ldz, int gact, int splitk, int accumulate,
                    float* a_rowsum, void* workspace, size_t ws_bytes, void* stream);
 
+/* `groups` (1..16) products of ONE shape as one launch: C_g = epilogue(A_g B_g^T), every argument of
+ * qarig_gemm_f32 with the pointers given as host arrays of `groups` device pointers (a NULL array =
+ * that epilogue input absent for every group; entries of one array may repeat, e.g. a shared A).
+ * Strides, layouts, activation ids, splitk and accumulate are common to the groups.
+ * sum_groups != 0: C[0] (+)= sum_g A_g B_g^T (plain epilogue), summed over (g, split) in ascending
+ * order.  Interior shapes only (qarig_gemm_grouped_supported: M, N multiples of 128, whole 16-deep
+ * tiles per split, 16-B aligned operands).  The q / k / v two-layer MLPs of an attention layer
+ * (models/layers.py:389-418) -- forward, both input gradients and both weight gradients -- run as
+ * one such launch per product instead of three; the cross-attention k / v MLPs of every decoder
+ * layer (models/layers.py:538-599, all reading the encoder output, models/Transformer.py:179-191)
+ * as one launch per product for all layers. */
+int qarig_gemm_grouped_supported(int M, int N, int K, int splitk);
+size_t qarig_gemm_grouped_workspace_bytes(int groups, int M, int N, int splitk, int sum_groups);
+int qarig_gemm_f32_grouped(int groups, const float* const* A, int64_t lda, int a_kcontig,
+                           const float* const* B, int64_t ldb, int b_kcontig, float* const* C,
+                           int64_t ldc, int M, int N, int K, const float* const* bias,
+                           const float* const* residual, int64_t ldr, float* const* preact,
+                           int64_t ldp, int act, const float* const* gradz, int64_t ldz, int gact,
+                           int splitk, int accumulate, int sum_groups, float* const* a_rowsum,
+                           void* workspace, size_t ws_bytes, void* stream);
+
 /* Opt-in reduced precision (BASELINE config 5: "fp8/bf16 MFMA attn/FFN"; never the fp32 parity
  * mode).  The Linear contractions of models/layers.py:234-304, 330-340, 389-418 with bf16
  * OPERANDS IN HBM, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation and the same fused
@@ -178,10 +199,12 @@ int qarig_posemb_fwd(const float* pos, int R, int D, const float* freq, float* o
 /* Token assembly of the training hot loop (train_quantized_transformer.py:423-484) in one launch:
  * from the LR / HR BMU indices to the windowed decoder input, target and absolute positions
  * (base: [lr | hr + k_lr] / enc-dec: [<start> | hr]; target [hr | <end>]; window of W tokens
- * starting at offs[n]; pos = offs[n] + w).  Replaces cat + unfold + gather + arange on the host. */
+ * starting at offs[n]; pos = offs[n] + w).  Replaces cat + unfold + gather + arange on the host.
+ * *bad_flag (device int, caller-zeroed, may be NULL) is set on a window start outside
+ * [0, S_in - W]; the window is then clamped (torch.gather would raise). */
 int qarig_assemble_tokens(const int64_t* lr, int S_lr, const int64_t* hr, int S_hr, int N, int base,
                           int k_lr, int k_hr, const int64_t* offs, int W, int64_t* hr_in,
-                          int64_t* hr_tg, int64_t* pos, void* stream);
+                          int64_t* hr_tg, int64_t* pos, int* bad_flag, void* stream);
 
 /* nn.Embedding + additive position table -- models/Transformer.py:127-139,154-167.
  * ids int64 (M = N*S); pe (S,D) or NULL; out (M,D). */

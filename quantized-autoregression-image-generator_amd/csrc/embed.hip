@@ -52,13 +52,18 @@ __global__ void assemble_tokens_kernel(const int64_t* __restrict__ lr, int S_lr,
                                        const int64_t* __restrict__ hr, int S_hr, int N, int base,
                                        int k_lr, int k_hr, const int64_t* __restrict__ offs, int W,
                                        int64_t* __restrict__ hr_in, int64_t* __restrict__ hr_tg,
-                                       int64_t* __restrict__ pos) {
+                                       int64_t* __restrict__ pos, int* __restrict__ bad_flag) {
     const int lead = base ? S_lr : 1;          // tokens in front of the HR tokens of the input
     const int64_t total = (int64_t)N * W;
+    const int64_t o_max = (int64_t)lead + S_hr - W;   // last valid window start
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int n = (int)(idx / W), w = (int)(idx - (int64_t)n * W);
-        const int64_t o = offs ? offs[n] : 0;
+        int64_t o = offs ? offs[n] : 0;
+        if (o < 0 || o > o_max) {                                  // a window outside the sequence: flag it
+            if (bad_flag) *bad_flag = 1;                           // (the host raises IndexError), read a
+            o = o < 0 ? 0 : o_max;                                 // clamped window instead of foreign memory
+        }
         const int64_t j = o + w;                                   // index in the full sequences
         int64_t vin;
         if (j < lead) vin = base ? lr[(int64_t)n * S_lr + j] : (int64_t)k_hr;
@@ -202,11 +207,12 @@ extern "C" int qarig_embedding_bwd(const int64_t* ids, int M, int D, int V, cons
 
 // hr_in / hr_tg / pos (N,W) int64 from the BMU indices (see assemble_tokens_kernel).  lr (N,S_lr)
 // is read by the base model only; offs (N) int64 window starts or NULL (then W must be the
-// input length S_lr + S_hr (base) / 1 + S_hr and pos may be NULL).  Offsets are trusted to lie in
-// [0, S_in - W] (the host draws them with randint(0, S_in - W + 1)).
+// input length S_lr + S_hr (base) / 1 + S_hr and pos may be NULL).  An offset outside [0, S_in - W]
+// sets *bad_flag (device int, may be NULL) and is clamped, as the other index-consuming kernels do.
 extern "C" int qarig_assemble_tokens(const int64_t* lr, int S_lr, const int64_t* hr, int S_hr, int N,
                                      int base, int k_lr, int k_hr, const int64_t* offs, int W,
-                                     int64_t* hr_in, int64_t* hr_tg, int64_t* pos, void* stream) {
+                                     int64_t* hr_in, int64_t* hr_tg, int64_t* pos, int* bad_flag,
+                                     void* stream) {
     QARIG_CHECK_ARG(hr && hr_in && hr_tg && (lr || !base), "assemble_tokens: null pointer");
     QARIG_CHECK_ARG(N > 0 && S_hr > 0 && W > 0 && (!base || S_lr > 0), "assemble_tokens: bad extents");
     QARIG_CHECK_DIMS("assemble_tokens", N, S_hr);
@@ -221,7 +227,7 @@ extern "C" int qarig_assemble_tokens(const int64_t* lr, int S_lr, const int64_t*
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(assemble_tokens_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, lr, S_lr,
-                       hr, S_hr, N, base, k_lr, k_hr, offs, W, hr_in, hr_tg, pos);
+                       hr, S_hr, N, base, k_lr, k_hr, offs, W, hr_in, hr_tg, pos, bad_flag);
     QARIG_CHECK_LAUNCH("assemble_tokens");
     return QARIG_OK;
 }

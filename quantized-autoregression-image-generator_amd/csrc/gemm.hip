@@ -470,6 +470,134 @@ __global__ __launch_bounds__(2 * NTHREADS, 1) void gemm_dma_pf2_kernel(const flo
                        team, team + 1);
 }
 
+// ---------------------------------------------------------------------------------
+// Grouped form: `groups` problems of ONE shape (M, N, K, layouts, strides, epilogue kind) with
+// their own operand / output pointers, as one launch.  The per-GPU shard of a small global batch
+// (2,048 rows) leaves every Linear product of the q/k/v MLPs (reference models/layers.py:389-418)
+// at 64 or 256 tiles -- one workgroup per CU or fewer, every launch paying its ramp, its store
+// drain and (for the 64-tile shapes) a split-K reduce of its own.  Three (self-attention: q, k, v
+// of one layer) or 2 x layers (the cross-attention k / v MLPs of every decoder layer, whose input
+// -- the encoder output -- is the same tensor) of them fill the chip as one grid.  The grid is
+// flat: workgroup -> (group g, reduction split z, tile), tiles of one (g, z) consecutive so that
+// an XCD's L2 sees neighbouring tiles of one problem.  Slab index = g * splitk + z; in "sum" mode
+// (sum_g A_g B_g^T: the input gradient of MLPs that share their input) all groups * splits slabs
+// reduce into one output.
+constexpr int GEMM_MAX_GROUPS = 16;
+struct GemmGroupPtrs {
+    const float* A[GEMM_MAX_GROUPS];
+    const float* B[GEMM_MAX_GROUPS];
+    float* C[GEMM_MAX_GROUPS];
+    const float* bias[GEMM_MAX_GROUPS];
+    const float* residual[GEMM_MAX_GROUPS];
+    float* preact[GEMM_MAX_GROUPS];
+    const float* gradz[GEMM_MAX_GROUPS];
+    float* rowsum[GEMM_MAX_GROUPS];
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_pf_grouped_kernel(GemmGroupPtrs gp, int64_t lda,
+                                                                          int64_t ldb, GemmEpilogue ep, int M,
+                                                                          int N, int K, int tiles_n, int tiles,
+                                                                          int splitk, float* slabs,
+                                                                          float* rs_part) {
+    __shared__ __attribute__((aligned(16))) float lds[PF_STAGES * DMA_STAGE_FLOATS];   // 64 KB
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_g = tiles * splitk;
+    const int g = lin / per_g;
+    const int r = lin - g * per_g;
+    const int z = r / tiles;
+    const int tile = r - z * tiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int per = K / splitk;                       // host: whole BK tiles per split
+    const int k_begin = z * per;
+    const int nk = per / BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* A = gp.A[g];
+    const float* B = gp.B[g];
+    ep.C = gp.C[g];
+    ep.bias = gp.bias[g];
+    ep.residual = gp.residual[g];
+    ep.preact = gp.preact[g];
+    ep.gradz = gp.gradz[g];
+    const int slab = g * splitk + z;
+    float* my_slab = slabs ? slabs + (int64_t)slab * M * N : nullptr;
+
+    Acc acc;
+    acc_zero(acc);
+    float rs = 0.0f;
+    const bool do_rs = !AKC && rs_part != nullptr && tn == 0 && tid < 128;
+    pf_ring<AKC, BKC>(acc, rs, do_rs, lds, A, lda, B, ldb, m0, n0, k_begin, nk, wave, lane, tid);
+    if (do_rs) rs_part[(int64_t)slab * M + m0 + tid] = rs;
+    __syncthreads();                      // ring no longer in use: the epilogue stages through it
+    // (1-D grid: blockIdx.z == 0, so the epilogue's slab offset is the one folded into my_slab)
+    gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, my_slab ? 2 : 1, my_slab);
+}
+
+// Reduce pass of a grouped launch.  blockIdx.y = output o, whose slabs are [o * nslab, (o + 1) *
+// nslab) in ascending (fixed) order; blocks [0, nb) of x: 16-B columns of the M x N output, plain
+// (+= when accumulate) or, EPI, through the full epilogue; the blocks behind them: the per-slab
+// row sums (bias gradient) of the same output.
+template <bool EPI>
+__global__ __launch_bounds__(256) void slab_reduce_grouped_kernel(const float* __restrict__ slabs, GemmGroupPtrs gp,
+                                                                  GemmEpilogue ep, int M, int N, int nslab,
+                                                                  int accumulate, int nb,
+                                                                  const float* __restrict__ rs_part) {
+    const int o = blockIdx.y;
+    if ((int)blockIdx.x >= nb) {
+        float* rs_out = gp.rowsum[o];
+        const int m = ((int)blockIdx.x - nb) * blockDim.x + threadIdx.x;
+        if (m < M && rs_out) {
+            const float* p = rs_part + (int64_t)o * nslab * M + m;
+            float s = 0.0f;
+            for (int zz = 0; zz < nslab; ++zz) s += p[(int64_t)zz * M];
+            rs_out[m] = accumulate ? rs_out[m] + s : s;
+        }
+        return;
+    }
+    const int64_t total = (int64_t)M * N;
+    const float* base = slabs + (int64_t)o * nslab * total;
+    float* C = gp.C[o];
+    const int n4 = N >> 2;
+    const int64_t total4 = total >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)nb * blockDim.x) {
+        float4 t = *reinterpret_cast<const float4*>(base + 4 * i);
+        for (int zz = 1; zz < nslab; ++zz) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)zz * total + 4 * i);
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        const int64_t row = i / n4;
+        const int col = (int)(i - row * n4) * 4;
+        float4* dst = reinterpret_cast<float4*>(C + row * ep.ldc + col);
+        if (!EPI) {
+            if (accumulate) {
+                const float4 c = *dst;
+                t.x = c.x + t.x; t.y = c.y + t.y; t.z = c.z + t.z; t.w = c.w + t.w;
+            }
+            *dst = t;
+            continue;
+        }
+        if (gp.bias[o]) {
+            const float4 b = *reinterpret_cast<const float4*>(gp.bias[o] + col);
+            t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+        }
+        if (gp.residual[o]) {
+            const float4 rv = *reinterpret_cast<const float4*>(gp.residual[o] + row * ep.ldr + col);
+            t.x += rv.x; t.y += rv.y; t.z += rv.z; t.w += rv.w;
+        }
+        if (gp.preact[o]) *reinterpret_cast<float4*>(gp.preact[o] + row * ep.ldp + col) = t;
+        float4 y = make_float4(act_fwd(t.x, ep.act), act_fwd(t.y, ep.act), act_fwd(t.z, ep.act),
+                               act_fwd(t.w, ep.act));
+        if (gp.gradz[o]) {
+            const float4 zv = *reinterpret_cast<const float4*>(gp.gradz[o] + row * ep.ldz + col);
+            y.x *= act_grad(zv.x, ep.gact); y.y *= act_grad(zv.y, ep.gact);
+            y.z *= act_grad(zv.z, ep.gact); y.w *= act_grad(zv.w, ep.gact);
+        }
+        *dst = y;
+    }
+}
+
 // out[i] (+ld handling) = sum_z slabs[z][i], z ascending: deterministic.
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                    int64_t ldc, int M, int N, int nslab, int accumulate) {
@@ -890,6 +1018,112 @@ extern "C" int qarig_gemm_f32(const float* A, int64_t lda, int a_kcontig, const 
     return gemm_dispatch(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, residual, ldr,
                          preact, ldp, act, gradz, ldz, gact, splitk, accumulate, a_rowsum, workspace,
                          ws_bytes, stream);
+}
+
+// ---- grouped interior GEMM (see gemm_dma_pf_grouped_kernel) ------------------------------------
+extern "C" int qarig_gemm_grouped_supported(int M, int N, int K, int splitk) {
+    if (M < 1 || N < 1 || K < 1 || splitk < 1 || splitk > 64) return 0;
+    if (M % BM || N % BN || K % splitk || (K / splitk) % BK || K / splitk < BK) return 0;
+    return qarig_dims_ok({M, N}) && qarig_dims_ok({M, K}) && qarig_dims_ok({N, K}) ? 1 : 0;
+}
+
+extern "C" size_t qarig_gemm_grouped_workspace_bytes(int groups, int M, int N, int splitk, int sum_groups) {
+    if (groups < 1 || groups > GEMM_MAX_GROUPS || M < 1 || N < 1 || splitk < 1 || splitk > 64) return 0;
+    const size_t ns = (size_t)groups * splitk;
+    const bool slabs = splitk > 1 || sum_groups;
+    return (slabs ? ns * M * N * sizeof(float) : 0) + ns * M * sizeof(float);
+}
+
+extern "C" int qarig_gemm_f32_grouped(int groups, const float* const* A, int64_t lda, int a_kcontig,
+                                      const float* const* B, int64_t ldb, int b_kcontig, float* const* C,
+                                      int64_t ldc, int M, int N, int K, const float* const* bias,
+                                      const float* const* residual, int64_t ldr, float* const* preact,
+                                      int64_t ldp, int act, const float* const* gradz, int64_t ldz, int gact,
+                                      int splitk, int accumulate, int sum_groups, float* const* a_rowsum,
+                                      void* workspace, size_t ws_bytes, void* stream) {
+    QARIG_CHECK_ARG(groups >= 1 && groups <= GEMM_MAX_GROUPS, "gemm_grouped: 1 <= groups <= %d (got %d)",
+                    GEMM_MAX_GROUPS, groups);
+    QARIG_CHECK_ARG(A && B && C, "gemm_grouped: null operand table");
+    if (splitk < 1) splitk = 1;
+    QARIG_CHECK_ARG(qarig_gemm_grouped_supported(M, N, K, splitk),
+                    "gemm_grouped: needs M %% 128 == 0, N %% 128 == 0 and whole 16-deep tiles per split "
+                    "(M=%d N=%d K=%d splitk=%d)", M, N, K, splitk);
+    QARIG_CHECK_ARG(act >= 0 && act <= 3 && gact >= 0 && gact <= 3, "gemm_grouped: bad activation id");
+    QARIG_CHECK_ARG(a_kcontig || !b_kcontig, "gemm_grouped: the (xc, kc) layout is not on the hot path");
+    QARIG_CHECK_ARG(!a_rowsum || !a_kcontig, "gemm_grouped: a_rowsum needs A stored [K][M]");
+    const bool plain = !bias && !residual && !preact && !gradz && act == ACT_NONE;
+    QARIG_CHECK_ARG(!(accumulate || sum_groups) || plain,
+                    "gemm_grouped: accumulate / sum_groups support the plain epilogue only");
+    QARIG_CHECK_ARG(!(sum_groups && a_rowsum), "gemm_grouped: sum_groups has no row sums");
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    QARIG_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && ldp % 4 == 0 && ldz % 4 == 0,
+                    "gemm_grouped: row strides must be multiples of 4 elements");
+    const int n_out = sum_groups ? 1 : groups;
+    GemmGroupPtrs gp;
+    for (int g = 0; g < GEMM_MAX_GROUPS; ++g) {
+        const int s = g < groups ? g : 0;
+        gp.A[g] = A[s];
+        gp.B[g] = B[s];
+        gp.C[g] = C[sum_groups ? 0 : s];
+        gp.bias[g] = bias ? bias[s] : nullptr;
+        gp.residual[g] = residual ? residual[s] : nullptr;
+        gp.preact[g] = preact ? preact[s] : nullptr;
+        gp.gradz[g] = gradz ? gradz[s] : nullptr;
+        gp.rowsum[g] = a_rowsum ? a_rowsum[s] : nullptr;
+        if (g < groups) {
+            QARIG_CHECK_ARG(gp.A[g] && gp.B[g] && (gp.C[g] || g >= n_out), "gemm_grouped: null operand in group %d", g);
+            QARIG_CHECK_ARG(al16(gp.A[g]) && al16(gp.B[g]) && al16(gp.C[g]) && al16(gp.bias[g]) &&
+                                al16(gp.residual[g]) && al16(gp.preact[g]) && al16(gp.gradz[g]),
+                            "gemm_grouped: operands must be 16-B aligned (group %d)", g);
+        }
+    }
+    const bool use_slabs = splitk > 1 || sum_groups;
+    const size_t need = qarig_gemm_grouped_workspace_bytes(groups, M, N, splitk, sum_groups);
+    if ((use_slabs || a_rowsum) && (!workspace || ws_bytes < need)) {
+        qarig_set_error("gemm_grouped: workspace too small (%zu < %zu)", ws_bytes, need);
+        return QARIG_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles_n = N / BN, tiles = (M / BM) * tiles_n;
+    const long total_wg = (long)tiles * splitk * groups;
+    QARIG_CHECK_ARG(total_wg <= (1L << 30), "gemm_grouped: grid too large");
+    float* slabs = use_slabs ? (float*)workspace : nullptr;
+    float* rs_part = a_rowsum ? (float*)workspace + (use_slabs ? (size_t)groups * splitk * M * N : 0) : nullptr;
+    if (accumulate && !use_slabs)      // C += A B^T: read-modify-write by the same lane
+        for (int g = 0; g < GEMM_MAX_GROUPS; ++g) gp.residual[g] = gp.C[g];
+    GemmEpilogue ep{nullptr, ldc, nullptr, nullptr, accumulate && !use_slabs ? ldc : ldr, nullptr, ldp, act,
+                    nullptr, ldz, gact, nullptr};
+    dim3 grid((unsigned)total_wg), block(NTHREADS);
+    if (a_kcontig && b_kcontig)
+        hipLaunchKernelGGL((gemm_dma_pf_grouped_kernel<true, true>), grid, block, 0, st, gp, lda, ldb, ep, M, N, K,
+                           tiles_n, tiles, splitk, slabs, rs_part);
+    else if (a_kcontig)
+        hipLaunchKernelGGL((gemm_dma_pf_grouped_kernel<true, false>), grid, block, 0, st, gp, lda, ldb, ep, M, N, K,
+                           tiles_n, tiles, splitk, slabs, rs_part);
+    else
+        hipLaunchKernelGGL((gemm_dma_pf_grouped_kernel<false, false>), grid, block, 0, st, gp, lda, ldb, ep, M, N,
+                           K, tiles_n, tiles, splitk, slabs, rs_part);
+    QARIG_CHECK_LAUNCH("gemm_grouped");
+    if (use_slabs || a_rowsum) {
+        const int nslab = sum_groups ? groups * splitk : splitk;
+        int nb = 0;
+        if (use_slabs) {
+            const int64_t total4 = (int64_t)M * N / 4;
+            nb = (int)((total4 + 255) / 256);
+            const int cap = n_out >= 4 ? 1024 : 2048;
+            if (nb > cap) nb = cap;
+        }
+        const int rb = a_rowsum ? (M + 255) / 256 : 0;
+        dim3 rgrid(nb + rb, n_out);
+        if (plain)
+            hipLaunchKernelGGL((slab_reduce_grouped_kernel<false>), rgrid, dim3(256), 0, st, slabs, gp, ep, M, N,
+                               nslab, accumulate, nb, rs_part);
+        else
+            hipLaunchKernelGGL((slab_reduce_grouped_kernel<true>), rgrid, dim3(256), 0, st, slabs, gp, ep, M, N,
+                               nslab, accumulate, nb, rs_part);
+        QARIG_CHECK_LAUNCH("gemm_grouped reduce");
+    }
+    return QARIG_OK;
 }
 
 // `groups` independent skinny products in one launch (decode step: the q/k/v MLPs of an

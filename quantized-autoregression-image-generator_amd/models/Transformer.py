@@ -139,6 +139,31 @@ class Transformer(nn.Module):
             return per_layer
         return [[l for group in per_layer for l in group]]
 
+    def _cross_kv_all_layers(self, enc):
+        """(k, v) of the cross-attention of EVERY decoder layer, evaluated up front as grouped
+        launches: the 2 x layers k / v MLPs (reference models/layers.py:389-418, 581-599) all read
+        the encoder output.  Single process only (None otherwise): under data parallelism each
+        layer groups its own k / v pair, so that its weight gradients are final when the layer's
+        backward is and its all-reduce bucket can leave early.  QARIG_CROSS_KV_GROUPING=all|layer
+        overrides."""
+        mode = QF.CROSS_KV_GROUPING
+        if mode is None:
+            import torch.distributed as dist
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            mode = "layer" if multi else "all"
+        if mode != "all":
+            return None
+        kvp = [layer.cross_attn_block.cross_attn.kv_params() for layer in self.decoder_layers]
+        if any(p is None for p in kvp) or len({p[2:] for p in kvp}) != 1:
+            return None
+        out = []
+        per = ops.GEMM_MAX_GROUPS // 2                 # layers per grouped launch
+        for i in range(0, len(kvp), per):
+            chunk = kvp[i:i + per]
+            res = QF.mlp2xg(enc, [blk for p in chunk for blk in p[:2]], chunk[0][2], chunk[0][3])
+            out += [(res[2 * j], res[2 * j + 1]) for j in range(len(chunk))]
+        return out
+
     def decode(self, x_dec, enc=None, pos_cond=None, pos_bound=None):
         table = self.dec_embedding.weight
         N, S = x_dec.shape
@@ -148,6 +173,9 @@ class Transformer(nn.Module):
         if self.use_pos_cond:
             cond = self._cond(pos_cond, N, S, D, pos_bound)
         ckpt = self.use_activation_checkpoint and torch.is_grad_enabled()
+        kvs = None
+        if enc is not None and self.use_encoder and not ckpt and torch.is_grad_enabled():
+            kvs = self._cross_kv_all_layers(enc)
         per_layer = self._cond_linears_per_layer() if ckpt and isinstance(cond, QF.CondTable) else None
         for li, layer in enumerate(self.decoder_layers):
             if ckpt:
@@ -159,7 +187,8 @@ class Transformer(nn.Module):
                 x = checkpoint.checkpoint(layer, x, cross_cond=enc, pos_cond=cond,
                                           use_reentrant=False)
             else:
-                x = layer(x=x, cross_cond=enc, pos_cond=cond)
+                x = layer(x=x, cross_cond=enc, pos_cond=cond,
+                          cross_kv=kvs[li] if kvs is not None else None)
         return _mlp2_forward(self.classifier, x)
 
     def forward(self, x_dec, x_enc=None, pos_cond=None, pos_bound=None):

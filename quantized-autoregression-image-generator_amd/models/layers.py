@@ -253,7 +253,19 @@ class AttentionLayer(nn.Module):
         self.k_block = block(cross_cond_dim)
         self.v_block = block(cross_cond_dim)
 
-    def forward(self, x, cross_cond=None):
+    def kv_params(self):
+        """((w1, b1, w2, b2) of k_block, the same of v_block, act1, act2) when the two blocks can
+        run as grouped launches on their common input (same activations), else None."""
+        kb, vb = self.k_block, self.v_block
+        if (kb[0]._act, kb[1]._act) != (vb[0]._act, vb[1]._act):
+            return None
+        return ((*_lin_params(kb[0]), *_lin_params(kb[1])), (*_lin_params(vb[0]), *_lin_params(vb[1])),
+                kb[0]._act, kb[1]._act)
+
+    def forward(self, x, cross_cond=None, kv=None):
+        """kv (additive): (k, v) already evaluated by the caller -- the cross-attention k / v MLPs of
+        every decoder layer read the same encoder output, so models.Transformer evaluates them for
+        all layers at once."""
         if not self.use_cross_attn:      # q, k, v from the same rows: one autograd node
             blocks = (self.q_block, self.k_block, self.v_block)
             if len({(b[0]._act, b[1]._act) for b in blocks}) == 1:
@@ -262,8 +274,15 @@ class AttentionLayer(nn.Module):
                 return QF.attention(q, k, v, self.heads, self.use_masked_attn)
         src = cross_cond if self.use_cross_attn else x
         q = _mlp2_forward(self.q_block, x)
-        k = _mlp2_forward(self.k_block, src)
-        v = _mlp2_forward(self.v_block, src)
+        if kv is not None:
+            k, v = kv
+        else:
+            kvp = self.kv_params()
+            if kvp is not None:          # k and v from the same rows: grouped launches
+                k, v = QF.mlp2xg(src, kvp[:2], kvp[2], kvp[3])
+            else:
+                k = _mlp2_forward(self.k_block, src)
+                v = _mlp2_forward(self.v_block, src)
         return QF.attention(q, k, v, self.heads, self.use_masked_attn)
 
 
@@ -309,9 +328,9 @@ class CrossAttentionBlock(nn.Module):
             in_dim=in_dim, out_dim=in_dim, skip_dim=in_dim, cond_dim=cond_dim,
             use_scale_layer=use_scale_layer, activation_type=activation_type)
 
-    def forward(self, x, cross_cond, cond=None):
+    def forward(self, x, cross_cond, cond=None, kv=None):
         h, xs = _norm_forward(self.cross_attn_norm, x, cond, self.use_adaln0)
-        h = self.cross_attn(x=h, cross_cond=cross_cond)
+        h = self.cross_attn(x=h, cross_cond=cross_cond, kv=kv)
         return self.cross_attn_res(x=h, cond=cond, x_skip=xs)
 
 
@@ -336,8 +355,8 @@ class TransformerBlock(nn.Module):
             in_dim=in_dim, hidden_dim=hidden_dim, use_adaln0=use_adaln0, cond_dim=cond_dim,
             use_scale_layer=use_scale_layer, activation_type=activation_type)
 
-    def forward(self, x, cross_cond=None, pos_cond=None):
+    def forward(self, x, cross_cond=None, pos_cond=None, cross_kv=None):
         x = self.self_attn_block(x, cond=pos_cond)
         if self.use_cross_attn:
-            x = self.cross_attn_block(x, cond=pos_cond, cross_cond=cross_cond)
+            x = self.cross_attn_block(x, cond=pos_cond, cross_cond=cross_cond, kv=cross_kv)
         return self.feedforward_block(x, cond=pos_cond)

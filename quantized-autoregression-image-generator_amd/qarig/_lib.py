@@ -30,6 +30,10 @@ SIGNATURES = {
     "qarig_gemm_workspace_bytes": (Z, [I, I, I]),
     "qarig_gemm_f32": (I, [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, I, P, P, Z,
                            P]),
+    "qarig_gemm_grouped_supported": (I, [I, I, I, I]),
+    "qarig_gemm_grouped_workspace_bytes": (Z, [I, I, I, I, I]),
+    "qarig_gemm_f32_grouped": (I, [I, P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, I, I, P,
+                                   P, Z, P]),
     "qarig_gemm_lp_supported": (I, [I, I, I, I]),
     "qarig_gemm_lp_workspace_bytes": (Z, [I, I, I]),
     "qarig_gemm_lp": (I, [P, L, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, I, I, P, L, P, L, P, Z,
@@ -51,7 +55,7 @@ SIGNATURES = {
     "qarig_som_band": (I, [P, I, I, F, I, P, P]),
     "qarig_index_histogram": (I, [P, L, I, P, P, P]),
     "qarig_posemb_fwd": (I, [P, I, I, P, P, P]),
-    "qarig_assemble_tokens": (I, [P, I, P, I, I, I, I, I, P, I, P, P, P, P]),
+    "qarig_assemble_tokens": (I, [P, I, P, I, I, I, I, I, P, I, P, P, P, P, P]),
     "qarig_embedding_fwd": (I, [P, I, I, I, I, P, P, P, P, P]),
     "qarig_embedding_bwd": (I, [P, I, I, I, P, P, P]),
     "qarig_layernorm_fwd": (I, [P, I, I, F, P, P, P, P, P, P, P, P, P]),

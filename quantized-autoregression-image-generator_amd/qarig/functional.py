@@ -285,10 +285,144 @@ class _MLP2x3(torch.autograd.Function):
         return (dx, None, None, *grads)
 
 
-def mlp2x3(x, blocks_params, act1, act2=0):
+# Grouped launches for MLPs that share their input (csrc/gemm.hip gemm_dma_pf_grouped_kernel): taken when
+# the per-product tile count leaves the chip under-filled (M = a few thousand rows: the per-GPU shard
+# of a small global batch).  QARIG_MLP_GROUPED=0 disables, =1 forces it on every supported shape.
+MLP_GROUPED = os.environ.get("QARIG_MLP_GROUPED")
+# cross-attention k / v MLPs: "all" (every decoder layer's pair in one grouped launch, evaluated
+# before the layer loop), "layer" (each layer its own pair) or None = "layer" under torch.distributed
+# with more than one rank, else "all" (models/Transformer.py _cross_kv_all_layers)
+CROSS_KV_GROUPING = os.environ.get("QARIG_CROSS_KV_GROUPING") or None
+MLP_GROUPED_MAX_ROWS = 8192
+
+
+class _MLP2xG(torch.autograd.Function):
+    """G two-layer MLPs y_g = act2(act1(x W1_g^T + b1_g) W2_g^T + b2_g) on ONE input x, all of one
+    shape: the q / k / v blocks of a self-attention layer, or the cross-attention k / v blocks of
+    one or of every decoder layer (reference models/layers.py:389-418, :581-599).  Every product --
+    both forward layers, dT1, dx (the sum over the G blocks, in block order), both weight gradients
+    with their bias gradients -- is ONE grouped launch (+ one grouped reduce where the reduction is
+    split) instead of G; the hidden tensors of the G blocks are slices of one allocation."""
+
+    @staticmethod
+    def forward(ctx, x, act1, act2, *params):
+        require_cuda(x, *params)
+        G = len(params) // 4
+        shp = x.shape
+        x2 = _2d(f32c(x))
+        M, D = x2.shape
+        w1s, b1s, w2s, b2s = params[0::4], params[1::4], params[2::4], params[3::4]
+        H, O = w1s[0].shape[0], w2s[0].shape[0]
+        dev = x2.device
+        hs = torch.empty((G, M, H), dtype=torch.float32, device=dev)
+        t1s = torch.empty((G, M, H), dtype=torch.float32, device=dev)
+        ops.gemm_grouped([x2] * G, w1s, list(hs.unbind(0)), M, H, D, bias=b1s, preact=list(t1s.unbind(0)),
+                         act=act1, splitk=ops.grouped_splitk(G, M, H, D))
+        ys = torch.empty((G, M, O), dtype=torch.float32, device=dev)
+        t2s = torch.empty((G, M, O), dtype=torch.float32, device=dev) if act2 else None
+        ops.gemm_grouped(list(hs.unbind(0)), w2s, list(ys.unbind(0)), M, O, H, bias=b2s,
+                         preact=list(t2s.unbind(0)) if act2 else None, act=act2,
+                         splitk=ops.grouped_splitk(G, M, O, H))
+        ctx.save_for_backward(x2, hs, t1s, t2s if act2 else x2.new_empty(0))
+        ctx.act1, ctx.act2, ctx.G = act1, act2, G
+        ctx.params = params
+        return tuple(y.reshape(*shp[:-1], O) for y in ys.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x2, hs, t1s, t2s = ctx.saved_tensors
+        G = ctx.G
+        params = ctx.params
+        w1s, b1s, w2s, b2s = params[0::4], params[1::4], params[2::4], params[3::4]
+        M, D = x2.shape
+        H, O = w1s[0].shape[0], w2s[0].shape[0]
+        dev = x2.device
+        dT2 = [_2d(f32c(d)) for d in dys]
+        if ctx.act2:
+            dT2 = [ops.act_bwd(d, t2s[g], ctx.act2) for g, d in enumerate(dT2)]
+        h = list(hs.unbind(0))
+        # dT1_g = (dT2_g W2_g) * act1'(t1_g)
+        dT1s = torch.empty((G, M, H), dtype=torch.float32, device=dev)
+        dT1 = list(dT1s.unbind(0))
+        ops.gemm_grouped(dT2, w2s, dT1, M, H, O, a_kcontig=True, b_kcontig=False, gradz=list(t1s.unbind(0)),
+                         gact=ctx.act1, splitk=ops.grouped_splitk(G, M, H, O))
+
+        def wgrads(dT, X, ws, bs, No, Ko):
+            """dW_g (No, Ko) = dT_g^T X_g over the M rows, db_g = column sums of dT_g."""
+            wslots, bslots = [_grad_slot(p) for p in ws], [_grad_slot(p) for p in bs]
+            inplace = all(s is not None for s in wslots) and all(s is not None for s in bslots)
+            if inplace:
+                outs, rsum = wslots, bslots
+            else:
+                dw = torch.empty((G, No, Ko), dtype=torch.float32, device=dev)
+                db = torch.empty((G, No), dtype=torch.float32, device=dev)
+                outs, rsum = list(dw.unbind(0)), list(db.unbind(0))
+            ops.gemm_grouped(dT, X, outs, No, Ko, M, a_kcontig=False, b_kcontig=False, accumulate=inplace,
+                             a_rowsum=rsum, splitk=ops.grouped_splitk(G, No, Ko, M))
+            if inplace:
+                for p in (*ws, *bs):
+                    _report_done(p)
+                return [None] * G, [None] * G
+            return outs, rsum
+
+        dw2, db2 = wgrads(dT2, h, w2s, b2s, O, H)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, D), dtype=torch.float32, device=dev)
+            ops.gemm_grouped(dT1, w1s, [dx], M, D, H, a_kcontig=True, b_kcontig=False, sum_groups=True,
+                             splitk=ops.grouped_splitk(G, M, D, H))
+            dx = dx.reshape(*dys[0].shape[:-1], D)
+        dw1, db1 = wgrads(dT1, [x2] * G, w1s, b1s, H, D)
+        grads = []
+        for g in range(G):
+            grads += [dw1[g], db1[g], dw2[g], db2[g]]
+        return (dx, None, None, *grads)
+
+
+def _mlp_group_ok(x, blocks_params, M):
+    """Same-shape blocks on dense 16-B aligned fp32 parameters that all want gradients, at a row
+    count where one product alone under-fills the chip, on shapes the grouped kernel takes."""
+    if MLP_GROUPED == "0" or ops.lp_mode() or not 2 <= len(blocks_params) <= ops.GEMM_MAX_GROUPS:
+        return False
+    if MLP_GROUPED != "1" and M > MLP_GROUPED_MAX_ROWS:
+        return False
+    w1, b1, w2, b2 = blocks_params[0]
+    if b1 is None or b2 is None or w1.dim() != 2 or w2.dim() != 2 or w2.shape[1] != w1.shape[0]:
+        return False
+    for p in blocks_params:
+        if (p[0].shape != w1.shape or p[2].shape != w2.shape or p[1] is None or p[3] is None
+                or p[1].shape != (w1.shape[0],) or p[3].shape != (w2.shape[0],)):
+            return False
+        for t in p:
+            if (t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16
+                    or not t.requires_grad or not t.is_cuda):
+                return False
+    H, D = w1.shape
+    O = w2.shape[0]
+    sup = ops.gemm_grouped_supported
+    G = len(blocks_params)
+    return (x.shape[-1] == D and sup(M, H, D, ops.grouped_splitk(G, M, H, D))
+            and sup(M, O, H, ops.grouped_splitk(G, M, O, H)) and sup(M, H, O, ops.grouped_splitk(G, M, H, O))
+            and sup(M, D, H, ops.grouped_splitk(G, M, D, H)) and sup(O, H, M, ops.grouped_splitk(G, O, H, M))
+            and sup(H, D, M, ops.grouped_splitk(G, H, D, M)))
+
+
+def mlp2xg(x, blocks_params, act1, act2=0):
+    """blocks_params: G (w1, b1, w2, b2) tuples of one shape, all applied to x.  Returns G tensors."""
+    M = x.numel() // x.shape[-1]
+    if not _no_grad() and _mlp_group_ok(x, blocks_params, M):
+        return _MLP2xG.apply(x, act1, act2, *[t for p in blocks_params for t in p])
+    if len(blocks_params) == 3:
+        return mlp2x3(x, blocks_params, act1, act2, _grouped=False)
+    return tuple(mlp2(x, *p, act1, act2) for p in blocks_params)
+
+
+def mlp2x3(x, blocks_params, act1, act2=0, _grouped=True):
     """blocks_params: three (w1, b1, w2, b2) tuples (q, k, v).  Returns (q, k, v)."""
     if _no_grad():
         return tuple(mlp2(x, *p, act1, act2) for p in blocks_params)
+    if _grouped and _mlp_group_ok(x, blocks_params, x.numel() // x.shape[-1]):
+        return _MLP2xG.apply(x, act1, act2, *[t for p in blocks_params for t in p])
     if ops.lp_mode() and all(_lp().mlp2_supported(x, p[0], p[2]) and p[2].shape[0] % 128 == 0
                                        for p in blocks_params):
         return _lp()._MLP2x3LP.apply(x, act1, act2, *[t for p in blocks_params for t in p])

@@ -33,17 +33,18 @@ def _shadow(w, transpose=False, pad_rows=0):
     pad_rows output rows (ragged classifier widths).  Cached until the next optimiser step."""
     if pad_rows and pad_rows != w.shape[0]:
         key = ("p", w.data_ptr(), tuple(w.shape), pad_rows, transpose, w._version, ops.LP_EPOCH)
-        hit = None if torch.cuda.is_current_stream_capturing() else ops._lp_cache.get(key)
+        hit = None if torch.cuda.is_current_stream_capturing() else ops._lp_get(key, w)
         if hit is not None:
             return hit
         wp = torch.zeros((pad_rows, w.shape[1]), dtype=torch.float32, device=w.device)
         wp[:w.shape[0]].copy_(w.detach())
         out = ops.cast_transpose_bf16(wp) if transpose else ops.cast_bf16(wp)
         if not torch.cuda.is_current_stream_capturing():
-            ops._lp_cache[key] = out
+            ops._lp_put(key, w, out)
         return out
     wd = w.detach()
     wd._qarig_weight = True
+    wd._qarig_src = w            # the cache entry is tied to the parameter, not to this temporary
     return ops.cast_transpose_bf16(wd, cache=True) if transpose else ops.cast_bf16(wd, cache=True)
 
 
@@ -64,6 +65,7 @@ def _fwd_nt(xq, xb, w, M, N, K, **epi):
     if xq is not None:
         wd = w.detach()
         wd._qarig_weight = True
+        wd._qarig_src = w
         w8, sw = ops.cast_fp8(wd, cache=True)
         ops.gemm_f8(xq[0], xq[1], w8, sw, M, N, K, **epi)
     else:

@@ -135,10 +135,30 @@ _lp_cache = {}
 
 
 def lp_invalidate():
+    """Every key carries LP_EPOCH, so all entries are dead after the bump: drop them (and the device
+    memory they hold) right away."""
     global LP_EPOCH
     LP_EPOCH += 1
-    if len(_lp_cache) > 4096:
-        _lp_cache.clear()
+    _lp_cache.clear()
+
+
+def _lp_get(key, src):
+    """Cached shadow of `src` under `key`, or None.  Keys name a tensor by address / shape / version
+    only, and an address can be handed to another tensor of the same shape once its owner is freed
+    (a second model built in the same process): an entry therefore also holds a weak reference to
+    the tensor it was made from and only serves that very tensor."""
+    hit = _lp_cache.get(key)
+    if hit is None:
+        return None
+    if hit[0]() is not src:
+        del _lp_cache[key]
+        return None
+    return hit[1]
+
+
+def _lp_put(key, src, value):
+    import weakref
+    _lp_cache[key] = (weakref.ref(src), value)
 
 
 def cast_bf16(x, cache=False):
@@ -146,14 +166,15 @@ def cast_bf16(x, cache=False):
     assert x.dtype == torch.float32 and x.is_contiguous()
     key = None
     if cache and not torch.cuda.is_current_stream_capturing():
+        src = getattr(x, "_qarig_src", x)
         key = ("n", x.data_ptr(), tuple(x.shape), x._version, LP_EPOCH)
-        hit = _lp_cache.get(key)
+        hit = _lp_get(key, src)
         if hit is not None:
             return hit
     out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     check(_lib.load().qarig_cast_bf16(ptr(x), ptr(out), x.numel(), stream()), "qarig_cast_bf16")
     if key is not None:
-        _lp_cache[key] = out
+        _lp_put(key, src, out)
     return out
 
 
@@ -164,8 +185,9 @@ def cast_fp8(x, cache=False, want_bf16=False):
     assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 4 == 0
     key = None
     if cache and not torch.cuda.is_current_stream_capturing():
+        src = getattr(x, "_qarig_src", x)
         key = ("f8", x.data_ptr(), tuple(x.shape), x._version, LP_EPOCH)
-        hit = _lp_cache.get(key)
+        hit = _lp_get(key, src)
         if hit is not None:
             return hit
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
@@ -175,7 +197,7 @@ def cast_fp8(x, cache=False, want_bf16=False):
                                      stream()), "qarig_cast_fp8")
     res = (out, aux[:1], xb) if want_bf16 else (out, aux[:1])
     if key is not None:
-        _lp_cache[key] = res
+        _lp_put(key, src, res)
     return res
 
 
@@ -208,8 +230,9 @@ def cast_transpose_bf16(x, cache=False):
     assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     key = None
     if cache and not torch.cuda.is_current_stream_capturing():
+        src = getattr(x, "_qarig_src", x)
         key = ("t", x.data_ptr(), tuple(x.shape), x.stride(0), x._version, LP_EPOCH)
-        hit = _lp_cache.get(key)
+        hit = _lp_get(key, src)
         if hit is not None:
             return hit
     R, Cc = x.shape
@@ -217,7 +240,7 @@ def cast_transpose_bf16(x, cache=False):
     check(_lib.load().qarig_cast_transpose_bf16(ptr(x), x.stride(0), R, Cc, ptr(out), stream()),
           "qarig_cast_transpose_bf16")
     if key is not None:
-        _lp_cache[key] = out
+        _lp_put(key, src, out)
     return out
 
 
@@ -335,6 +358,79 @@ def gemm_grouped_skinny(A, W, bias=None, act=0, shared_a=False):
         ptr(A), K, a_gs, ptr(W), K, N * K, ptr(C), N, M * N, ptr(bias), N, G, M, N, K, act,
         stream()), "qarig_gemm_grouped_skinny_f32")
     return C
+
+
+GEMM_MAX_GROUPS = 16          # csrc/gemm.hip GEMM_MAX_GROUPS
+
+
+def grouped_splitk(groups, M, N, K):
+    """Reduction split of a grouped launch of `groups` (M, N, K) products: 1 when the groups alone
+    fill the chip twice over, else the smallest split whose workgroup count is at least 512 and a
+    (near) multiple of the 256 CUs -- co-resident workgroups share a CU's matrix pipes, so the
+    launch lasts as long as its busiest CU."""
+    tiles = groups * ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 512:
+        return 1
+    best, best_eff = 1, 0.0
+    for s in (1, 2, 3, 4, 6, 8, 12, 16):
+        if K % (16 * s) or K // s < 128:
+            continue
+        wg = tiles * s
+        eff = wg / (-(-wg // 256) * 256)
+        if wg >= 512 and eff >= 0.95:
+            return s
+        if eff > best_eff + 1e-9:
+            best, best_eff = s, eff
+    return best
+
+
+def gemm_grouped_supported(M, N, K, splitk=1):
+    return not lp_mode() and bool(_lib.load().qarig_gemm_grouped_supported(M, N, K, splitk))
+
+
+def _ptr_table(tensors, G):
+    if tensors is None:
+        return None
+    assert len(tensors) == G
+    return (_lib.P * G)(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
+def gemm_grouped(A, B, C, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, residual=None, preact=None,
+                 act=0, gradz=None, gact=0, splitk=1, accumulate=False, sum_groups=False, a_rowsum=None):
+    """`len(A)` products of one shape in one launch (include/qarig.h qarig_gemm_f32_grouped): lists
+    of fp32 tensors per group (A / B entries may repeat), outputs in the tensors of C (one tensor
+    when sum_groups).  Operands must be dense row-major with a common row stride."""
+    G = len(A)
+    assert 1 <= G <= GEMM_MAX_GROUPS and len(B) == G
+    require_cuda(*A, *B, *C)
+    lda, ldb, ldc = A[0].stride(0), B[0].stride(0), C[0].stride(0)
+    for t in (*A, *B, *C, *(bias or ()), *(residual or ()), *(preact or ()), *(gradz or ()), *(a_rowsum or ())):
+        assert t.dtype == torch.float32 and t.stride(-1) == 1
+    assert all(t.stride(0) == lda for t in A) and all(t.stride(0) == ldb for t in B)
+    assert all(t.stride(0) == ldc and t.shape == (M, N) for t in C) and len(C) == (1 if sum_groups else G)
+    ld = lambda ts: ts[0].stride(0) if ts else 0   # noqa: E731
+    for ts in (residual, preact, gradz):
+        if ts:
+            assert all(t.stride(0) == ts[0].stride(0) and t.shape == (M, N) for t in ts)
+    lib = _lib.load()
+    ws, nws = None, 0
+    if splitk > 1 or sum_groups or a_rowsum is not None:
+        nws = lib.qarig_gemm_grouped_workspace_bytes(G, M, N, splitk, int(sum_groups))
+        ws = workspace(nws, A[0].device, "gemm")
+        nws = ws.numel()
+    if GEMM_EVENTS is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    Ct = list(C) + [C[0]] * (G - len(C))
+    check(lib.qarig_gemm_f32_grouped(
+        G, _ptr_table(A, G), lda, int(a_kcontig), _ptr_table(B, G), ldb, int(b_kcontig), _ptr_table(Ct, G), ldc,
+        M, N, K, _ptr_table(bias, G), _ptr_table(residual, G), ld(residual), _ptr_table(preact, G), ld(preact),
+        act, _ptr_table(gradz, G), ld(gradz), gact, splitk, int(accumulate), int(sum_groups),
+        _ptr_table(a_rowsum, G), ptr(ws), nws, stream()), "qarig_gemm_f32_grouped")
+    if GEMM_EVENTS is not None:
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record()
+        GEMM_EVENTS.append((2.0 * G * M * N * K, ev0, ev1))
 
 
 def colsum(X, out=None, accumulate=False):
@@ -558,7 +654,8 @@ def assemble_tokens(lr_idx, hr_idx, base, k_lr, k_hr, offs=None, window=None):
         assert offs.shape == (N,)
     check(_lib.load().qarig_assemble_tokens(ptr(lr_idx) if base else None, S_lr, ptr(hr_idx), S_hr, N,
                                             int(base), int(k_lr), int(k_hr), ptr(offs), W, ptr(hr_in),
-                                            ptr(hr_tg), ptr(pos), stream()), "qarig_assemble_tokens")
+                                            ptr(hr_tg), ptr(pos), ptr(_bad_flag(dev)), stream()),
+          "qarig_assemble_tokens")
     return hr_in, hr_tg, pos
 
 

@@ -149,9 +149,14 @@ class FlatAdam:
         ops.lp_invalidate()
 
     def advance_captured(self):
+        """Called before every replay of a captured step: the replayed Adam kernel rewrites the
+        parameters without touching torch's version counters, so the reduced-precision weight
+        shadows an eager forward may have cached (per-checkpoint sampling between replays) are stale
+        from here on."""
         self.step_count += 1
         step_size, bc2_sqrt = self._step_scalars(self.step_count)
         self._dev_step_buffer().copy_(torch.tensor([step_size, bc2_sqrt], dtype=torch.float32))
+        ops.lp_invalidate()
 
     def state_dict(self):
         state = {}

@@ -334,3 +334,60 @@ def test_bf16_train_step_tracks_fp32_step():
     cos = float((gf * gb).sum() / (gf.norm() * gb.norm()))
     assert cos > 0.999, cos
     assert not torch.equal(gf, gb)
+
+
+def test_weight_shadows_follow_captured_graph_replays(bf16_mode):
+    """Graph-replayed training (pipeline.GraphedTrainStep) rewrites the parameters from a HIP kernel
+    without touching torch's version counters: an eager no_grad forward between replays (the
+    per-checkpoint sampling of train_quantized_transformer.py) must see the CURRENT weights, not the
+    bf16 shadows it cached at an earlier evaluation.  Reference of each evaluation: a second model
+    loaded with the current fp32 weights (its own, fresh shadows)."""
+    from models.Codebook import Codebook
+    from models.Transformer import Transformer
+    from qarig import pipeline
+    from qarig.optim import FlatAdam
+
+    def build_model():
+        torch.manual_seed(3)
+        m = Transformer(use_encoder=False, use_pos_cond=True, num_enc_layers=None, num_dec_layers=1,
+                        num_enc_embedding=None, num_dec_embedding=128 + 128, self_attn_heads=16,
+                        cross_attn_heads=None, transformer_in_dim=128, transformer_out_dim=129,
+                        transformer_hidden_dim=256).cuda()
+        g = torch.Generator().manual_seed(6)
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.abs().max() == 0:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        return m
+
+    g = torch.Generator().manual_seed(4)
+    lr_cb = Codebook(patch_dim=(16, 16), image_dim=(16, 16), image_channel=4, num_embeddings=128).cuda()
+    hr_cb = Codebook(patch_dim=(1, 1), image_dim=(16, 16), image_channel=4, num_embeddings=128).cuda()
+    with torch.no_grad():
+        lr_cb.codebook.weight.copy_(torch.tanh(torch.randn((128, 1024), generator=g)))
+        hr_cb.codebook.weight.copy_(torch.tanh(torch.randn((128, 4), generator=g)))
+    m = build_model()
+    opt = FlatAdam(m.parameters(), lr=1e-2, betas=(0.5, 0.999))
+    step = pipeline.GraphedTrainStep(m, opt, lr_cb, hr_cb, True, 128, warmup=1)
+    xe = torch.randint(0, 256, (4, 128), generator=g).cuda()
+    pe = torch.arange(128)[None].repeat(4, 1).cuda()
+
+    def evaluate(model):
+        with torch.no_grad():
+            return model(xe, None, pe, pos_bound=257).clone()
+
+    def fresh_copy_eval():
+        twin = build_model()
+        twin.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+        return evaluate(twin)
+
+    outs = []
+    for it in range(4):
+        z = torch.tanh(torch.randn((4, 4, 16, 16), generator=g)).cuda()
+        rand = torch.randint(0, 257 - 128 + 1, (4,), generator=g)
+        step(z, rand)
+        got = evaluate(m)          # caches the weight shadows of THIS moment
+        assert torch.equal(got, fresh_copy_eval()), f"stale shadows after step {it}"
+        outs.append(got)
+    assert step.graph is not None
+    assert not torch.equal(outs[-1], outs[-2])      # the replays did move the weights

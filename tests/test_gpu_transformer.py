@@ -393,6 +393,57 @@ def test_readme_block_sizes_train_step_grads_vs_oracle(cond_table):
     assert worst < 2e-4, worst   # fp32 vs fp32 with different summation orders, K up to 2048
 
 
+@pytest.mark.parametrize("kv_grouping", ["all", "layer"])
+def test_readme_block_sizes_encdec_train_step_grads_vs_oracle(cond_table, kv_grouping):
+    """The enc-dec stage at README block sizes (512 / 2048 / 64 + 64 heads of 8), 2 decoder + 1 encoder
+    layers, 2 x 256 decoder tokens against 256 encoder tokens (reference models/layers.py:538-599: cross
+    attention dQ / dK / dV with Sk = S_enc, the k / v MLPs on the encoder output): loss and EVERY
+    parameter gradient against the CPU oracle, with the cross-attention k / v MLPs grouped per layer and
+    over all layers (2,048-row shapes: the grouped launches are on)."""
+    from models.Transformer import Transformer
+    from oracle import ref_models as rm
+    from qarig import functional as QF
+    from qarig.optim import FlatAdam
+    torch.manual_seed(6)
+    m = Transformer(use_encoder=True, use_pos_cond=True, num_enc_layers=1, num_dec_layers=2,
+                    num_enc_embedding=512, num_dec_embedding=513, self_attn_heads=64,
+                    cross_attn_heads=64, transformer_in_dim=512, transformer_out_dim=513,
+                    transformer_hidden_dim=2048)
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.abs().max() == 0:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.02)
+    N, S, S_enc = 2, 256, 256
+    x = torch.randint(0, 513, (N, S), generator=gen)
+    x_enc = torch.randint(0, 512, (N, S_enc), generator=gen)
+    t = torch.randint(0, 513, (N, S), generator=gen)
+    pos = torch.randint(0, 2, (N, 1), generator=gen) + torch.arange(S)[None]
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    cfg = dict(use_encoder=True, use_pos_cond=True, num_enc_layers=1, num_dec_layers=2, self_attn_heads=64,
+               cross_attn_heads=64, hidden_activation="silu")
+    ref_loss = rm.cross_entropy(rm.transformer_forward(sd, cfg, x, x_enc, pos), t)
+    ref_loss.backward()
+    m = m.cuda()
+    opt = FlatAdam(m.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    opt.zero_grad()
+    old = QF.CROSS_KV_GROUPING
+    try:
+        QF.CROSS_KV_GROUPING = kv_grouping
+        logits = m(x.cuda(), x_enc.cuda(), pos.cuda())
+        loss = QF.cross_entropy(logits.view(-1, 513), t.cuda().flatten())
+        loss.backward()
+    finally:
+        QF.CROSS_KV_GROUPING = old
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-5
+    worst, worst_name = 0.0, None
+    for n, p in m.named_parameters():
+        e = grad_err(p.grad, sd[n].grad, floor=1e-7)
+        if e > worst:
+            worst, worst_name = e, n
+    assert worst < 2e-4, (worst, worst_name)   # fp32 vs fp32 with different summation orders, K up to 2048
+
+
 def test_mlp2_ragged_wide_output_runs_padded_and_matches_fp64():
     """The classifier shape class (many rows, 513 = K_hr + 1 output columns): _MLP2 runs its second
     layer on zero-padded weights so that forward, d-input and d-weight take the interior kernels;

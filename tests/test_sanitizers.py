@@ -21,6 +21,10 @@ lib = ctypes.CDLL(sys.argv[1])
 P, I, L, Z, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 calls = 0
 statuses = {}
+# arguments that are HOST arrays of device pointers (read by the host side): given a real 16-entry table
+HOST_TABLES = {"qarig_gemm_f32_grouped": (1, 4, 7, 12, 13, 15, 18, 24)}
+def table(p):
+    return (P * 16)(*[p] * 16)
 for name, (res, args) in sorted(_lib.SIGNATURES.items()):
     fn = getattr(lib, name)
     fn.restype, fn.argtypes = res, args
@@ -29,8 +33,9 @@ for name, (res, args) in sorted(_lib.SIGNATURES.items()):
     ints = [i for i, a in enumerate(args) if a in (I, L, Z)]
     def build(ptr, ival, fval):
         out = []
-        for a in args:
-            if a is P: out.append(ptr)
+        for i, a in enumerate(args):
+            if a is P and i in HOST_TABLES.get(name, ()): out.append(table(ptr) if ptr is not None else None)
+            elif a is P: out.append(ptr)
             elif a is F: out.append(fval)
             elif a is ctypes.c_char_p: out.append(None)
             else: out.append(ival)
@@ -73,6 +78,14 @@ call("qarig_cast_fp8", X, 16384 * 512, X, X, X, X, None)
 for (M, N, K, ak, bk, sk) in ((2048, 2048, 512, 1, 1, 1), (2048, 512, 2048, 0, 0, 4)):      # the paired kernel's launches
     call("qarig_gemm_f32", X, K if ak else M, ak, X, K if bk else N, bk, X, N, M, N, K, None, None, 0, None, 0, 0,
          None, 0, 0, sk, 0, None, X, 1 << 40, None)
+# grouped launches: q/k/v forward, second layer with a split reduction, the summed input gradient of 14 blocks,
+# weight gradients with row sums
+for (G, M, N, K, ak, bk, sk, sumg, rs) in ((3, 2048, 2048, 512, 1, 1, 1, 0, 0), (3, 2048, 512, 2048, 1, 1, 4, 0, 0),
+                                           (14, 2048, 512, 2048, 1, 0, 1, 1, 0), (3, 512, 2048, 2048, 0, 0, 4, 0, 1),
+                                           (16, 2048, 2048, 512, 1, 0, 1, 0, 0)):
+    call("qarig_gemm_f32_grouped", G, table(X), K if ak else M, ak, table(X), K if bk else N, bk, table(X), N, M, N, K,
+         table(X) if ak and bk else None, None, 0, None, 0, 0, None, 0, 0, sk, rs, sumg, table(X) if rs else None,
+         X, 1 << 40, None)
 for (N, C, H, W, p, K) in ((64, 4, 32, 32, 2, 512), (64, 4, 32, 32, 32, 512), (64, 4, 64, 64, 1, 8192), (3, 4, 12, 20, 2, 77)):
     call("qarig_bmu_fwd", X, N, C, H, W, p, p, X, K, C * p * p, X, X, 1 << 40, None)
 for (N, Sq, Sk, H, d, causal) in ((64, 256, 256, 64, 8, 1), (2, 4096, 4096, 64, 8, 1), (2, 4096, 1024, 64, 8, 0),
