@@ -1,0 +1,147 @@
+"""The gfx950 machine code of lib/libqarig_hip.so under tools/isa_lint.py (no GPU): hazards around
+inline-asm MFMAs, loads consumed before their s_waitcnt, hand-set M0 mixed with compiler-managed M0.
+VERDICT round 2, weak #9: two GPU-side failures of round 2 came from exactly these invariants, which
+lived in hand-placed s_nops and operand-tied waits; this makes them a property of the build.
+First the checks are shown to FIRE on minimal listings (a lint that reports nothing proves nothing),
+then the whole library must be clean."""
+import os
+import sys
+
+from conftest import PKG, ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _run(text):
+    import isa_lint as L
+    code, labels = L.parse_listing(text)
+    return (L.check_hazards("k", code, labels), L.check_waitcnt("k", code, labels), L.check_m0("k", code))
+
+
+def test_r1_valu_write_then_mfma_source():
+    bad = """
+        v_mov_b32_e32 v1, v2
+        v_mfma_f32_32x32x2_f32 v[4:19], v1, v3, v[4:19]
+    """
+    assert any(f.startswith("R1") for f in _run(bad)[0])
+    one_state = bad.replace("v_mfma", "s_nop 0\n        v_mfma")
+    assert any(f.startswith("R1") for f in _run(one_state)[0])
+    good = bad.replace("v_mfma", "s_nop 1\n        v_mfma")
+    assert not _run(good)[0]
+    # the write reaches the MFMA through a taken branch
+    branch = """
+        v_cndmask_b32_e32 v1, v2, v3, vcc
+        s_cbranch_scc1 L1
+        s_nop 4
+        L1:
+        v_mfma_f32_4x4x1_16b_f32 v[4:7], v1, v3, v[4:7]
+    """
+    assert any(f.startswith("R1") for f in _run(branch)[0])
+
+
+def test_r2_mfma_result_needs_its_passes():
+    chain = """
+        v_mfma_f32_32x32x2_f32 v[0:15], v40, v41, v[0:15]
+        v_mfma_f32_32x32x2_f32 v[16:31], v40, v42, v[16:31]
+        v_mfma_f32_32x32x2_f32 v[0:15], v43, v41, v[0:15]
+        s_nop 15
+        s_nop 1
+        v_add_f32_e32 v50, v0, v0
+    """
+    assert not _run(chain)[0]                      # accumulate chains and a drained read are fine
+    early = chain.replace("s_nop 1\n", "")
+    assert any(f.startswith("R2") for f in _run(early)[0])     # 16 wait states < 18
+    overwrite = """
+        v_mfma_f32_4x4x1_16b_f32 v[0:3], v8, v9, v[0:3]
+        v_mov_b32_e32 v2, 0
+    """
+    assert any(f.startswith("R2") for f in _run(overwrite)[0])
+    as_operand = """
+        v_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]
+        s_nop 7
+        v_mfma_f32_16x16x32_bf16 v[4:7], v[0:3], v[12:15], v[4:7]
+    """
+    assert any(f.startswith("R2") for f in _run(as_operand)[0])   # D read as A after 8 of 11 states
+    assert not _run(as_operand.replace("s_nop 7", "s_nop 10"))[0]
+
+
+def test_r3_load_destination_before_its_wait():
+    bad = """
+        global_load_dword v1, v[2:3], off
+        v_add_f32_e32 v4, v1, v1
+    """
+    assert _run(bad)[1]
+    assert not _run(bad.replace("v_add", "s_waitcnt vmcnt(0)\n        v_add"))[1]
+    counted = """
+        buffer_load_dwordx4 v[10:13], v1, s[4:7], 0 offen
+        buffer_load_dwordx4 v[14:17], v2, s[4:7], 0 offen
+        s_waitcnt vmcnt(1)
+        v_add_f32_e32 v4, v10, v11
+    """
+    assert not _run(counted)[1]                    # the older load has landed
+    assert _run(counted.replace("v10, v11", "v14, v15"))[1]
+    lds = """
+        ds_read_b128 v[20:23], v5 offset:1024
+        v_mfma_f32_32x32x2_f32 v[32:47], v20, v30, v[32:47]
+    """
+    assert _run(lds)[1]
+    assert not _run(lds.replace("v_mfma", "s_waitcnt lgkmcnt(0)\n        v_mfma"))[1]
+    reused = """
+        buffer_load_dword v7, v1, s[4:7], 0 offen
+        v_mov_b32_e32 v7, 0
+    """
+    assert _run(reused)[1]                         # the in-flight load would overwrite the new value
+    loop = """
+        L0:
+        v_add_f32_e32 v4, v1, v1
+        global_load_dword v1, v[2:3], off
+        s_cbranch_scc1 L0
+        s_endpgm
+    """
+    assert _run(loop)[1]                           # consumed on the next trip without a wait
+    # the same scalar compare tested twice (macro-unrolled bodies): the second outcome follows the first
+    correlated = """
+        global_load_dword v1, v[2:3], off
+        s_cmp_ge_i32 s4, s5
+        s_cbranch_scc0 L2
+        s_cmp_ge_i32 s4, s5
+        s_cbranch_scc1 L3
+        v_add_f32_e32 v4, v1, v1
+        L2:
+        s_waitcnt vmcnt(0)
+        v_add_f32_e32 v4, v1, v1
+        L3:
+        s_endpgm
+    """
+    assert not _run(correlated)[1]
+    assert _run(correlated.replace("s_cbranch_scc1 L3", "s_add_i32 s4, s4, 1\n        s_cmp_ge_i32 s4, s5\n        s_cbranch_scc1 L3"))[1]
+
+
+def test_r4_hand_set_m0_is_not_mixed_with_compiler_managed_m0():
+    own = """
+        s_mov_b32 m0, s8
+        s_nop 0
+        global_load_lds_dwordx4 v1, s[2:3]
+    """
+    assert not _run(own)[2]
+    mixed = own + """
+        global_load_lds_dwordx4 v[4:5], off
+    """
+    assert _run(mixed)[2]
+    stale = own + """
+        v_mov_b32_e32 v9, 0
+        s_add_u32 s2, s2, 64
+        v_mov_b32_e32 v10, 0
+        v_mov_b32_e32 v11, 0
+        global_load_lds_dwordx4 v1, s[2:3]
+    """
+    assert _run(stale)[2]
+
+
+def test_library_machine_code_is_clean():
+    import build as qbuild
+    import isa_lint as L
+    so = qbuild.build_lib(verbose=False)
+    findings, stats = L.lint(so)
+    assert stats["kernels"] > 150 and stats["mfma"] > 5000 and stats["asm_style_loads"] > 300, stats
+    assert not findings, "\n".join(findings[:20])
