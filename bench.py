@@ -78,8 +78,11 @@ def parse_args(argv=None):
                          "bf16 / fp8 MFMA, fp32 accumulate), the default for --config c5 (bf16); "
                          "reported under its own workload name, never as the c2 headline")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the whole training step from a captured HIP graph (single GPU; "
-                         "helps launch-bound per-GPU batches such as --config c4)")
+                    help="replay the training step from captured HIP graphs (one graph on a single GPU; "
+                         "under data parallelism a chain of segments cut at the gradient buckets, the "
+                         "bucket all-reduces issued between them).  The default for --config c4, whose "
+                         "8-sequence shards are ~1,000 launches of 20-80 us")
+    ap.add_argument("--eager", action="store_true", help="plain stream launches (the default except for c4)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="c2 (default, the headline workload), or the per-GPU shard of config 4 / 5")
     ap.add_argument("--batch", type=int, default=None, help="override the per-GPU batch")
@@ -287,15 +290,19 @@ def main():
     nwin = pipeline.num_windows(seq, cfg["window"])
     rng = torch.Generator().manual_seed(4)
 
+    use_graph = (args.graph or args.config == "c4") and not args.eager
     graphed = pipeline.GraphedTrainStep(model, optim, lr_cb, hr_cb, cfg["base"], cfg["window"]) \
-        if args.graph else None
+        if use_graph else None
+
+    def eager_step(rand):
+        hr_in, lr_in, hr_tg, pos = pipeline.tokenize_window(z, lr_cb, hr_cb, cfg["base"], cfg["window"], rand)
+        return pipeline.train_step(model, optim, hr_in, lr_in, hr_tg, pos, pos_bound=seq)
 
     def step():
         rand = parallel.shard(torch.randint(0, nwin, (N * world,), generator=rng))
         if graphed is not None:
             return graphed(z, rand)
-        hr_in, lr_in, hr_tg, pos = pipeline.tokenize_window(z, lr_cb, hr_cb, cfg["base"], cfg["window"], rand)
-        return pipeline.train_step(model, optim, hr_in, lr_in, hr_tg, pos, pos_bound=seq)
+        return eager_step(rand)
 
     def fence():
         if world > 1:
@@ -321,12 +328,12 @@ def main():
     # second, short pass: HIP events around every GEMM launch (on the launch stream) for the
     # roofline object; kept out of the headline loop, which carries no per-launch events
     events = []
-    if not args.no_kernel_events and graphed is None:
+    if not args.no_kernel_events:
         ev_steps = min(2, args.steps)
         ops.GEMM_EVENTS = []
         t1 = time.perf_counter()
-        for _ in range(ev_steps):
-            step()
+        for _ in range(ev_steps):      # eager launches (a replayed graph has no per-launch events)
+            eager_step(parallel.shard(torch.randint(0, nwin, (N * world,), generator=rng)))
         fence()
         dt_ev = time.perf_counter() - t1
         events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
@@ -369,7 +376,9 @@ def main():
                       "params": int(optim.total),
                       "parallelism": f"dp{world}", "loss": round(loss_val, 5),
                       "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
-                      "launch": "captured HIP graph replay" if args.graph else "eager stream launches"}}
+                      "launch": ("captured HIP graph replay" + (f" ({len(graphed.graph.graphs)} segments, bucket "
+                                 "all-reduces between them)" if graphed.segmented else ""))
+                      if graphed is not None else "eager stream launches"}}
     if allreduce is not None:
         out["allreduce"] = allreduce
     if rank == 0:
@@ -385,18 +394,21 @@ def main():
             ach = fl / ms / 1e9
             traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-            if os.path.exists(pmc) and precision == "f32" and args.config == "c2":
-                tj = json.load(open(pmc))
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_src = (f"profiles/gemm_traffic.json (round {tj.get('round')}: rocprofv3 --pmc "
-                               "FETCH_SIZE / WRITE_SIZE passes of this command, reads doubled per the "
-                               "gfx950 calibration; not re-measured by this run)")
+            key = args.config if precision == "f32" else f"{args.config}_{precision}"
+            tj = json.load(open(pmc)).get(key) if os.path.exists(pmc) else None
+            if tj:
+                traffic = tj.get("fabric_bytes_per_launch")
+                traffic_src = (f"profiles/gemm_traffic.json[{key}] (round {tj.get('round')}: rocprofv3 --pmc "
+                               "FETCH_SIZE / WRITE_SIZE passes of this command, reads doubled per the gfx950 "
+                               "calibration; L2-miss (fabric-side) bytes, Infinity-Cache hits included = an "
+                               "upper bound of the HBM bytes; not re-measured by this run)")
             # fp8 mode: the forward x W^T products run on gemm_f8_kernel, every other product on the
             # bf16 kernel, so the family is priced against the bf16 peak and the e4m3 launches are
             # listed beside it against their own
             peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS,
                     "fp8": PEAK_BF16_MFMA_TFLOPS}[precision]
-            kname = {"f32": "qarig::gemm_dma_kernel<*> / gemm_kernel<*> (fp32 MFMA 32x32x2)",
+            kname = {"f32": "qarig::gemm_dma_pf_kernel<*> / gemm_dma_pf_grouped_kernel<*> / gemm_dma_pf2_kernel<*> "
+                            "(fp32 MFMA 32x32x2, 4-stage LDS-DMA ring)",
                      "bf16": "qarig::gemm_lp_kernel<bf16,*> (bf16 MFMA 32x32x16, bf16 operands in HBM)",
                      "fp8": "qarig::gemm_lp_kernel<bf16,*> + gemm_f8_kernel (forward x W^T on fp8 e4m3 "
                             "MFMA 32x32x64, e4m3 operands in HBM); priced against the bf16 peak"}[precision]

@@ -6,9 +6,12 @@ profiles/:
   TAG_pmc_by_kernel.csv    FETCH_SIZE / WRITE_SIZE per launch, aggregated by kernel
   TAG_sq_by_kernel.csv     SQ / GRBM counters per launch, aggregated by kernel, plus derived
                            MFMA-busy share, VALU instructions per MFMA and effective clock
-  gemm_traffic.json        HBM bytes per GEMM-family launch, read by bench.py ("traffic")
+  gemm_traffic.json        fabric-side bytes per GEMM-family launch and configuration, read by bench.py
+                           ("traffic"): FETCH_SIZE / WRITE_SIZE count L2 misses, i.e. traffic that reaches
+                           the Infinity Fabric -- Infinity-Cache (MALL) hits included, so an upper bound of
+                           the HBM bytes
 
-    python3 profiles/summarize.py TAG --on-box     (on the GPU box: raw CSVs -> gpurun_out/TAG_summary,
+    python3 profiles/summarize.py TAG --on-box [--config c4]   (on the GPU box: raw CSVs -> gpurun_out/TAG_summary,
                                                     raw per-dispatch counter CSVs deleted: they
                                                     exceed what gpurun merges back)
     python3 profiles/summarize.py TAG              (here: gpurun_out/TAG_summary -> profiles/)
@@ -28,6 +31,9 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 on_box = "--on-box" in sys.argv
+cfg_name = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "c2"
+if "--precision" in sys.argv:
+    cfg_name += "_" + sys.argv[sys.argv.index("--precision") + 1]
 here = os.path.dirname(os.path.abspath(__file__))
 src = os.path.join(os.path.dirname(here), "gpurun_out")
 summ = os.path.join(src, f"{tag}_summary")
@@ -96,7 +102,7 @@ def box():
                 wn, wt = w[k]["WRITE_SIZE"] if k in w else (0, 0.0)
                 wr = wt / max(1, wn)
                 fh.write(f"\"{k}\",{n},{fe:.1f},{wr:.1f},{(2 * fe + wr) * 1024:.0f}\n")
-        is_gemm = lambda k: "gemm_kernel" in k or "gemm_dma_kernel" in k or "gemm_lp_kernel" in k
+        is_gemm = lambda k: "gemm_" in k and "reduce" not in k and "skinny" not in k
         fb, wb = agg(fpath, big_only=True), agg(wpath, big_only=True)
         gf = [v["FETCH_SIZE"] for k, v in fb.items() if is_gemm(k)]
         gw = [v["WRITE_SIZE"] for k, v in wb.items() if is_gemm(k)]
@@ -104,15 +110,18 @@ def box():
         if n:
             fetch = sum(b for _, b in gf) / n
             write = sum(b for _, b in gw) / max(1, sum(a for a, _ in gw))
-            json.dump({"round": tag, "kernel": "qarig GEMM family (gemm_dma_kernel / gemm_kernel / gemm_lp_kernel)",
+            json.dump({"config": cfg_name, "round": tag,
+                       "kernel": "qarig GEMM family (gemm_dma_pf* / gemm_kernel / gemm_lp* / gemm_f8*)",
                        "launches_profiled": n,
                        "FETCH_SIZE_KiB_per_launch": round(fetch, 1),
                        "WRITE_SIZE_KiB_per_launch": round(write, 1),
-                       "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
+                       "fabric_bytes_per_launch": int((2 * fetch + write) * 1024),
+                       "what": "L2-miss (fabric-side) bytes per launch, Infinity-Cache hits included: an upper "
+                               "bound of the HBM bytes",
                        "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py; reads doubled "
                                "per the gfx950 FETCH_SIZE calibration; launches of >= 100k work-items only "
                                "(the same set bench.py's roofline object averages)"},
-                      open(os.path.join(summ, "gemm_traffic.json"), "w"), indent=1)
+                      open(os.path.join(summ, f"{tag}_gemm_traffic.json"), "w"), indent=1)
     # SQ / GRBM sets
     rows = collections.defaultdict(dict)
     for p in ("sq1", "sq2"):
@@ -159,7 +168,16 @@ def box():
 def local():
     n = 0
     for p in glob.glob(os.path.join(summ, "*")):
-        shutil.copy(p, os.path.join(here, os.path.basename(p)))
+        if p.endswith("_gemm_traffic.json"):      # merged into profiles/gemm_traffic.json under its configuration
+            one_cfg = json.load(open(p))
+            dst = os.path.join(here, "gemm_traffic.json")
+            allcfg = json.load(open(dst)) if os.path.exists(dst) else {}
+            if "round" in allcfg:                 # the round-2 layout (one configuration, no key)
+                allcfg = {}
+            allcfg[one_cfg["config"]] = one_cfg
+            json.dump(allcfg, open(dst, "w"), indent=1)
+        else:
+            shutil.copy(p, os.path.join(here, os.path.basename(p)))
         n += 1
     print(f"copied {n} files from {summ}")
 

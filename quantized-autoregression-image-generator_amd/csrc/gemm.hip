@@ -656,15 +656,17 @@ __global__ void slab_reduce_epilogue_kernel(const float* __restrict__ slabs, Gem
 
 // Column sums of X[M][N] (bias gradients; LayerNorm gamma/beta gradients).
 // Stage 1: one block per (64 columns x COLSUM_ROWS rows), fixed order inside.
-constexpr int COLSUM_ROWS = 512;
+// Rows per block: enough blocks to fill the chip at a few thousand rows too (2,048 x 512 -- the
+// LayerNorm-affine gradients of an 8-sequence shard -- ran 31 us on 32 blocks of 512 rows).
+static inline int colsum_rows(int M) { return M >= 32768 ? 512 : (M >= 8192 ? 128 : 32); }
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X,
                                                              int64_t ldx, int M, int N,
-                                                             float* __restrict__ part) {
+                                                             float* __restrict__ part, int rows) {
     __shared__ float red[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cx;
-    const int r0 = blockIdx.y * COLSUM_ROWS;
-    const int r1 = min(M, r0 + COLSUM_ROWS);
+    const int r0 = blockIdx.y * rows;
+    const int r1 = min(M, r0 + rows);
     float s = 0.0f;
     if (col < N)
         for (int r = r0 + ry; r < r1; r += 4) s += X[(int64_t)r * ldx + col];
@@ -983,7 +985,8 @@ extern "C" int qarig_slab_reduce_f32(const float* slabs, float* out, int64_t ldc
 
 extern "C" size_t qarig_colsum_workspace_bytes(int M, int N) {
     if (M < 1 || N < 1 || M > (1 << 30)) return 0;
-    const int chunks = (M + COLSUM_ROWS - 1) / COLSUM_ROWS;
+    const int rows = colsum_rows(M);
+    const int chunks = (M + rows - 1) / rows;
     return (size_t)chunks * N * sizeof(float);
 }
 
@@ -996,11 +999,12 @@ extern "C" int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float
         qarig_set_error("colsum: workspace too small");
         return QARIG_ERR_WORKSPACE;
     }
-    const int chunks = (M + COLSUM_ROWS - 1) / COLSUM_ROWS;
+    const int rows = colsum_rows(M);
+    const int chunks = (M + rows - 1) / rows;
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, X, ldx,
-                       M, N, part);
+                       M, N, part, rows);
     QARIG_CHECK_LAUNCH("colsum partial");
     int blocks = (N + 255) / 256;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, out, (int64_t)N, 1,

@@ -104,7 +104,11 @@ class Transformer(nn.Module):
                                     groups=self._cond_linear_groups())
         self._last_cond_form = "per_token"
         cond = ops.posemb(pos_cond.flatten(), D).reshape(N, S, D)
-        return _mlp2_forward(self.pos_cond_layer, cond)
+        cond = _mlp2_forward(self.pos_cond_layer, cond)
+        if torch.is_grad_enabled() and QF.USE_COND_GROUPS and ops.gemm_grouped_supported(N * S, D, D):
+            # training rows without a (worthwhile) position table: the projections of `cond` in groups
+            return QF.CondTokens(cond, groups=self._cond_linear_groups())
+        return cond
 
     def _cond_linears_per_layer(self):
         """Per decoder layer, the nn.Linear modules that project `cond` inside its blocks."""
@@ -176,7 +180,8 @@ class Transformer(nn.Module):
         kvs = None
         if enc is not None and self.use_encoder and not ckpt and torch.is_grad_enabled():
             kvs = self._cross_kv_all_layers(enc)
-        per_layer = self._cond_linears_per_layer() if ckpt and isinstance(cond, QF.CondTable) else None
+        per_layer = self._cond_linears_per_layer() if ckpt and isinstance(cond, (QF.CondTable, QF.CondTokens)) \
+            else None
         for li, layer in enumerate(self.decoder_layers):
             if ckpt:
                 if per_layer is not None:

@@ -83,6 +83,9 @@ class AdaLNZero(nn.Module):
             return QF.layernorm_mod_table(x, cond.projection(self.scale_layer.scale),
                                           cond.projection(self.shift_layer.shift), cond, self.norm.eps,
                                           with_skip=with_skip)
+        if isinstance(cond, QF.CondTokens):    # per-token cond, projections evaluated in groups
+            return QF.layernorm_mod(x, cond.projection(self.scale_layer.scale),
+                                    cond.projection(self.shift_layer.shift), self.norm.eps, with_skip=with_skip)
         return QF.layernorm_mod(x, self.scale_layer(cond), self.shift_layer(cond), self.norm.eps,
                                 with_skip=with_skip)
 
@@ -192,6 +195,8 @@ class ResidualLinearLayer(nn.Module):
         if self.use_scale_layer:
             if isinstance(cond, QF.CondTable):
                 x = QF.mul_table(x, cond.projection(self.scale_layer.scale), cond)
+            elif isinstance(cond, QF.CondTokens):
+                x = QF.mul(x, cond.projection(self.scale_layer.scale))
             else:
                 x = QF.mul(x, self.scale_layer(cond))
         x_skip = self.skip_linear(x_skip)

@@ -121,7 +121,12 @@ def last_error():
     return buf.value.decode("utf-8", "replace")
 
 
+N_CALLS = 0      # C-ABI calls checked so far (pipeline._SegmentedCapture: "has this segment launched anything?")
+
+
 def check(status, what):
+    global N_CALLS
+    N_CALLS += 1
     if status != 0:
         raise RuntimeError(f"{what} failed ({status}): {last_error()}")
 

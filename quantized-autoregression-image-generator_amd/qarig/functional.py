@@ -477,6 +477,7 @@ class _LayerNormAffine(torch.autograd.Function):
         y, mean, rstd = ops.layernorm_fwd(x2, gamma=gamma, beta=beta, eps=eps)
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.shape = x.shape
+        ctx.params = (gamma, beta)
         ctx.set_materialize_grads(False)
         return _with_skip(y.reshape(x.shape), x, with_skip)
 
@@ -485,6 +486,13 @@ class _LayerNormAffine(torch.autograd.Function):
         x2, gamma, mean, rstd = ctx.saved_tensors
         dy2, add = _skip_grads(dy, dskip, x2)
         dx, dyx = ops.layernorm_bwd(dy2, x2, mean, rstd, gamma=gamma, want_dy_xhat=True, dx_add=add)
+        gslot, bslot = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
+        if gslot is not None and bslot is not None:     # column sums straight into the .grad slots
+            ops.colsum(dyx, out=gslot, accumulate=True)
+            ops.colsum(dy2, out=bslot, accumulate=True)
+            _report_done(ctx.params[0])
+            _report_done(ctx.params[1])
+            return dx.reshape(ctx.shape), None, None, None, None
         return dx.reshape(ctx.shape), ops.colsum(dyx), ops.colsum(dy2), None, None
 
 
@@ -722,6 +730,8 @@ COND_TABLE_MIN_RATIO = 4
 # "layer" (one per layer: gradients final in layer order, for the overlapped data-parallel
 # all-reduce) or None = "layer" under torch.distributed with more than one rank, else "all"
 COND_TABLE_GROUPING = os.environ.get("QARIG_COND_GROUPING") or None
+# per-token cond (no table): its projections as grouped launches (CondTokens); QARIG_COND_GROUPS=0 disables
+USE_COND_GROUPS = os.environ.get("QARIG_COND_GROUPS", "1") != "0"
 
 
 class CondTable:
@@ -744,7 +754,10 @@ class CondTable:
         P, D = table.shape
         for group in groups:
             group = list(group)
-            if (group and P <= 512 and D % 256 == 0
+            # tables of up to 512 rows: the weight-streaming grouped kernel; longer ones (sequences of
+            # more than ~500 tokens: BASELINE config 4's 1,025) the grouped 128 x 128-tile launches
+            fits = (P <= 512 and D % 256 == 0) or ops.gemm_grouped_supported(P, D, D)
+            if (group and fits
                     and all(l.weight.shape == (D, D) and l.bias is not None for l in group)):
                 for l in group:
                     self._group_of[id(l)] = group
@@ -778,25 +791,117 @@ class CondTable:
         return self._proj[id(linear)]
 
 
+class CondTokens:
+    """Per-token `cond` (N,S,D) whose ScaleLayer / ShiftLayer projections are evaluated as grouped
+    launches: every projection of a decoder (3 per block: AdaLN scale, shift and the residual gate,
+    reference models/layers.py:100-153, 258-304) reads the same tensor, so up to 16 of them are one
+    128 x 128-tile launch forward, one for the summed gradient of `cond` and one for their weight
+    gradients (_TableProjections on the token rows) -- instead of one product, two gradient products
+    and their split-K reduces per projection and an accumulation add per extra consumer of `cond`.
+    Taken when the position table is not worth it (fewer than COND_TABLE_MIN_RATIO times fewer
+    positions than tokens: BASELINE config 4's 1,025-token sequences at 8 x 256 tokens per GPU).
+    Same `projection` / `ensure` interface as CondTable; the consumers are the per-token kernels."""
+
+    def __init__(self, cond, groups=()):
+        self.cond = cond
+        self._flat = cond.reshape(-1, cond.shape[-1])
+        self._proj = {}
+        self._group_of = {}
+        M, D = self._flat.shape
+        for group in groups:
+            group = list(group)
+            if (group and ops.gemm_grouped_supported(M, D, D)
+                    and all(l.weight.shape == (D, D) and l.bias is not None for l in group)):
+                for l in group:
+                    self._group_of[id(l)] = group
+
+    def ensure(self, linears):
+        for l in linears:
+            if id(l) in self._group_of:
+                self.projection(l)
+
+    def projection(self, linear):
+        got = self._proj.get(id(linear))
+        if got is not None:
+            return got
+        group = self._group_of.get(id(linear))
+        if group is None:
+            return linear_act(self.cond, linear.weight, linear.bias)
+        params = [t for l in group for t in (l.weight, l.bias)]
+        outs = _TableProjections.apply(self._flat, *params)
+        for l, o in zip(group, outs):
+            self._proj[id(l)] = o.reshape(self.cond.shape)
+        return self._proj[id(linear)]
+
+
 class _TableProjections(torch.autograd.Function):
-    """G projections of the same (P,D) table, out_g = table W_g^T + b_g, as one grouped
-    skinny launch; backward as two GEMMs over the concatenated gradients (d-table with
-    K = G*D, d-weights as one (G*D, D) product) instead of 2G small ones."""
+    """G projections of the same (P,D) table, out_g = table W_g^T + b_g.  Up to 512 rows: one grouped
+    skinny launch; backward as two GEMMs over the concatenated gradients (d-table with K = G*D,
+    d-weights as one (G*D, D) product) instead of 2G small ones.  Longer tables: grouped 128 x 128-tile
+    launches of up to 16 members on the parameters where they lie (no stacked copy) -- forward, the
+    d-table sum over the members, and the weight gradients with their bias row sums accumulated
+    straight into the .grad slots."""
 
     @staticmethod
     def forward(ctx, table, *params):
         require_cuda(table)
         weights, biases = params[0::2], params[1::2]
         tab = f32c(table)
+        P, D = tab.shape
+        ctx.params = params
+        ctx.tiled = not (P <= 512 and D % 256 == 0)
+        if ctx.tiled:
+            G = len(weights)
+            out = torch.empty((G, P, D), dtype=torch.float32, device=tab.device)
+            for c in range(0, G, ops.GEMM_MAX_GROUPS):
+                n = min(ops.GEMM_MAX_GROUPS, G - c)
+                ops.gemm_grouped([tab] * n, list(weights[c:c + n]), list(out[c:c + n].unbind(0)), P, D, D,
+                                 bias=list(biases[c:c + n]), splitk=ops.grouped_splitk(n, P, D, D))
+            ctx.save_for_backward(tab)
+            return tuple(out.unbind(0))
         W = torch.stack([w.detach() for w in weights])             # (G, D, D)
         b = torch.stack([v.detach() for v in biases])               # (G, D)
         out = ops.gemm_grouped_skinny(tab, W, b, shared_a=True)     # (G, P, D)
         ctx.save_for_backward(tab, W)
-        ctx.params = params
         return tuple(out.unbind(0))
 
     @staticmethod
+    def _backward_tiled(ctx, douts):
+        (tab,) = ctx.saved_tensors
+        P, D = tab.shape
+        wparams, bparams = ctx.params[0::2], ctx.params[1::2]
+        G = len(wparams)
+        dev = tab.device
+        cols = [f32c(d) if d is not None else torch.zeros((P, D), dtype=torch.float32, device=dev) for d in douts]
+        wslots = [_grad_slot(p) for p in wparams]
+        bslots = [_grad_slot(p) for p in bparams]
+        inplace = all(s is not None for s in wslots) and all(s is not None for s in bslots)
+        if not inplace:
+            dW = torch.empty((G, D, D), dtype=torch.float32, device=dev)
+            db = torch.empty((G, D), dtype=torch.float32, device=dev)
+            wslots, bslots = list(dW.unbind(0)), list(db.unbind(0))
+        dtab = torch.empty((P, D), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        for c in range(0, G, ops.GEMM_MAX_GROUPS):
+            n = min(ops.GEMM_MAX_GROUPS, G - c)
+            if dtab is not None:
+                ops.gemm_grouped(cols[c:c + n], list(wparams[c:c + n]), [dtab], P, D, D, a_kcontig=True,
+                                 b_kcontig=False, sum_groups=True, accumulate=c > 0,
+                                 splitk=ops.grouped_splitk(n, P, D, D))
+            ops.gemm_grouped(cols[c:c + n], [tab] * n, wslots[c:c + n], D, D, P, a_kcontig=False, b_kcontig=False,
+                             accumulate=inplace, a_rowsum=bslots[c:c + n], splitk=ops.grouped_splitk(n, D, D, P))
+        if inplace:
+            for p in ctx.params:
+                _report_done(p)
+            return (dtab, *([None] * len(ctx.params)))
+        grads = [dtab]
+        for g in range(G):
+            grads += [wslots[g], bslots[g]]
+        return tuple(grads)
+
+    @staticmethod
     def backward(ctx, *douts):
+        if ctx.tiled:
+            return _TableProjections._backward_tiled(ctx, douts)
         tab, W = ctx.saved_tensors
         G, D, _ = W.shape
         P = tab.shape[0]

@@ -44,6 +44,7 @@ class FlatAdam:
         self.step_count = 0
         self._overlap = False
         self._works = []
+        self._capture_cut = None    # set by pipeline._SegmentedCapture while it records a step
         with torch.no_grad():
             for p, o, s in zip(self.params, offs, sizes):
                 view = self.flat_param[o:o + s].view(p.shape)
@@ -78,6 +79,7 @@ class FlatAdam:
                 lo, count = end, 0
         self._pending = list(self._pending0)
         self._done = set()
+        self._launched = 0
         for p in self.params:
             p._qarig_grad_done = self._grad_done
             p.register_post_accumulate_grad_hook(self._grad_done)
@@ -87,27 +89,48 @@ class FlatAdam:
         # kernel path and by autograd's post-accumulate hook
         if id(p) in self._done:
             return
+        if self._capture_cut is not None:
+            self._capture_cut(None, len(self.params) - len(self._done))
         self._done.add(id(p))
         b = self._bucket_of[id(p)]
         self._pending[b] -= 1
         if self._pending[b] == 0:
-            lo, hi = self._bucket_range[b]
-            self._works.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM,
-                                               async_op=True))
+            if self._capture_cut is not None:
+                # a step is being recorded into graph segments: the bucket's all-reduce is not part
+                # of the recording, the segment ends here and replay issues the collective behind it
+                self._capture_cut(b, 0)
+            else:
+                self.launch_bucket(b)
+
+    def launch_bucket(self, b):
+        lo, hi = self._bucket_range[b]
+        self._works.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        self._launched += 1
+
+    def reset_overlap_bookkeeping(self):
+        """After a recording pass (no collective was issued, every parameter reported)."""
+        self._pending = list(self._pending0)
+        self._done = set()
+        self._launched = 0
 
     def finish_allreduce(self):
         """Waits for the overlapped bucket all-reduces (no-op without overlap).  Returns
         True if this step's gradients have been reduced by the overlapped path."""
         if not self._overlap:
             return False
-        if any(n != 0 for n in self._pending):
+        # a replayed step (pipeline._SegmentedCapture) runs no hooks: its buckets were launched by
+        # the replay loop, one per recorded cut
+        replayed = not self._done and self._launched == len(self._bucket_range)
+        if not replayed and any(n != 0 for n in self._pending):
             raise RuntimeError("overlapped all-reduce: some parameters never reported a gradient "
                                f"(pending per bucket: {self._pending})")
+        if self._launched != len(self._bucket_range):
+            raise RuntimeError(f"overlapped all-reduce: {self._launched} of {len(self._bucket_range)} "
+                               "gradient buckets were exchanged")
         for w in self._works:
             w.wait()
         self._works = []
-        self._pending = list(self._pending0)
-        self._done = set()
+        self.reset_overlap_bookkeeping()
         return True
 
     # -- torch.optim API subset the reference's training loops use ------------------

@@ -70,6 +70,81 @@ def train_step(model, optim, hr_input, lr_input, hr_target, pos_idx, dp=True, po
     return loss
 
 
+class _SegmentedCapture:
+    """forward + backward of one step recorded as a CHAIN of HIP graphs, cut wherever the backward
+    pass completes a gradient bucket of the overlapped data-parallel all-reduce
+    (FlatAdam.enable_allreduce_overlap): replay launches segment k, then -- eagerly, on RCCL's own
+    stream, ordered behind the segment by the usual stream event -- the all-reduce of the bucket
+    that segment completed, then segment k+1, so the exchange overlaps the replayed rest of
+    backward exactly as it overlaps the eager one, and the host issues a dozen graph launches
+    instead of ~1,200 kernels.  The collectives themselves are not captured (nothing about RCCL's
+    capture support is assumed).  All segments allocate from one private memory pool and are
+    replayed in capture order.  A segment is cut at the first parameter report AFTER a bucket has
+    completed (never behind the last one), so no segment is empty."""
+
+    def __init__(self, optim):
+        self.optim = optim
+        self.graphs = []
+        self.bucket_after = []      # buckets whose all-reduce follows segment k
+
+    def capture(self, body):
+        import torch.distributed as dist
+        opt = self.optim
+        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        pool = torch.cuda.graph_pool_handle()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+
+        from . import _lib
+        calls_at_begin = [0]
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=pool, capture_error_mode=mode)
+            self.graphs.append(g)
+            calls_at_begin[0] = _lib.N_CALLS
+
+        ready = []
+
+        def cut(bucket, params_left):
+            """FlatAdam._grad_done: (None, parameters still to report) on entry, (b, 0) when bucket b
+            has just become final."""
+            if bucket is not None:
+                ready.append(bucket)
+            elif ready and params_left > 1:
+                self.graphs[-1].capture_end()
+                self.bucket_after.append(list(ready))
+                del ready[:]
+                begin()
+
+        # backward on THIS thread: the cuts end / begin captures from the gradient hooks, and a
+        # thread-local capture may only be ended by the thread that began it
+        with torch.cuda.stream(side), torch.autograd.set_multithreading_enabled(False):
+            begin()
+            opt._capture_cut = cut if opt._overlap else None
+            try:
+                out = body()
+            finally:
+                opt._capture_cut = None
+            if _lib.N_CALLS == calls_at_begin[0]:
+                # every remaining parameter was reported by the launch that closed the previous
+                # segment: give the trailing segment one (no-op) node rather than an empty graph
+                opt._dev_step_buffer().mul_(1.0)
+            self.graphs[-1].capture_end()
+            self.bucket_after.append(list(ready))
+        torch.cuda.current_stream().wait_stream(side)
+        if opt._overlap:
+            opt.reset_overlap_bookkeeping()
+        return out
+
+    def replay(self):
+        opt = self.optim
+        for g, buckets in zip(self.graphs, self.bucket_after):
+            g.replay()
+            for b in buckets:
+                opt.launch_bucket(b)
+
+
 class GraphedTrainStep:
     """The whole training step -- BMU tokenisation, window slicing, forward, cross-entropy,
     backward, Adam -- captured ONCE into a HIP graph (torch.cuda.CUDAGraph over the library's
@@ -82,14 +157,16 @@ class GraphedTrainStep:
 
     What varies between steps lives in static device buffers refreshed before each replay: the
     latent batch, the per-sample window offsets, and Adam's step size / bias correction
-    (FlatAdam.advance_captured).  Single process only: collectives are not captured, so data-
-    parallel runs keep the eager `train_step`.  The first `warmup` calls run eagerly (they are
-    real training steps; they also size every workspace and the allocator pools)."""
+    (FlatAdam.advance_captured).  The first `warmup` calls run eagerly (they are real training
+    steps; they also size every workspace and the allocator pools).
+
+    Data parallel (more than one rank, or FlatAdam's overlapped all-reduce enabled): the step is a
+    chain of graph segments cut at the gradient buckets (_SegmentedCapture) with the bucket
+    all-reduces issued between them, and Adam (which must wait for the last collective) is one eager
+    launch behind them."""
 
     def __init__(self, model, optim, lr_codebook, hr_codebook, train_base_model, window, warmup=2):
-        if parallel.world_size() > 1:
-            raise RuntimeError("GraphedTrainStep is single-process: data-parallel all-reduces are "
-                               "not captured; use pipeline.train_step")
+        self.segmented = parallel.world_size() > 1 or optim._overlap
         self.model, self.optim = model, optim
         self.lr_cb, self.hr_cb = lr_codebook, hr_codebook
         self.base, self.window = train_base_model, window
@@ -107,11 +184,20 @@ class GraphedTrainStep:
         logits = self.model(x_dec=hr_in, x_enc=lr_in, pos_cond=pos, pos_bound=seq)
         loss = QF.cross_entropy(logits.view(-1, logits.shape[-1]), hr_tg.flatten())
         loss.backward()
-        if captured:
+        if self.segmented:
+            if not captured:
+                self._exchange_and_step()
+        elif captured:
             self.optim.step_captured()
         else:
             self.optim.step()
         return loss.detach()
+
+    def _exchange_and_step(self):
+        w = parallel.world_size()
+        if not self.optim.finish_allreduce() and w > 1:
+            parallel.allreduce_flat(self.optim.flat_grad)
+        self.optim.step(grad_scale=1.0 / w)
 
     def __call__(self, z, rand):
         """z: latent batch on the device; rand: int64 window offsets (host or device).
@@ -126,15 +212,23 @@ class GraphedTrainStep:
             self._rand = rand.to(z.device).clone()
             self.optim._dev_step_buffer()      # must exist BEFORE capture: created inside, its
             torch.cuda.synchronize()           # zero-fill would be replayed ahead of every Adam
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._loss = self._body(self._z, self._rand, captured=True)
+            if self.segmented:
+                self.graph = _SegmentedCapture(self.optim)
+                self._loss = self.graph.capture(lambda: self._body(self._z, self._rand, captured=True))
+            else:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._loss = self._body(self._z, self._rand, captured=True)
         else:
             if z.shape != self._z.shape:
                 raise ValueError(f"GraphedTrainStep was captured for batches of shape {tuple(self._z.shape)}, "
                                  f"got {tuple(z.shape)}")
             self._z.copy_(z)
             self._rand.copy_(rand)
+        if self.segmented:
+            self.graph.replay()
+            self._exchange_and_step()
+            return self._loss
         self.optim.advance_captured()
         self.graph.replay()
         return self._loss

@@ -161,6 +161,60 @@ def test_grouped_table_projections_match_per_token_path(grouping):
         assert grad_err(res[True][1][n], gref, floor=1e-7) < 5e-5, n
 
 
+@pytest.mark.parametrize("slots", [True, False])
+def test_long_position_tables_run_grouped_tile_launches(slots):
+    """Sequences longer than 512 positions (BASELINE config 4: 1,025): the table projections go through the
+    grouped 128 x 128-tile launches (18 members = two launches of 16 + 2) forward, for the summed table
+    gradient and for the weight gradients + bias row sums -- into FlatAdam's .grad slots or as returned
+    tensors; every parameter gradient against the per-token evaluation."""
+    from models.Transformer import Transformer
+    from qarig import functional as QF
+    from qarig.optim import FlatAdam
+    torch.manual_seed(8)
+    m = Transformer(use_encoder=False, use_pos_cond=True, num_enc_layers=None, num_dec_layers=3,
+                    num_enc_embedding=None, num_dec_embedding=60, self_attn_heads=16,
+                    cross_attn_heads=None, transformer_in_dim=128, transformer_out_dim=41,
+                    transformer_hidden_dim=256).cuda()
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.abs().max() == 0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    if slots:
+        FlatAdam(m.parameters(), lr=1e-3)          # points every .grad into its flat buffer
+    N, S, total = 6, 128, 700                      # P = 768 rows
+    x = torch.randint(0, 60, (N, S), generator=g).cuda()
+    t = torch.randint(0, 41, (N, S), generator=g).cuda()
+    pos = (torch.randint(0, total - S + 1, (N, 1), generator=g) + torch.arange(S)[None]).cuda()
+    old = (QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO, QF.COND_TABLE_GROUPING)
+    res = {}
+    try:
+        for table in (False, True):
+            QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO, QF.COND_TABLE_GROUPING = table, 0, "all"
+            for p in m.parameters():
+                if slots:
+                    p.grad.zero_()
+                else:
+                    p.grad = None
+            calls = []
+            orig = QF._TableProjections.apply
+            if table:
+                QF._TableProjections.apply = staticmethod(lambda *a: (calls.append(len(a)), orig(*a))[1])
+            try:
+                logits = m(x, None, pos, pos_bound=total)
+                QF.cross_entropy(logits.view(-1, 41), t.flatten()).backward()
+            finally:
+                QF._TableProjections.apply = orig
+            if table:
+                assert calls == [1 + 12 * 3] and m._last_cond_form == "table", calls
+            res[table] = (logits.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+    finally:
+        QF.USE_COND_TABLE, QF.COND_TABLE_MIN_RATIO, QF.COND_TABLE_GROUPING = old
+    assert rel_err(res[True][0], res[False][0]) < 1e-5
+    for n, gref in res[False][1].items():
+        assert grad_err(res[True][1][n], gref, floor=1e-7) < 5e-5, n
+
+
 def test_out_of_range_positions_are_flagged_not_dereferenced():
     from qarig import functional as QF
     from qarig import ops

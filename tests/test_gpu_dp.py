@@ -172,46 +172,120 @@ def test_rccl_single_rank_overlapped_allreduce_path():
     assert torch.equal(got, want)
 
 
+def _graph_build(base=True):
+    from models.Codebook import Codebook
+    from models.Transformer import Transformer
+    from qarig.optim import FlatAdam
+    torch.manual_seed(3)
+    g = torch.Generator().manual_seed(4)
+    lr_cb = Codebook(patch_dim=(8, 8) if base else (4, 4), image_dim=(8, 8), image_channel=4, num_embeddings=16).cuda()
+    hr_cb = Codebook(patch_dim=(2, 2), image_dim=(8, 8), image_channel=4, num_embeddings=32).cuda()
+    with torch.no_grad():
+        lr_cb.codebook.weight.copy_(torch.tanh(torch.randn(lr_cb.codebook.weight.shape, generator=g)))
+        hr_cb.codebook.weight.copy_(torch.tanh(torch.randn((32, 16), generator=g)))
+    m = Transformer(use_encoder=not base, use_pos_cond=True, num_enc_layers=None if base else 1, num_dec_layers=2,
+                    num_enc_embedding=None if base else 16, num_dec_embedding=48 if base else 33,
+                    self_attn_heads=8, cross_attn_heads=None if base else 8, transformer_in_dim=64,
+                    transformer_out_dim=33, transformer_hidden_dim=128).cuda()
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.abs().max() == 0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    return lr_cb, hr_cb, m, FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
+
+
+def _graph_batches(n=5):
+    g = torch.Generator().manual_seed(9)
+    return [(torch.tanh(torch.randn((6, 4, 8, 8), generator=g)), torch.randint(0, 17 - 12 + 1, (6,), generator=g))
+            for _ in range(n)]
+
+
+def _eager_reference(base=True):
+    from qarig import pipeline
+    lr_cb, hr_cb, m, opt = _graph_build(base)
+    losses = []
+    for z, rand in _graph_batches():
+        hr_in, lr_in, hr_tg = pipeline.tokenize(z.cuda(), lr_cb, hr_cb, base)
+        hr_in, hr_tg, pos = pipeline.slide(hr_in, hr_tg, 12, rand)
+        losses.append(float(pipeline.train_step(m, opt, hr_in, lr_in, hr_tg, pos, dp=False, pos_bound=17)))
+    return opt.flat_param.detach().clone(), losses
+
+
 def test_graphed_train_step_matches_eager_steps():
     """pipeline.GraphedTrainStep: after its eager warm-up the step is replayed from a captured
     HIP graph (tokenisation, forward, loss, backward, Adam with device-side step scalars);
     five steps on changing batches must leave the weights of five eager steps."""
-    from models.Codebook import Codebook
-    from models.Transformer import Transformer
     from qarig import pipeline
-    from qarig.optim import FlatAdam
-
-    def build():
-        torch.manual_seed(3)
-        g = torch.Generator().manual_seed(4)
-        lr_cb = Codebook(patch_dim=(8, 8), image_dim=(8, 8), image_channel=4, num_embeddings=16).cuda()
-        hr_cb = Codebook(patch_dim=(2, 2), image_dim=(8, 8), image_channel=4, num_embeddings=32).cuda()
-        with torch.no_grad():
-            lr_cb.codebook.weight.copy_(torch.tanh(torch.randn((16, 256), generator=g)))
-            hr_cb.codebook.weight.copy_(torch.tanh(torch.randn((32, 16), generator=g)))
-        m = Transformer(use_encoder=False, use_pos_cond=True, num_enc_layers=None, num_dec_layers=2,
-                        num_enc_embedding=None, num_dec_embedding=48, self_attn_heads=8,
-                        cross_attn_heads=None, transformer_in_dim=64, transformer_out_dim=33,
-                        transformer_hidden_dim=128).cuda()
-        with torch.no_grad():
-            for p in m.parameters():
-                if p.abs().max() == 0:
-                    p.copy_(torch.randn(p.shape, generator=g) * 0.05)
-        return lr_cb, hr_cb, m, FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
-
-    g = torch.Generator().manual_seed(9)
-    batches = [(torch.tanh(torch.randn((6, 4, 8, 8), generator=g)).cuda(),
-                torch.randint(0, 17 - 12 + 1, (6,), generator=g)) for _ in range(5)]
-    lr_cb, hr_cb, m, opt = build()
-    losses_e = []
-    for z, rand in batches:
-        hr_in, lr_in, hr_tg = pipeline.tokenize(z, lr_cb, hr_cb, True)
-        hr_in, hr_tg, pos = pipeline.slide(hr_in, hr_tg, 12, rand)
-        losses_e.append(float(pipeline.train_step(m, opt, hr_in, lr_in, hr_tg, pos, dp=False, pos_bound=17)))
-    want = opt.flat_param.detach().clone()
-    lr_cb, hr_cb, m, opt = build()
+    want, losses_e = _eager_reference()
+    lr_cb, hr_cb, m, opt = _graph_build()
     step = pipeline.GraphedTrainStep(m, opt, lr_cb, hr_cb, True, 12, warmup=2)
-    losses_g = [float(step(z, rand)) for z, rand in batches]
+    losses_g = [float(step(z.cuda(), rand)) for z, rand in _graph_batches()]
     assert step.graph is not None and opt.step_count == 5
     assert torch.equal(opt.flat_param, want)
     assert losses_g == losses_e
+
+
+def _graph_worker(rank, world, port, q, backend, base):
+    from conftest import PKG, ROOT
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from qarig import functional as QF
+    from qarig import optim as qoptim
+    from qarig import parallel, pipeline
+    QF.COND_TABLE_MIN_RATIO = 0
+    parallel.init(backend=backend, force=True)
+    torch.cuda.set_device(0)
+    lr_cb, hr_cb, m, _ = _graph_build(base)
+    qoptim.BUCKET_ELEMS = 40_000                     # several buckets -> several graph segments
+    opt = qoptim.FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    parallel.broadcast_params(opt.flat_param)
+    opt.enable_allreduce_overlap(force=True)
+    nb = len(opt._bucket_range)
+    step = pipeline.GraphedTrainStep(m, opt, lr_cb, hr_cb, base, 12, warmup=2)
+    assert step.segmented
+    for z, rand in _graph_batches():
+        loss = step(parallel.shard(z).cuda(), parallel.shard(rand))
+    segs = len(step.graph.graphs)
+    launched = sorted(b for bs in step.graph.bucket_after for b in bs)
+    if rank == 0:
+        q.put((opt.flat_param.detach().cpu(), float(loss), segs, nb, launched))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,backend,base", [(1, "nccl", True), (2, "gloo", True), (2, "gloo", False)])
+def test_segmented_graph_step_with_bucket_allreduces(world, backend, base):
+    """GraphedTrainStep under data parallelism: forward + backward replayed as HIP-graph SEGMENTS cut
+    at the gradient buckets, the bucket all-reduces issued between the segments (over RCCL with one
+    rank: bit-identical to eager steps; over gloo with two ranks on half batches: the weights of
+    single-process steps on the whole batches up to summation order), Adam behind the last one."""
+    want, _ = _eager_reference(base)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, q, backend, base)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue
+    got = None
+    for _ in range(180):
+        try:
+            got = q.get(timeout=1)
+            break
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()
+    assert got is not None and all(p.exitcode == 0 for p in procs)
+    flat, loss, segs, nb, launched = got
+    assert nb > 2 and segs > 1 and launched == list(range(nb)), (segs, nb, launched)
+    if world == 1:
+        assert torch.equal(flat, want.cpu())
+    else:
+        assert float((flat - want.cpu()).abs().max()) < 5e-5 * float(want.abs().max())

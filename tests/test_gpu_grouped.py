@@ -179,10 +179,13 @@ def _encdec(seed=5, layers=3):
     return m.cuda()
 
 
-@pytest.mark.parametrize("mode", ["all", "layer"])
-def test_transformer_step_grouped_vs_ungrouped(mode):
+@pytest.mark.parametrize("mode,cond_form", [("all", "table"), ("layer", "table"), ("all", "tokens"), ("layer", "tokens")])
+def test_transformer_step_grouped_vs_ungrouped(mode, cond_form):
     """One enc-dec training step with the grouped q/k/v + cross-attention k/v launches (both groupings of
-    the cross-attention pairs) against the same step with grouping off: logits, loss, every gradient."""
+    the cross-attention pairs) against the same step with grouping off: logits, loss, every gradient.
+    cond_form "tokens": per-token conditioning (no position table) with its 9 projections per decoder
+    layer evaluated as grouped launches (QF.CondTokens; one group for the decoder, or one per layer)
+    against one Linear node per projection."""
     from qarig import functional as QF
     from qarig.optim import FlatAdam
     N, S, Se = 2, 128, 64
@@ -192,21 +195,27 @@ def test_transformer_step_grouped_vs_ungrouped(mode):
     tg = torch.randint(0, 50, (N, S), generator=g).cuda()
     pos = (torch.arange(S)[None] + torch.tensor([[0], [7]])).cuda()
     res = {}
-    old = (QF.MLP_GROUPED, QF.CROSS_KV_GROUPING, QF.COND_TABLE_MIN_RATIO)
+    old = (QF.MLP_GROUPED, QF.CROSS_KV_GROUPING, QF.COND_TABLE_MIN_RATIO, QF.USE_COND_TABLE, QF.USE_COND_GROUPS,
+           QF.COND_TABLE_GROUPING)
     try:
         QF.COND_TABLE_MIN_RATIO = 0
+        QF.USE_COND_TABLE = cond_form == "table"
+        QF.COND_TABLE_GROUPING = mode
         for tag, grouped in (("on", "1"), ("off", "0")):
             QF.MLP_GROUPED, QF.CROSS_KV_GROUPING = grouped, mode
+            QF.USE_COND_GROUPS = grouped == "1"
             m = _encdec()
             opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.5, 0.999))
             opt.zero_grad()
             logits = m(x, xe, pos, pos_bound=S + 8)
+            assert m._last_cond_form == ("table" if cond_form == "table" else "per_token")
             loss = QF.cross_entropy(logits.view(-1, 50), tg.flatten())
             loss.backward()
             res[tag] = (logits.detach().clone(), float(loss.detach()), opt.flat_grad.clone(),
                         {k: p.grad.clone() for k, p in m.named_parameters()})
     finally:
-        QF.MLP_GROUPED, QF.CROSS_KV_GROUPING, QF.COND_TABLE_MIN_RATIO = old
+        (QF.MLP_GROUPED, QF.CROSS_KV_GROUPING, QF.COND_TABLE_MIN_RATIO, QF.USE_COND_TABLE, QF.USE_COND_GROUPS,
+         QF.COND_TABLE_GROUPING) = old
     assert rel_err(res["on"][0], res["off"][0]) < 5e-6
     assert abs(res["on"][1] - res["off"][1]) < 1e-5
     for k, gref in res["off"][3].items():

@@ -35,6 +35,9 @@ class Trace(TorchDispatchMode):
         frames = [f for f in traceback.extract_stack()[:-1]
                   if ROOT in f.filename and "dispatch_trace" not in f.filename]
         where = " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in frames[-3:][::-1]) or "(autograd engine)"
+        if name.startswith(("add.", "add_.")):
+            node = torch._C._current_autograd_node()
+            where += f"  [while running {node.name() if node is not None else None}]"
         extra = ""
         if name.startswith(("copy_", "add_", "add.", "clone", "_to_copy", "fill_", "zero_", "cat", "stack")) and args:
             t = args[0] if isinstance(args[0], torch.Tensor) else (args[0][0] if args[0] else None)

@@ -20,5 +20,5 @@ rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 echo "sq2 done"
 # the raw per-dispatch CSVs are large; keep only what profiles/summarize.py reads
 find $OUT/${TAG}_* -name '*_agent_info.csv' -delete 2>/dev/null || true
-python3 profiles/summarize.py $TAG --on-box
+python3 profiles/summarize.py $TAG --on-box $*
 ls -la $OUT/${TAG}_summary
