@@ -52,6 +52,25 @@ int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH, int pW,
                   const float* codebook, int K, int D, int64_t* out_idx, void* workspace,
                   size_t ws_bytes, void* stream);
 
+/* The same search through a coarse pass on the bf16 MFMA (every operand split into three bf16
+ * pieces that add up to it exactly, six products + |w|^2 per 32 x 32 tile), a per-row certificate
+ * (second-smallest - smallest > 3 eps, eps a proven bound of the coarse error) and the literal
+ * fp32 re-scan of every row without one: bit-identical indices to qarig_bmu_fwd's exact kernels.
+ * qarig_bmu_fwd takes this form by itself where it applies (D <= 16, D % 4 == 0, K % 32 == 0,
+ * K <= 1024, >= 24576 rows); this entry forces it and counts the re-scanned rows into
+ * uncertified[0] (device unsigned[8], caller-zeroed, may be NULL; [1..3] += clock64() cycles of the
+ * staging / scan / finish phases of every block, [4] += blocks: tools/bmu_bench.py).  models/Codebook.py:77-99. */
+int qarig_bmu_fwd_coarse(const float* x, int N, int C, int H, int W, int pH, int pW,
+                         const float* codebook, int K, int D, int64_t* out_idx,
+                         unsigned* uncertified, const void* prepared, void* stream);
+/* The staged form of a codebook for `prepared` above (may be NULL: every workgroup then stages the
+ * codebook itself): qarig_bmu_prepare_bytes(K, D) bytes (0 = the coarse form does not apply), written
+ * by qarig_bmu_prepare.  A frozen codebook -- tokenising a dataset (generate_fmap_dataset.py /
+ * train_quantized_transformer.py:412-421 call get_patches_bmu with fixed codebooks every step) -- is
+ * prepared once; its image must be rebuilt after the codebook changes. */
+size_t qarig_bmu_prepare_bytes(int K, int D);
+int qarig_bmu_prepare(const float* codebook, int K, int D, void* image, void* stream);
+
 /* ---- Linear algebra core ----------------------------------------------------- */
 
 /* C[M,N] = epilogue(sum_k A(m,k) B(n,k)).  a_kcontig: A stored [M][K] (1) or

@@ -1019,6 +1019,366 @@ __global__ __launch_bounds__(256) void bmu_fewrows_argmin_kernel(const float* __
 
 using namespace qarig;
 
+// ---------------------------------------------------------------------------------------------
+// Coarse pass on the bf16 MFMA + certificate + exact re-scan (D <= 16, K <= 1024, K % 32 == 0).
+//
+// The exact kernels above run at the SUM of their fp32-MFMA and vector-ALU cycles (the two do not
+// overlap on this chip: DESIGN 10) -- 9 MFMAs of 64 cycles and a 16-candidate scan per 32 x 32
+// tile.  The bf16 MFMA is 16x faster per product AND co-executes with the vector ALU, so here the
+// candidates' t = -2 x.w + |w|^2 come from the bf16 pipe at (almost) full fp32 accuracy and the
+// scan is all that is left on the vector ALU:
+//   * every operand is split into three bf16 pieces, v = h + m + l EXACTLY (3 x 8 = 24 mantissa
+//     bits, successive round-to-nearest remainders), and the six products hh, hm, mh, hl, lh, mm are
+//     accumulated in fp32 by six v_mfma_f32_32x32x16_bf16 (K = 16 = the whole patch width in one
+//     instruction); |w|^2 (its exact fp32 chain, split the same way) enters through a seventh MFMA
+//     against a row of ones.  7 x 32 = 224 matrix cycles per tile, under the scan's ~256.
+//   * what the coarse value can be off by: the three dropped products (<= 2^-26 |x||2w| per element)
+//     and the rounding of at most 7 x 16 fp32 additions, against the definition's own 17-step chain:
+//     |t~ - t| <= eps = 1e-5 (|x|^2 + 2 max|w|^2)  (gamma_112 = 6.7e-6 on sum|terms| <= 2|x||w| + |w|^2).
+//   * certificate: the scan keeps (min, its first index, second-smallest) of t~ per row.  If
+//     second - min > 3 eps, the exact minimum is the same candidate and no other candidate can tie
+//     with it after the definition's `+ |x|^2`, clamp and sqrt (those collapse values closer than
+//     ~2^-22 (t + |x|^2) < eps): the index is final.  Every other row (near-ties, exact ties,
+//     non-finite data) is re-scanned with the literal definition -- codes rebuilt EXACTLY from their
+//     LDS image (h + m + l; a code whose split is not exact, e.g. a denormal piece, sends the block
+//     to the fp32 codebook in memory instead), the row's fp32 values from an LDS copy -- so the
+//     result is bit-identical to oracle/bmu_oracle.c on every input, as before.
+typedef __bf16 bmu_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int bmu_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t bmu_pack_bf16(float a, float b) {   // a in the low half
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, b2));
+}
+// (a, b) = H + M + L piecewise; returns false if the three pieces do not add up to the values
+__device__ __forceinline__ bool bmu_split3(float a, float b, uint32_t& H, uint32_t& M, uint32_t& L) {
+    H = bmu_pack_bf16(a, b);
+    const float ha = __uint_as_float(H << 16), hb = __uint_as_float(H & 0xffff0000u);
+    const float ra = a - ha, rb = b - hb;
+    M = bmu_pack_bf16(ra, rb);
+    const float ma = __uint_as_float(M << 16), mb = __uint_as_float(M & 0xffff0000u);
+    const float sa = ra - ma, sb = rb - mb;
+    L = bmu_pack_bf16(sa, sb);
+    const float la = __uint_as_float(L << 16), lb = __uint_as_float(L & 0xffff0000u);
+    return (ha + ma) + la == a && (hb + mb) + lb == b;
+}
+__device__ __forceinline__ float bmu_join3(uint32_t H, uint32_t M, uint32_t L, int hi) {
+    const uint32_t mask = hi ? 0xffff0000u : 0u;
+    const float h = __uint_as_float(hi ? (H & mask) : (H << 16));
+    const float m = __uint_as_float(hi ? (M & mask) : (M << 16));
+    const float l = __uint_as_float(hi ? (L & mask) : (L << 16));
+    return (h + m) + l;
+}
+
+constexpr float BMU_COARSE_EPS = 1e-5f;
+
+// PREP: stages the image of a codebook (what every block of the search kernel builds in LDS) into
+// `image` instead: [planes: K x 128 B][|w|^2: K x 4 B][max |w|^2, inexact flag: 8 B].  A frozen
+// codebook (tokenising a dataset, the Transformer training loop) is prepared once and its image
+// copied into LDS by every later launch (qarig_bmu_prepare).
+template <bool PREP>
+__global__ __launch_bounds__(NTHREADS, 2) void bmu_coarse_kernel(PatchGeom g, PatchOffsets po,
+                                                                 const float* __restrict__ w, int K,
+                                                                 int64_t* __restrict__ out,
+                                                                 unsigned* __restrict__ stats,
+                                                                 const unsigned char* __restrict__ image_in,
+                                                                 unsigned char* __restrict__ image_out) {
+    // planes [hi | mid | lo | w2-pieces] of fragments: [plane][tile][half][code] x 16 B
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    bmu_u32x4* frag = reinterpret_cast<bmu_u32x4*>(lds_raw);
+    const int NT = K >> 5;
+    const int plane = NT * 64;                                  // fragments per plane
+    float* W2 = reinterpret_cast<float*>(frag + 4 * plane);     // [K] exact |w|^2 chains
+    float* XS = W2 + K;                                         // [128][16] the block's patch rows, fp32
+    float* red = XS + 128 * 16;                                 // [8] reductions, [8..12) flag masks, [12] inexact
+    unsigned* flagmask = reinterpret_cast<unsigned*>(red + 8);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, cl = lane & 31;
+    const int p0 = blockIdx.x * 128;
+    const int D = g.D;
+    const long long tc0 = stats ? clock64() : 0;      // phase clocks (tests / tools only)
+
+    // ---- this lane's patch row: 8 of its 16 elements (e = 8h .. 8h+7); the loads are issued first
+    // so that their latency runs under the codebook staging
+    const int prow = p0 + wave * 32 + cl;
+    const bool live = prow < g.R;
+    float xv[8];
+    if constexpr (!PREP) {
+        const float* px = g.x + patch_row_base_fast(g, po, live ? prow : g.R - 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int off = h ? po.off[8 + q] : po.off[q];        // (po.off[e >= D] = po.off[0]: a valid address)
+            xv[q] = px[off];
+        }
+    }
+    // ---- stage the codebook: -2w split three ways, |w|^2 chain, its three pieces; two codes per
+    // pass with all eight 16-B loads in flight
+    float w2max = 0.0f;
+    int inexact = 0;
+    const size_t image_bytes = (size_t)K * 132;               // planes + |w|^2 (a multiple of 16: K % 32 == 0)
+    if (!PREP && image_in) {
+        // a prepared image: straight into LDS, 16 B per lane, every load of a pass in flight
+        const uint4* src = reinterpret_cast<const uint4*>(image_in);
+        uint4* dst = reinterpret_cast<uint4*>(lds_raw);
+        const int n16 = (int)(image_bytes >> 4);
+        for (int i = tid; i < n16; i += 8 * NTHREADS) {
+            uint4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = src[min(i + u * NTHREADS, n16 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i + u * NTHREADS < n16) dst[i + u * NTHREADS] = t[u];
+        }
+        const float* hdr = reinterpret_cast<const float*>(image_in + image_bytes);
+        w2max = hdr[0];
+        inexact = hdr[1] != 0.0f;
+    } else
+    for (int k0 = tid; k0 < K; k0 += 2 * NTHREADS) {
+        float4 raw[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = min(k0 + u * NTHREADS, K - 1);
+            const float4* wk4 = reinterpret_cast<const float4*>(w + (int64_t)k * D);   // host: D % 4 == 0, 16-B aligned
+#pragma unroll
+            for (int q = 0; q < 4; ++q) raw[u][q] = 4 * q < D ? wk4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = k0 + u * NTHREADS;
+            if (k >= K) break;
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[4 * q] = raw[u][q].x; v[4 * q + 1] = raw[u][q].y; v[4 * q + 2] = raw[u][q].z; v[4 * q + 3] = raw[u][q].w;
+            }
+            float w2 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) w2 = e < D ? fmaf(v[e], v[e], w2) : w2;
+            W2[k] = w2;
+            w2max = fmaxf(w2max, w2);
+            if (!(w2 <= 3.0e38f)) inexact = 1;          // a NaN / Inf code: the definition's clamp decides, exactly
+            const int T = k >> 5, c = k & 31;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                bmu_u32x4 H, M, L;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t a, b, cc;
+                    if (!bmu_split3(-2.0f * v[8 * hh + 2 * q], -2.0f * v[8 * hh + 2 * q + 1], a, b, cc)) inexact = 1;
+                    H[q] = a; M[q] = b; L[q] = cc;
+                }
+                const int at = (T * 2 + hh) * 32 + c;
+                frag[at] = H;
+                frag[plane + at] = M;
+                frag[2 * plane + at] = L;
+            }
+            // |w|^2 = three bf16 pieces (k = 0, 1, 2 of the seventh MFMA, against ones)
+            const float q0 = __uint_as_float(bmu_pack_bf16(w2, 0.0f) << 16);
+            const float r1 = w2 - q0;
+            const uint32_t P01 = bmu_pack_bf16(w2, r1);
+            const float q1 = __uint_as_float(P01 & 0xffff0000u);
+            const float r2 = r1 - q1;
+            const uint32_t P2 = bmu_pack_bf16(r2, 0.0f);
+            if ((q0 + q1) + __uint_as_float(P2 << 16) != w2) inexact = 1;
+            const int at = (T * 2) * 32 + c;
+            frag[3 * plane + at] = bmu_u32x4{P01, P2, 0u, 0u};
+            frag[3 * plane + at + 32] = bmu_u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    float x2a = 0.0f;
+    bmu_u32x4 XH = {0u, 0u, 0u, 0u}, XM = XH, XL = XH;
+    if constexpr (!PREP) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xv[q] = 8 * h + q < D ? xv[q] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t a, b, cc;
+            if (!bmu_split3(xv[2 * q], xv[2 * q + 1], a, b, cc)) inexact = 1;   // (the coarse value is then off; the
+            XH[q] = a; XM[q] = b; XL[q] = cc;                                   //  block re-scans every row exactly)
+            x2a += xv[2 * q] * xv[2 * q] + xv[2 * q + 1] * xv[2 * q + 1];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) XS[(wave * 32 + cl) * 16 + 8 * h + q] = xv[q];
+        x2a += __shfl_xor(x2a, 32);
+    }
+    const bmu_u32x4 ONES = h == 0 ? bmu_u32x4{0x3f803f80u, 0x00003f80u, 0u, 0u} : bmu_u32x4{0u, 0u, 0u, 0u};
+    // block-wide max |w|^2 and the inexact flag
+    w2max = wave_max(w2max);
+    inexact = __any(inexact);
+    if (lane == 0) { red[wave] = w2max; red[4 + wave] = inexact ? 1.0f : 0.0f; }
+    __syncthreads();
+    w2max = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const bool any_inexact = (red[4] + red[5] + red[6] + red[7]) != 0.0f;   // then every row is re-scanned
+    if constexpr (PREP) {
+        const uint4* src = reinterpret_cast<const uint4*>(lds_raw);
+        uint4* dst = reinterpret_cast<uint4*>(image_out);
+        for (int i = tid; i < (int)(image_bytes >> 4); i += NTHREADS) dst[i] = src[i];
+        if (tid == 0) {
+            float* hdr = reinterpret_cast<float*>(image_out + image_bytes);
+            hdr[0] = w2max;
+            hdr[1] = any_inexact ? 1.0f : 0.0f;
+        }
+        return;
+    }
+
+    const long long tc1 = stats ? clock64() : 0;
+    // ---- the coarse scan, software-pipelined: the seven MFMAs of tile T+1 (a dependent chain of
+    // 32-cycle instructions on the matrix pipe) are issued between the scan steps of tile T (8
+    // vector-ALU instructions = 32 cycles each pair of steps), so neither pipe waits for the other
+    // scan state: (min, second-smallest) of t~ and WHERE the minimum first appeared -- the register index
+    // r inside its tile (an inline constant of the select: no per-candidate code arithmetic) and the tile
+    float best = INFINITY, sec = INFINITY;
+    int ridx = 0, tidx = -1;
+    const bmu_bf16x8 bXH = __builtin_bit_cast(bmu_bf16x8, XH), bXM = __builtin_bit_cast(bmu_bf16x8, XM),
+                     bXL = __builtin_bit_cast(bmu_bf16x8, XL), bON = __builtin_bit_cast(bmu_bf16x8, ONES);
+    const bmu_u32x4* fl = frag + h * 32 + cl;
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+    // fragments of a tile: [0] hi, [1] mid, [2] lo, [3] |w|^2 pieces; double-buffered, a tile's fragments
+    // are read from LDS one whole step before the MFMAs that take them
+#define BMU_FRAGS(F, T_)                                                                            \
+    {                                                                                               \
+        const int t_ = min(T_, NT - 1) * 64;                                                         \
+        F[0] = __builtin_bit_cast(bmu_bf16x8, fl[t_]);                                               \
+        F[1] = __builtin_bit_cast(bmu_bf16x8, fl[plane + t_]);                                       \
+        F[2] = __builtin_bit_cast(bmu_bf16x8, fl[2 * plane + t_]);                                   \
+        F[3] = __builtin_bit_cast(bmu_bf16x8, fl[3 * plane + t_]);                                   \
+    }
+#define BMU_MFMA(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC, 0, 0, 0)
+    // one candidate: 4 vector-ALU instructions (v_med3, v_cmp, 2 x v_cndmask)
+#define BMU_SCAN(ACC, r)                                                                            \
+    {                                                                                               \
+        const float t_ = ACC[r];                                                                    \
+        sec = __builtin_amdgcn_fmed3f(best, t_, sec);                                               \
+        const bool lt_ = t_ < best;                                                                 \
+        ridx = lt_ ? (r) : ridx;                                                                    \
+        best = lt_ ? t_ : best;                                                                     \
+    }
+    // NXT = chain of tile TC + 1 from the fragments FC (read a step ago), interleaved with the scan of
+    // CUR (tile TC); FN receives the fragments of tile TC + 2 (clamped past the end: harmless repeats)
+#define BMU_STEP(CUR, NXT, TC, FC, FN)                                                              \
+    {                                                                                               \
+        BMU_FRAGS(FN, (TC) + 2)                                                                      \
+        const float before_ = best;                                                                 \
+        NXT = zero16;                                                                                \
+        BMU_MFMA(NXT, FC[3], bON); BMU_SCAN(CUR, 0) BMU_SCAN(CUR, 1)                                 \
+        BMU_MFMA(NXT, FC[2], bXH); BMU_SCAN(CUR, 2) BMU_SCAN(CUR, 3)                                 \
+        BMU_MFMA(NXT, FC[0], bXL); BMU_SCAN(CUR, 4) BMU_SCAN(CUR, 5)                                 \
+        BMU_MFMA(NXT, FC[1], bXM); BMU_SCAN(CUR, 6) BMU_SCAN(CUR, 7)                                 \
+        BMU_MFMA(NXT, FC[1], bXH); BMU_SCAN(CUR, 8) BMU_SCAN(CUR, 9)                                 \
+        BMU_MFMA(NXT, FC[0], bXM); BMU_SCAN(CUR, 10) BMU_SCAN(CUR, 11) BMU_SCAN(CUR, 12)             \
+        BMU_MFMA(NXT, FC[0], bXH); BMU_SCAN(CUR, 13) BMU_SCAN(CUR, 14) BMU_SCAN(CUR, 15)             \
+        tidx = best < before_ ? (TC) : tidx;                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) {                                           \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                       \
+        }                                                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                           \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                      \
+        }                                                                                            \
+    }
+    f32x16 accA = zero16, accB;
+    bmu_bf16x8 fA[4], fB[4];
+    BMU_FRAGS(fA, 0)
+    BMU_FRAGS(fB, 1)
+    BMU_MFMA(accA, fA[3], bON); BMU_MFMA(accA, fA[2], bXH); BMU_MFMA(accA, fA[0], bXL); BMU_MFMA(accA, fA[1], bXM);
+    BMU_MFMA(accA, fA[1], bXH); BMU_MFMA(accA, fA[0], bXM); BMU_MFMA(accA, fA[0], bXH);
+    int T = 0;
+    for (; T + 2 <= NT; T += 2) {
+        BMU_STEP(accA, accB, T, fB, fA)          // scans tile T, chains tile T+1 (fB), reads tile T+2 into fA
+        BMU_STEP(accB, accA, T + 1, fA, fB)      // scans tile T+1, chains tile T+2 (fA), reads tile T+3 into fB
+    }
+    if (T < NT) BMU_STEP(accA, accB, T, fB, fA)
+#undef BMU_STEP
+#undef BMU_SCAN
+#undef BMU_MFMA
+#undef BMU_FRAGS
+    const long long tc2 = stats ? clock64() : 0;
+    // ---- merge the two lane halves of a row, certify
+    const int idx = tidx < 0 ? INT_MAX : tidx * 32 + 4 * h + (ridx & 3) + 8 * (ridx >> 2);
+    BmuState st = bmu_merge(BmuState{best, idx, sec},
+                            BmuState{__shfl_xor(best, 32), __shfl_xor(idx, 32), __shfl_xor(sec, 32)});
+    const float eps = BMU_COARSE_EPS * (1.001f * x2a + 2.0f * w2max);
+    const bool certified = !any_inexact && (st.sec - st.d2 > 3.0f * eps);
+    const int flag = live && h == 0 && !certified;
+    if (live && h == 0 && certified) out[prow] = (int64_t)st.idx;
+    const unsigned long long fm = __ballot(flag);
+    if (lane == 0) flagmask[wave] = (unsigned)fm;
+    __syncthreads();
+    if (stats && tid == 0) {
+        const unsigned n = __popc(flagmask[0]) + __popc(flagmask[1]) + __popc(flagmask[2]) + __popc(flagmask[3]);
+        if (n) atomicAdd(stats, n);
+    }
+    // ---- literal re-scan of the rows without a certificate
+    const bool from_memory = any_inexact;
+    float* rs = red;                                   // [4] per-wave minima (red[0..3] no longer needed)
+    int* ri = reinterpret_cast<int*>(red + 4);
+    for (int wv = 0; wv < 4; ++wv)
+    for (unsigned m = flagmask[wv]; m; m &= m - 1) {
+        const int r = wv * 32 + __ffs((int)m) - 1;
+        float xs[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xs[e] = XS[r * 16 + e];
+        float x2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x2 = e < D ? fmaf(xs[e], xs[e], x2) : x2;
+        float bd = INFINITY;
+        int bi = INT_MAX;
+        for (int k = tid; k < K; k += NTHREADS) {
+            float m2[16];
+            if (from_memory) {
+                const float* wk = w + (int64_t)k * D;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) m2[e] = e < D ? -2.0f * wk[e] : 0.0f;
+            } else {
+                const int T = k >> 5, c = k & 31;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int at = (T * 2 + hh) * 32 + c;
+                    const bmu_u32x4 H = frag[at], M = frag[plane + at], L = frag[2 * plane + at];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        m2[8 * hh + 2 * q] = bmu_join3(H[q], M[q], L[q], 0);
+                        m2[8 * hh + 2 * q + 1] = bmu_join3(H[q], M[q], L[q], 1);
+                    }
+                }
+            }
+            float acc = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc = e < D ? fmaf(m2[e], xs[e], acc) : acc;
+            const float d = sqrtf(fmaxf((acc + W2[k]) + x2, 0.0f));
+            if (d < bd) { bd = d; bi = k; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float s2 = __shfl_xor(bd, o);
+            const int i2 = __shfl_xor(bi, o);
+            if (s2 < bd || (s2 == bd && i2 < bi)) { bd = s2; bi = i2; }
+        }
+        __syncthreads();
+        if (lane == 0) { rs[wave] = bd; ri[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (rs[q] < bd || (rs[q] == bd && ri[q] < bi)) { bd = rs[q]; bi = ri[q]; }
+            out[p0 + r] = bi == INT_MAX ? 0 : (int64_t)bi;
+        }
+    }
+    if (stats && tid == 0) {
+        const long long tc3 = clock64();
+        atomicAdd(stats + 1, (unsigned)(tc1 - tc0));
+        atomicAdd(stats + 2, (unsigned)(tc2 - tc1));
+        atomicAdd(stats + 3, (unsigned)(tc3 - tc2));
+        atomicAdd(stats + 4, 1u);
+    }
+}
+
 static int bmu_code_tiles(int K) { return (K + BM - 1) / BM; }
 
 static constexpr int FEWROWS_MAX = 128, FEWROWS_MIN_D = 512;
@@ -1030,6 +1390,91 @@ extern "C" size_t qarig_bmu_workspace_bytes(int64_t rows, int K) {
     // few-rows form: rows x K dot products + |w|^2 + |x|^2
     if (rows <= FEWROWS_MAX) need = need > ((size_t)rows * K + K + rows) * 4 ? need : ((size_t)rows * K + K + rows) * 4;
     return need;
+}
+
+static bool bmu_coarse_ok(const PatchGeom& g, int K, const float* codebook) {
+    return g.D <= 16 && g.D % 4 == 0 && K % 32 == 0 && K >= 32 && K <= 1024 && g.R > 25 &&
+           (((uintptr_t)codebook) & 15) == 0;
+}
+
+static void bmu_patch_offsets(const PatchGeom& g, PatchOffsets& po) {
+    for (int e = 0; e < 16; ++e) {
+        const int ee = e < g.D ? e : 0;
+        const int j = ee % g.pW, i = (ee / g.pW) % g.pH, c = ee / (g.pW * g.pH);
+        po.off[e] = (c * g.H + i) * g.W + j;
+    }
+    auto magic = [](int d, unsigned& m, int& sh) {
+        int L = 0;
+        while ((1LL << L) < d) ++L;
+        sh = 31 + L;
+        m = (unsigned)((1ULL << sh) / (unsigned long long)d + 1ULL);
+    };
+    magic(g.gh * g.gw, po.m_per, po.sh_per);
+    magic(g.gw, po.m_gw, po.sh_gw);
+}
+
+static size_t bmu_coarse_lds(int K) { return (size_t)K * 128 + (size_t)K * 4 + 128 * 16 * 4 + 16 * 4; }
+static void bmu_coarse_attr(size_t shm) {
+    static size_t attr_shm = 0;
+    if (shm > attr_shm) {
+        (void)hipFuncSetAttribute((const void*)bmu_coarse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipFuncSetAttribute((const void*)bmu_coarse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        attr_shm = shm;
+    }
+}
+
+static int bmu_coarse_launch(const PatchGeom& g, const float* codebook, int K, int64_t* out_idx,
+                             unsigned* stats, const void* image, hipStream_t st) {
+    PatchOffsets po;
+    bmu_patch_offsets(g, po);
+    const size_t shm = bmu_coarse_lds(K);
+    bmu_coarse_attr(shm);
+    hipLaunchKernelGGL(bmu_coarse_kernel<false>, dim3((g.R + 127) / 128), dim3(NTHREADS), shm, st, g, po, codebook, K,
+                       out_idx, stats, (const unsigned char*)image, (unsigned char*)nullptr);
+    QARIG_CHECK_LAUNCH("bmu coarse");
+    return QARIG_OK;
+}
+
+// Image of a codebook for qarig_bmu_fwd_coarse (its `prepared` argument): bytes, and the one-block kernel
+// that writes it.  0 bytes = the coarse form does not take this codebook.
+extern "C" size_t qarig_bmu_prepare_bytes(int K, int D) {
+    if (D < 1 || D > 16 || D % 4 || K < 32 || K > 1024 || K % 32) return 0;
+    return (size_t)K * 132 + 16;
+}
+extern "C" int qarig_bmu_prepare(const float* codebook, int K, int D, void* image, void* stream) {
+    QARIG_CHECK_ARG(codebook && image, "bmu_prepare: null pointer");
+    QARIG_CHECK_ARG(qarig_bmu_prepare_bytes(K, D) != 0 && (((uintptr_t)codebook | (uintptr_t)image) & 15) == 0,
+                    "bmu_prepare: needs D <= 16, D %% 4 == 0, K %% 32 == 0, 32 <= K <= 1024, 16-B aligned pointers");
+    PatchGeom g{nullptr, 1, 1, 1, 1, 1, 1, 1, 1, D, 1};
+    PatchOffsets po{};
+    const size_t shm = bmu_coarse_lds(K);
+    bmu_coarse_attr(shm);
+    hipLaunchKernelGGL(bmu_coarse_kernel<true>, dim3(1), dim3(NTHREADS), shm, (hipStream_t)stream, g, po, codebook, K,
+                       (int64_t*)nullptr, (unsigned*)nullptr, (const unsigned char*)nullptr, (unsigned char*)image);
+    QARIG_CHECK_LAUNCH("bmu prepare");
+    return QARIG_OK;
+}
+
+// The coarse-pass form on its own (tests, benchmarks): fails where qarig_bmu_fwd would fall back to
+// the exact kernels; *uncertified (device, caller-zeroed, may be NULL) += rows that took the exact
+// re-scan.
+extern "C" int qarig_bmu_fwd_coarse(const float* x, int N, int C, int H, int W, int pH, int pW,
+                                    const float* codebook, int K, int D, int64_t* out_idx,
+                                    unsigned* uncertified, const void* prepared, void* stream) {
+    QARIG_CHECK_ARG(x && codebook && out_idx, "bmu_coarse: null pointer");
+    QARIG_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && pH > 0 && pW > 0 && K > 0 && pH <= H && pW <= W,
+                    "bmu_coarse: bad extents");
+    QARIG_CHECK_DIMS("bmu_coarse", N, C, H, W);
+    QARIG_CHECK_DIMS("bmu_coarse", K, C, pH, pW);
+    QARIG_CHECK_ARG(D == C * pH * pW, "bmu_coarse: codebook width %d != C*pH*pW = %d", D, C * pH * pW);
+    PatchGeom g{x, N, C, H, W, pH, pW, H / pH, W / pW, D, 0};
+    const int64_t rows = (int64_t)N * g.gh * g.gw;
+    QARIG_CHECK_ARG(rows < INT_MAX, "bmu_coarse: too many patch rows");
+    g.R = (int)rows;
+    QARIG_CHECK_ARG(bmu_coarse_ok(g, K, codebook),
+                    "bmu_coarse: needs D <= 16, D %% 4 == 0, K %% 32 == 0, 32 <= K <= 1024, more than 25 rows");
+    QARIG_CHECK_ARG(!prepared || (((uintptr_t)prepared) & 15) == 0, "bmu_coarse: prepared image must be 16-B aligned");
+    return bmu_coarse_launch(g, codebook, K, out_idx, uncertified, prepared, (hipStream_t)stream);
 }
 
 extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH, int pW,
@@ -1084,6 +1529,12 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
     nsplit = (ctiles + per - 1) / per;
     int64_t* direct = nsplit == 1 ? out_idx : (int64_t*)nullptr;
     static const bool resident_on = []() { const char* e = getenv("QARIG_BMU_RESIDENT"); return !(e && e[0] == '0'); }();
+    // coarse bf16 pass + certificate + exact re-scan where it beats the exact kernels although every
+    // workgroup stages the codebook itself (callers with a frozen codebook pass a prepared image to
+    // qarig_bmu_fwd_coarse instead: qarig.ops.bmu)
+    static const int coarse_env = []() { const char* e = getenv("QARIG_BMU_COARSE"); return e ? atoi(e) : -1; }();
+    if (bmu_coarse_ok(g, K, codebook) && coarse_env != 0 && (coarse_env == 1 || g.R >= 24576))
+        return bmu_coarse_launch(g, codebook, K, out_idx, nullptr, nullptr, st);
     if (D <= 16 && resident_on) {
         const int ks = D <= 4 ? 2 : (D <= 8 ? 4 : 8);
         const int bpc = (2 * ks + 1) * 4;                         // LDS bytes per code

@@ -27,6 +27,9 @@ SIGNATURES = {
     "qarig_last_error": (I, [c_char_p, Z]),
     "qarig_bmu_workspace_bytes": (Z, [L, I]),
     "qarig_bmu_fwd": (I, [P, I, I, I, I, I, I, P, I, I, P, P, Z, P]),
+    "qarig_bmu_fwd_coarse": (I, [P, I, I, I, I, I, I, P, I, I, P, P, P, P]),
+    "qarig_bmu_prepare_bytes": (Z, [I, I]),
+    "qarig_bmu_prepare": (I, [P, I, I, P, P]),
     "qarig_gemm_workspace_bytes": (Z, [I, I, I]),
     "qarig_gemm_f32": (I, [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, I, P, P, Z,
                            P]),

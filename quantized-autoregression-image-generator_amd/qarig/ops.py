@@ -20,6 +20,35 @@ def act_id(name):
 
 
 # --------------------------------------------------------------------------- BMU
+_bmu_images = {}
+
+
+def bmu_image(codebook):
+    """Prepared image of a codebook for the coarse-pass search (include/qarig.h qarig_bmu_prepare), or
+    None where that form does not apply.  Cached per codebook tensor until it changes: torch's version
+    counter, and -- for a parameter FlatAdam owns, whose updates bypass that counter -- the optimiser's
+    step count."""
+    K, D = codebook.shape
+    lib = _lib.load()
+    nb = lib.qarig_bmu_prepare_bytes(K, D)
+    if nb == 0 or codebook.data_ptr() % 16:
+        return None
+    owner = getattr(codebook, "_qarig_owner", None)
+    key = (codebook.data_ptr(), K, D, codebook._version, owner.step_count if owner is not None else -1)
+    hit = _bmu_images.get(id(codebook))
+    if hit is not None and hit[0] == key and hit[1]() is codebook:
+        return hit[2]
+    if torch.cuda.is_current_stream_capturing():
+        return None                       # no allocation / caching inside a capture: the kernel stages by itself
+    import weakref
+    img = torch.empty(nb, dtype=torch.uint8, device=codebook.device)
+    check(lib.qarig_bmu_prepare(ptr(codebook), K, D, ptr(img), stream()), "qarig_bmu_prepare")
+    if len(_bmu_images) > 64:
+        _bmu_images.clear()
+    _bmu_images[id(codebook)] = (key, weakref.ref(codebook), img)
+    return img
+
+
 def bmu(x, codebook, patch_dim):
     """int64 (N*Seq,) best-matching-unit indices of every patch of x (N,C,H,W).
 
@@ -27,18 +56,42 @@ def bmu(x, codebook, patch_dim):
     (reference models/Codebook.py:77-99)."""
     require_cuda(x, codebook)
     x = f32c(x)
+    cb = codebook if (codebook.dtype == torch.float32 and codebook.is_contiguous()) else f32c(codebook)
+    N, C, H, W = x.shape
+    pH, pW = patch_dim
+    K, D = cb.shape
+    rows = N * (H // pH) * (W // pW)
+    out = torch.empty(rows, dtype=torch.int64, device=x.device)
+    lib = _lib.load()
+    # (large launches take the coarse-pass kernel inside qarig_bmu_fwd; a prepared codebook image --
+    # bmu_image / bmu_coarse(prepared=True) -- measured the same launch time as staging the codebook in
+    # every workgroup: that phase is bound by the latency of the patch gather, not by the conversion)
+    nb = lib.qarig_bmu_workspace_bytes(rows, K)
+    ws = workspace(nb, x.device)
+    check(lib.qarig_bmu_fwd(ptr(x), N, C, H, W, pH, pW, ptr(cb), K, D, ptr(out), ptr(ws),
+                            ws.numel(), stream()), "qarig_bmu_fwd")
+    return out
+
+
+def bmu_coarse(x, codebook, patch_dim, prepared=False):
+    """(indices, rows that needed the exact re-scan): the coarse-pass form of `bmu` forced
+    (include/qarig.h qarig_bmu_fwd_coarse); raises where it does not apply.  prepared: through the
+    cached codebook image (bmu_image) instead of staging the codebook in every workgroup."""
+    require_cuda(x, codebook)
+    x = f32c(x)
     codebook = f32c(codebook)
     N, C, H, W = x.shape
     pH, pW = patch_dim
     K, D = codebook.shape
-    rows = N * (H // pH) * (W // pW)
-    out = torch.empty(rows, dtype=torch.int64, device=x.device)
-    lib = _lib.load()
-    nb = lib.qarig_bmu_workspace_bytes(rows, K)
-    ws = workspace(nb, x.device)
-    check(lib.qarig_bmu_fwd(ptr(x), N, C, H, W, pH, pW, ptr(codebook), K, D, ptr(out), ptr(ws),
-                            ws.numel(), stream()), "qarig_bmu_fwd")
-    return out
+    out = torch.empty(N * (H // pH) * (W // pW), dtype=torch.int64, device=x.device)
+    cnt = torch.zeros(8, dtype=torch.int32, device=x.device)    # [0] re-scanned rows, [1..4] phase clocks
+    img = bmu_image(codebook) if prepared else None
+    check(_lib.load().qarig_bmu_fwd_coarse(ptr(x), N, C, H, W, pH, pW, ptr(codebook), K, D, ptr(out), ptr(cnt),
+                                           ptr(img), stream()), "qarig_bmu_fwd_coarse")
+    return out, cnt[:1] if not BMU_COARSE_PHASES else cnt
+
+
+BMU_COARSE_PHASES = False      # tools: return all eight counters
 
 
 # -------------------------------------------------------------------------- GEMM
@@ -476,7 +529,9 @@ def pick_splitk(M, N, K):
         while s > 1 and (K % s or (K // s) % 16 or s * tiles > 512):
             s -= 1
         return max(1, s)
-    s = max(1, min(max(1, 512 // tiles), K // 512, 32))
+    # (a 512 x 512 gradient over 2,048 rows -- 16 tiles -- measured 40 us in 4 slices of 512 rows and
+    # 29 us in 8 of 256: with few tiles the slices may be as short as 16 k-tiles)
+    s = max(1, min(max(1, 512 // tiles), K // (256 if tiles <= 32 else 512), 32))
     # slices that divide K into whole 16-deep tiles keep the launch on the interior kernels
     # (the padded classifier's 640 x 2048 output over K = 16384 asked for 6: 2736-deep slices
     # sent it to the guarded kernel at half the rate)

@@ -51,6 +51,7 @@ class FlatAdam:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_grad[o:o + s].view(p.shape)
+                p._qarig_owner = self      # caches of derived data (ops.bmu_image) follow step_count
 
     # -- data-parallel overlap ----------------------------------------------------------
     def enable_allreduce_overlap(self, force=False):
@@ -178,7 +179,10 @@ class FlatAdam:
         from here on."""
         self.step_count += 1
         step_size, bc2_sqrt = self._step_scalars(self.step_count)
-        self._dev_step_buffer().copy_(torch.tensor([step_size, bc2_sqrt], dtype=torch.float32))
+        if not hasattr(self, "_dev_step_feed"):
+            from .pipeline import PinnedFeed
+            self._dev_step_feed = PinnedFeed(self._dev_step_buffer())
+        self._dev_step_feed.push(torch.tensor([step_size, bc2_sqrt], dtype=torch.float32))
         ops.lp_invalidate()
 
     def state_dict(self):

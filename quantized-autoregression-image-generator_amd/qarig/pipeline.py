@@ -44,7 +44,10 @@ def tokenize_window(feature_map, lr_codebook, hr_codebook, train_base_model, win
     from . import ops
     lr_idx = lr_codebook.get_patches_bmu(feature_map, reshape=True)
     hr_idx = hr_codebook.get_patches_bmu(feature_map, reshape=True)
-    offs = None if rand_indices is None else rand_indices.to(feature_map.device)
+    offs = rand_indices
+    if offs is not None and not offs.is_cuda:
+        # pinned + non-blocking: a copy from pageable memory would make the host wait for the device
+        offs = offs.pin_memory().to(feature_map.device, non_blocking=True)
     hr_in, hr_tg, pos = ops.assemble_tokens(lr_idx, hr_idx, train_base_model, lr_codebook.num_embeddings,
                                             hr_codebook.num_embeddings, offs, window)
     return hr_in, (None if train_base_model else lr_idx), hr_tg, pos
@@ -68,6 +71,31 @@ def train_step(model, optim, hr_input, lr_input, hr_target, pos_idx, dp=True, po
         parallel.allreduce_flat(optim.flat_grad)
     optim.step(grad_scale=1.0 / w)
     return loss
+
+
+class PinnedFeed:
+    """Small per-step host values (window offsets, Adam's step scalars) on their way into the static
+    device buffers of a replayed graph: through a ring of PINNED host slots and non-blocking copies,
+    so that the host never waits for the device (a copy from pageable memory is synchronous: with it
+    the host could not run ahead of a replayed step at all).  A slot is reused only after the copy
+    that last read it has completed (one event per slot)."""
+
+    def __init__(self, dev_tensor, slots=8):
+        self.dev = dev_tensor
+        self.slots = [torch.empty(dev_tensor.shape, dtype=dev_tensor.dtype, pin_memory=True) for _ in range(slots)]
+        self.events = [None] * slots
+        self.i = 0
+
+    def push(self, host_values):
+        i = self.i
+        self.i = (i + 1) % len(self.slots)
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        self.slots[i].copy_(host_values)
+        self.dev.copy_(self.slots[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[i] = ev
 
 
 class _SegmentedCapture:
@@ -173,6 +201,7 @@ class GraphedTrainStep:
         self.warmup = warmup
         self.calls = 0
         self.graph = None
+        self._rand_feed = None
 
     def _body(self, z, rand, captured):
         hr_in, lr_in, hr_tg, pos = tokenize_window(z, self.lr_cb, self.hr_cb, self.base, self.window,
@@ -224,7 +253,12 @@ class GraphedTrainStep:
                 raise ValueError(f"GraphedTrainStep was captured for batches of shape {tuple(self._z.shape)}, "
                                  f"got {tuple(z.shape)}")
             self._z.copy_(z)
-            self._rand.copy_(rand)
+            if rand.is_cuda:
+                self._rand.copy_(rand)
+            else:
+                if self._rand_feed is None:
+                    self._rand_feed = PinnedFeed(self._rand)
+                self._rand_feed.push(rand)
         if self.segmented:
             self.graph.replay()
             self._exchange_and_step()

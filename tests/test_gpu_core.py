@@ -241,6 +241,78 @@ def test_bmu_full_size_properties():
     assert torch.equal(ops.bmu(img, w, (2, 2)).cpu(), torch.arange(256))
 
 
+@pytest.mark.parametrize("case", ["trained_p1", "trained_p2", "ties"])
+def test_bmu_coarse_pass_on_reference_goldens(case):
+    """The coarse-pass form (bf16 MFMA on three-way operand splits + certificate + exact re-scan) on
+    the reference-golden cases it applies to (D <= 16, K a multiple of 32): bit-identical to the C
+    oracle and to the reference's own indices; `ties` (duplicated patches / units) must come out
+    through the exact re-scan with the first-index rule."""
+    from qarig import ops
+    from oracle import bmu as obmu
+    g = load_golden("bmu")[case]
+    p = int(g["p"])
+    got, cnt = ops.bmu_coarse(g["x"].cuda(), g["w"].cuda(), (p, p))
+    want = obmu.bmu(g["x"].numpy(), g["w"].numpy(), (p, p))
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(got.cpu().numpy(), g["idx"].numpy().reshape(-1))
+    if case == "ties":
+        assert int(cnt.item()) > 0
+
+
+@pytest.mark.parametrize("N,C,H,W,p,K,kind", [
+    (64, 4, 64, 64, 2, 512, "trained"),      # the metric's own launch: 65,536 rows x 512 x 16
+    (64, 4, 32, 32, 1, 512, "trained"),      # D = 4
+    (16, 2, 32, 32, 2, 1024, "trained"),     # D = 8, the largest resident codebook
+    (3, 4, 34, 26, 2, 96, "trained"),        # ragged row count (663 rows: a partial last block)
+    (16, 4, 32, 32, 2, 512, "fresh"),        # degenerate fresh-init codebook: (nearly) every row uncertified
+    (8, 4, 32, 32, 2, 256, "dups"),          # duplicated units and patches that ARE units (d = 0, clamp)
+    (8, 4, 32, 32, 2, 256, "tiny"),          # denormal-range data: pieces that do not add up -> memory path
+    (8, 4, 32, 32, 2, 64, "wide"),           # large dynamic range
+])
+def test_bmu_coarse_pass_bit_exact(N, C, H, W, p, K, kind):
+    from qarig import ops
+    from oracle import bmu as obmu
+    g = torch.Generator().manual_seed(N + 3 * p + K + len(kind))
+    D = C * p * p
+    x = torch.tanh(torch.randn((N, C, H, W), generator=g))
+    w = torch.tanh(torch.randn((K, D), generator=g))
+    if kind == "fresh":
+        w = (torch.rand((K, D), generator=g) * 2 - 1) / K
+    elif kind == "dups":
+        w[K // 2] = w[0]
+        w[K - 1] = w[1]
+        w[7] = w[300 % K]
+        img = w[:64].reshape(1, 64, C, p, p)            # patches that are codebook rows
+        x[0, :, :8 * p, :8 * p] = img.reshape(8, 8, C, p, p).permute(2, 0, 3, 1, 4).reshape(C, 8 * p, 8 * p)
+        x[1] = x[0]
+    elif kind == "tiny":
+        x = x * 1e-39
+        w = w * 1e-39
+    elif kind == "wide":
+        x = x * torch.exp(4 * torch.randn((N, 1, H, W), generator=g))
+        w = w * torch.exp(4 * torch.randn((K, 1), generator=g))
+    got, cnt = ops.bmu_coarse(x.cuda(), w.cuda(), (p, p))
+    want = obmu.bmu(x.numpy(), w.numpy(), (p, p))
+    assert np.array_equal(got.cpu().numpy(), want), (kind, int((got.cpu().numpy() != want).sum()))
+    # the same through a prepared codebook image (what ops.bmu does for a frozen codebook), twice: the
+    # second call takes the cached image
+    wc = w.cuda()
+    for _ in range(2):
+        got_p, cnt_p = ops.bmu_coarse(x.cuda(), wc, (p, p), prepared=True)
+        assert np.array_equal(got_p.cpu().numpy(), want), kind
+        assert int(cnt_p.item()) == int(cnt.item())
+    wc.mul_(-1.0)                                   # the codebook changes: the image must follow
+    got_n, _ = ops.bmu_coarse(x.cuda(), wc, (p, p), prepared=True)
+    assert np.array_equal(got_n.cpu().numpy(), obmu.bmu(x.numpy(), (-w).numpy(), (p, p))), kind
+    rows = want.size
+    if kind == "trained":
+        assert int(cnt.item()) <= max(4, rows // 200), (int(cnt.item()), rows)   # the certificate carries the load
+    if kind in ("tiny",):
+        assert int(cnt.item()) == rows
+    # the dispatcher takes the same path by itself on large launches and agrees
+    assert np.array_equal(ops.bmu(x.cuda(), w.cuda(), (p, p)).cpu().numpy(), want)
+
+
 def test_cpu_tensor_is_refused():
     from qarig import ops
     with pytest.raises(RuntimeError):

@@ -91,7 +91,8 @@ def _worker(rank, world, port, overlap, q, backend="gloo", wide=False):
     for _ in range(2):
         loss = pipeline.train_step(m, opt, x, e, t, pos)
     if rank == 0:
-        q.put((opt.flat_param.detach().cpu(), float(loss)))
+        # by value (numpy): a torch tensor travels as a file descriptor that dies with this process
+        q.put((opt.flat_param.detach().cpu().numpy(), float(loss.detach())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -132,6 +133,7 @@ def test_dp2_step_equals_single_process(overlap, wide):
         if p.is_alive():
             p.kill()
     assert got is not None and all(p.exitcode == 0 for p in procs)
+    got = torch.from_numpy(got)
     # two Adam steps: the second one sees weights that already differ by summation-order noise
     assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
 
@@ -169,7 +171,7 @@ def test_rccl_single_rank_overlapped_allreduce_path():
     if p.is_alive():
         p.kill()
     assert got is not None and p.exitcode == 0
-    assert torch.equal(got, want)
+    assert torch.equal(torch.from_numpy(got), want)
 
 
 def _graph_build(base=True):
@@ -251,7 +253,7 @@ def _graph_worker(rank, world, port, q, backend, base):
     segs = len(step.graph.graphs)
     launched = sorted(b for bs in step.graph.bucket_after for b in bs)
     if rank == 0:
-        q.put((opt.flat_param.detach().cpu(), float(loss), segs, nb, launched))
+        q.put((opt.flat_param.detach().cpu().numpy(), float(loss), segs, nb, launched))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -284,6 +286,7 @@ def test_segmented_graph_step_with_bucket_allreduces(world, backend, base):
             p.kill()
     assert got is not None and all(p.exitcode == 0 for p in procs)
     flat, loss, segs, nb, launched = got
+    flat = torch.from_numpy(flat)
     assert nb > 2 and segs > 1 and launched == list(range(nb)), (segs, nb, launched)
     if world == 1:
         assert torch.equal(flat, want.cpu())

@@ -147,3 +147,73 @@ def test_cached_train_mode_sampling_matches():
                                              mode="train", use_kv_cache=cached))
     assert outs[0].shape == (N, total + 1)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_config3_cascade_three_stages_readme_size_cached_equals_full_window(monkeypatch):
+    """BASELINE config 3 as generate_images.py:101-366 runs it: base + 2 encoder-decoder stages at
+    README sizes (512 / 2048 / 64 heads, 7 decoder + 5 encoder layers, K = 512), HR patch 8 -> 4 -> 2
+    (16 / 64 / 256 tokens), 4 images, num_beam = beam_width = 4, window 256, T = 1.0, each stage
+    conditioned on the previous stage's tokens.  The reference's algorithm (full window re-evaluated
+    for every token, real torch.multinomial draws under a seed) is run first and every draw recorded;
+    the KV-cache loop is then fed the same draws and must see the same probability row at EVERY draw
+    (1e-5), keep the same chunks and end with the same tokens; <end> is never emitted."""
+    from models.Transformer import Transformer
+    from qarig import sampling
+    K, N = 512, 4
+    seqs = [16, 64, 256]
+
+    def stage_model(s):
+        base = s == 0
+        torch.manual_seed(100 + s)
+        m = Transformer(use_encoder=not base, use_pos_cond=True, num_enc_layers=None if base else 5,
+                        num_dec_layers=7, num_enc_embedding=None if base else K,
+                        num_dec_embedding=2 * K if base else K + 1, self_attn_heads=64,
+                        cross_attn_heads=None if base else 64, transformer_in_dim=512,
+                        transformer_out_dim=K + 1, transformer_hidden_dim=2048)
+        g = torch.Generator().manual_seed(200 + s)
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.abs().max() == 0:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+        return m.cuda().eval()
+
+    real_multinomial = torch.multinomial
+    record = []
+
+    def recording(probs, num_samples, *a, **k):
+        out = real_multinomial(probs, num_samples, *a, **k)
+        record.append((probs.detach().clone(), out.detach().clone()))
+        return out
+
+    state = {"d": 0, "worst": 0.0}
+
+    def injected(probs, num_samples, *a, **k):
+        want_p, tok = record[state["d"]]
+        err = float((probs - want_p).abs().max())
+        state["worst"] = max(state["worst"], err)
+        assert err < 1e-5, f"draw {state['d']}: cached probabilities differ by {err}"
+        state["d"] += 1
+        return tok
+
+    results = {}
+    for cached in (False, True):
+        monkeypatch.setattr(torch, "multinomial", injected if cached else recording)
+        torch.manual_seed(69)
+        prev = torch.randint(0, K, (N, 1), generator=torch.Generator().manual_seed(7)).cuda()
+        per_stage = []
+        for s in range(3):
+            base = s == 0
+            m = stage_model(s)
+            first = prev if base else torch.full((N, 1), K, dtype=torch.int64, device="cuda")
+            toks = sampling.generate_tokens(m, first, None if base else prev, seqs[s], 1.0, True, 256,
+                                            end_token=K, shift=K if base else 0, num_beam=4, beam_width=4,
+                                            mode="generate", use_kv_cache=cached)
+            assert toks.shape[1] >= seqs[s]
+            prev = (toks[:, 1:] - (K if base else 0))[:, :seqs[s]].contiguous()
+            assert int(prev.min()) >= 0 and int(prev.max()) < K, "<end> or an out-of-vocabulary id was emitted"
+            per_stage.append(prev.clone())
+            del m
+        results[cached] = per_stage
+    assert state["d"] == len(record) == sum(seqs) * 4          # num_beam draws per accepted token
+    for s in range(3):
+        assert torch.equal(results[False][s], results[True][s]), s

@@ -70,3 +70,38 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def phases():
+    """Where a block of the coarse-pass kernel spends its time (clock64() cycles at ~100 MHz / shader clock,
+    summed over blocks by the kernel itself when the counter buffer is given)."""
+    from qarig import ops
+    ops.BMU_COARSE_PHASES = True
+    g = torch.Generator().manual_seed(9)
+    for rows_shape in ((64, 4, 64, 64), (16, 4, 64, 64), (8, 4, 64, 64)):
+        x = torch.tanh(torch.randn(rows_shape, generator=g)).cuda()
+        w = torch.tanh(torch.randn((512, 16), generator=g)).cuda()
+        for prepared in (False, True):
+            ops.bmu_coarse(x, w, (2, 2), prepared=prepared)
+            torch.cuda.synchronize()
+            _, c = ops.bmu_coarse(x, w, (2, 2), prepared=prepared)
+            c = c.cpu().tolist()
+            nb = max(1, c[4])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            gph = torch.cuda.CUDAGraph()
+            img = ops.bmu_image(w) if prepared else None
+            with torch.cuda.graph(gph):
+                for _ in range(20):
+                    ops.bmu_coarse(x, w, (2, 2), prepared=prepared)
+            gph.replay()
+            e0.record()
+            gph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            print(f"coarse {rows_shape[0] * 1024:6d} rows prepared={int(prepared)}: {e0.elapsed_time(e1) * 50:6.2f} us/launch, "
+                  f"re-scanned rows {c[0]}, per block cycles: stage+gather {c[1] / nb:7.0f}  scan {c[2] / nb:7.0f}  "
+                  f"finish {c[3] / nb:7.0f}  (blocks {nb})")
+
+
+if __name__ == "__main__" and os.environ.get("BMU_PHASES") == "1":
+    phases()
