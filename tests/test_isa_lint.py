@@ -57,9 +57,9 @@ def test_r2_mfma_result_needs_its_passes():
     """
     assert any(f.startswith("R2") for f in _run(overwrite)[0])
     as_operand = """
-        v_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]
+        v_mfma_f32_32x32x16_bf16 v[0:15], v[20:23], v[24:27], v[0:15]
         s_nop 7
-        v_mfma_f32_16x16x32_bf16 v[4:7], v[0:3], v[12:15], v[4:7]
+        v_mfma_f32_32x32x16_bf16 v[32:47], v[0:3], v[24:27], v[32:47]
     """
     assert any(f.startswith("R2") for f in _run(as_operand)[0])   # D read as A after 8 of 11 states
     assert not _run(as_operand.replace("s_nop 7", "s_nop 10"))[0]

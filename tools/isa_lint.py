@@ -39,7 +39,8 @@ _MFMA_PASSES = (
     ("v_mfma_f32_32x32x2_f32", 16), ("v_mfma_f32_32x32x2f32", 16), ("v_mfma_f32_32x32x1", 16),
     ("v_mfma_f32_16x16x4_f32", 8), ("v_mfma_f32_16x16x4f32", 8), ("v_mfma_f32_16x16x1", 8),
     ("v_mfma_f32_4x4x1", 2), ("v_mfma_f32_4x4x4", 2),
-    ("v_mfma_f32_16x16x32", 8), ("v_mfma_f32_32x32x16", 16),
+    # gfx950 bf16 / f16: 32x32x16 = 32,768 flop at 1,017 flop / cycle / SIMD (2.5 PF dense) = 32 cycles = 8 passes
+    ("v_mfma_f32_16x16x32", 4), ("v_mfma_f32_32x32x16", 8),
     ("v_mfma_f32_32x32x64", 16), ("v_mfma_scale_f32_32x32x64", 16),
     ("v_mfma_f32_16x16x128", 8), ("v_mfma_scale_f32_16x16x128", 8),
     ("v_mfma_f32_16x16x16", 8), ("v_mfma_f32_32x32x8", 16), ("v_mfma_f32_32x32x4", 16),
