@@ -33,18 +33,29 @@ _REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
 _LABEL = re.compile(r"^<(L\d+)>:")
 _FUNC = re.compile(r"^[0-9a-f]+ <(.+)>:$")
 
-# passes of the MFMAs this library uses (instruction name prefix -> passes); fp32-input MFMAs are
-# not XDL ops (one wait state less)
-_MFMA_PASSES = (
-    ("v_mfma_f32_32x32x2_f32", 16), ("v_mfma_f32_32x32x2f32", 16), ("v_mfma_f32_32x32x1", 16),
-    ("v_mfma_f32_16x16x4_f32", 8), ("v_mfma_f32_16x16x4f32", 8), ("v_mfma_f32_16x16x1", 8),
-    ("v_mfma_f32_4x4x1", 2), ("v_mfma_f32_4x4x4", 2),
-    # gfx950 bf16 / f16: 32x32x16 = 32,768 flop at 1,017 flop / cycle / SIMD (2.5 PF dense) = 32 cycles = 8 passes
-    ("v_mfma_f32_16x16x32", 4), ("v_mfma_f32_32x32x16", 8),
-    ("v_mfma_f32_32x32x64", 16), ("v_mfma_scale_f32_32x32x64", 16),
-    ("v_mfma_f32_16x16x128", 8), ("v_mfma_scale_f32_16x16x128", 8),
-    ("v_mfma_f32_16x16x16", 8), ("v_mfma_f32_32x32x8", 16), ("v_mfma_f32_32x32x4", 16),
-)
+# passes of an MFMA from its shape and input type (gfx950): cycles = flop / (flop per cycle per SIMD
+# of the type's dense peak), a pass = 4 cycles
+_MFMA_NAME = re.compile(r"v_mfma(?:_scale)?_f32_(\d+)x(\d+)x(\d+)(?:_(\d+)b)?_?(\w+)$")
+
+
+def _mfma_passes(mn):
+    m = _MFMA_NAME.match(mn)
+    if not m:
+        raise ValueError(f"isa_lint: unknown MFMA {mn}: teach _mfma_passes its shape")
+    M, N, K, blocks, typ = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4) or 1), m.group(5)
+    flop = 2 * M * N * K * blocks
+    if typ == "f32":
+        rate = 64               # 157.3 TF dense
+    elif typ in ("bf16", "f16"):
+        rate = 1024             # 2.5 PF
+    elif "f8" in typ or "bf8" in typ or typ in ("i8", "f8f6f4"):
+        rate = 2048             # 5 PF
+    else:
+        raise ValueError(f"isa_lint: unknown MFMA input type in {mn}")
+    cycles = max(8, flop // rate)
+    return {8: 2, 16: 4, 32: 8, 64: 16}.get(cycles, 16), typ == "f32"
+
+
 _NEED_F32 = {2: 4, 4: 6, 8: 10, 16: 18}
 _NEED_XDL = {2: 5, 4: 7, 8: 11, 16: 19}
 
@@ -115,14 +126,7 @@ class Ins:
             defs += _regs(self.ops[1])
         self.defs, self.uses = defs, uses
         if self.mfma:
-            passes = 0
-            for pre, p in _MFMA_PASSES:
-                if mn.startswith(pre):
-                    passes = p
-                    break
-            if not passes:
-                raise ValueError(f"isa_lint: unknown MFMA {mn}: add its pass count")
-            f32 = mn.rsplit("_", 1)[-1] in ("f32", "2f32", "4f32", "1f32")     # input type = last name token
+            passes, f32 = _mfma_passes(mn)
             self.need = (_NEED_F32 if f32 else _NEED_XDL)[passes]
             # operands: D, A, B, C [, modifiers]
             self.srcc = tuple(_regs(self.ops[3])) if len(self.ops) > 3 else ()
