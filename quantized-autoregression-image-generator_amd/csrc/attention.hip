@@ -722,10 +722,9 @@ static int attn_check(int N, int Sq, int Sk, int H, int d, int causal) {
 // Launch geometry: a workgroup covers 4 adjacent heads x (W x 64) rows (queries; keys in the
 // dK/dV pass), W waves per head.  W = 4 reads a 256-token sequence's K/V exactly once but leaves
 // one 16-wave workgroup per CU; all three passes default to W = 2.
-// QARIG_ATTN_QW / QARIG_ATTN_BW override (1, 2 or 4; tuning knob, any value is correct).
-static int attn_waves(int rows, int d, const char* env, int dflt, int wmax) {
-    int w = dflt;
-    if (const char* e = getenv(env)) w = atoi(e);
+// Options attn_qw / attn_bw override (1, 2 or 4; tuning knob, any value is correct).
+static int attn_waves(int rows, int d, int option, int dflt, int wmax) {
+    int w = option > 0 ? option : dflt;
     w = w >= 4 ? 4 : (w >= 2 ? 2 : 1);
     if (w > wmax) w = wmax;
     while (w > 1 && (w / 2) * 64 >= rows) w /= 2;      // no more slices than the rows need
@@ -770,7 +769,7 @@ static int attention_fwd_impl(const float* q, const float* k, const float* v, in
     // measured (tools/attn_bench.py, 64 x 256 tokens, 64 heads of 8): W = 1 / 2 / 4 -> 100 / 100 /
     // 124 us; W = 2 reads K and V 1.5x (1.25x of the launch's algorithmic bytes in all) where
     // W = 1 reads them 2.5x, and keeps two workgroups per CU to even out the causal imbalance
-    const int W = attn_waves(Sq, d, "QARIG_ATTN_QW", 2, d <= 16 ? 4 : 2);
+    const int W = attn_waves(Sq, d, g_qarig_opt.attn_qw, 2, d <= 16 ? 4 : 2);
     const int threads = 256 * W, rows = 64 * W;
     const size_t lds = attn_lds_bytes(threads, d, 1, 1, false, LP);
     dim3 grid((unsigned)(N * ((H + HPB - 1) / HPB) * ((Sq + rows - 1) / rows))), block(threads);
@@ -794,7 +793,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
     AttnDims a{N, Sq, Sk, H, causal, 1.4426950408889634f / sqrt_d, 1.0f / sqrt_d};
     const int hgroups = (H + HPB - 1) / HPB;
     {
-        const int W = attn_waves(Sq, d, "QARIG_ATTN_BW", 2, 2);
+        const int W = attn_waves(Sq, d, g_qarig_opt.attn_bw, 2, 2);
         const int threads = 256 * W, rows = 64 * W;
         const size_t lds = attn_lds_bytes(threads, d, 2, 1, false, LP);
         dim3 grid((unsigned)(N * hgroups * ((Sq + rows - 1) / rows))), block(threads);
@@ -806,7 +805,7 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
         QARIG_CHECK_LAUNCH("attention_bwd dq");
     }
     {
-        const int W = attn_waves(Sk, d, "QARIG_ATTN_BW", 2, 2);
+        const int W = attn_waves(Sk, d, g_qarig_opt.attn_bw, 2, 2);
         const int threads = 256 * W, rows = 64 * W;
         const size_t lds = attn_lds_bytes(threads, d, 2, 2, true, LP);
         dim3 grid((unsigned)(N * hgroups * ((Sk + rows - 1) / rows))), block(threads);

@@ -1528,14 +1528,13 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
     const int per = (ctiles + nsplit - 1) / nsplit;
     nsplit = (ctiles + per - 1) / per;
     int64_t* direct = nsplit == 1 ? out_idx : (int64_t*)nullptr;
-    static const bool resident_on = []() { const char* e = getenv("QARIG_BMU_RESIDENT"); return !(e && e[0] == '0'); }();
     // coarse bf16 pass + certificate + exact re-scan where it beats the exact kernels although every
     // workgroup stages the codebook itself (callers with a frozen codebook pass a prepared image to
     // qarig_bmu_fwd_coarse instead: qarig.ops.bmu)
-    static const int coarse_env = []() { const char* e = getenv("QARIG_BMU_COARSE"); return e ? atoi(e) : -1; }();
+    const int coarse_env = g_qarig_opt.bmu_coarse;
     if (bmu_coarse_ok(g, K, codebook) && coarse_env != 0 && (coarse_env == 1 || g.R >= 24576))
         return bmu_coarse_launch(g, codebook, K, out_idx, nullptr, nullptr, st);
-    if (D <= 16 && resident_on) {
+    if (D <= 16) {
         const int ks = D <= 4 ? 2 : (D <= 8 ? 4 : 8);
         const int bpc = (2 * ks + 1) * 4;                         // LDS bytes per code
         const int chunk_max = RES_MAX_LDS / bpc / 256 * 256;
@@ -1543,7 +1542,7 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
         // waves sharing a row tile: as few as still give the chip two workgroups per CU
         int cs = 1;
         while (cs < 4 && (int64_t)((g.R + 128 / cs - 1) / (128 / cs)) * nchunks < 512) cs *= 2;
-        if (const char* e = getenv("QARIG_BMU_CS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) cs = v; }
+        if (const int v = g_qarig_opt.bmu_cs; v == 1 || v == 2 || v == 4) cs = v;
         const int unit = 64 * cs;                                 // two 32-code tiles per wave
         const int chunk = ((K + nchunks - 1) / nchunks + unit - 1) / unit * unit;
         const size_t shm = (size_t)chunk * bpc + (size_t)(3 * 128 + 128 + 128 + 512) * sizeof(float);
@@ -1565,18 +1564,13 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
         dim3 grid((g.R + 128 / cs - 1) / (128 / cs), nchunks), block(NTHREADS);
         // group scan where a wave walks at least 4 tile pairs (its one-off re-evaluation of the winning
         // group costs about what it saves on 2); QARIG_BMU_GROUPS=0/1 overrides
-        static const int groups_env = []() { const char* e = getenv("QARIG_BMU_GROUPS"); return e ? atoi(e) : -1; }();
+        const int groups_env = g_qarig_opt.bmu_groups;
         // (D <= 8 only: with D = 16 the nine MFMAs per tile dominate and the group form measured no gain)
         const bool groups = groups_env >= 0 ? groups_env != 0 : (ks <= 4 && chunk / (32 * cs) >= 8);
-        // four tiles per step (four independent accumulate chains) where the wave's tile count allows
-        static const int quad_env = []() { const char* e = getenv("QARIG_BMU_QUADS"); return e ? atoi(e) : -1; }();
-        const bool quads = groups && (chunk / (32 * cs)) % 4 == 0 && quad_env == 1;   // measured: no gain; opt-in
+        // (a four-tiles-per-step form -- four independent accumulate chains -- measured no gain and was removed)
 #define QARIG_BMU_RES(KS_, CS_)                                                                    \
         do {                                                                                       \
-            if (quads)                                                                             \
-                hipLaunchKernelGGL((bmu_resident_kernel<KS_, CS_, true, 4>), grid, block, shm, st, g, po,     \
-                                   codebook, K, chunk, part_d, part_i, part_s, part_x2, direct_r); \
-            else if (groups)                                                                       \
+            if (groups)                                                                            \
                 hipLaunchKernelGGL((bmu_resident_kernel<KS_, CS_, true, 2>), grid, block, shm, st, g, po,     \
                                    codebook, K, chunk, part_d, part_i, part_s, part_x2, direct_r); \
             else                                                                                   \
@@ -1603,16 +1597,13 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
         return QARIG_OK;
     }
     if (D <= 64) {
-        const int nkt = D <= 16 ? 1 : (D <= 32 ? 2 : 4);
+        const int nkt = D <= 32 ? 2 : 4;
         const size_t shm = (size_t)3 * nkt * TILE_FLOATS * sizeof(float);
         dim3 grid(ptiles, nsplit), block(NTHREADS);
 #define QARIG_BMU_SMALL(NKT_, KS_)                                                              \
         hipLaunchKernelGGL((bmu_small_kernel<NKT_, KS_>), grid, block, shm, st, g, codebook, K, per, \
                            part_d, part_i, part_s, part_x2, direct)
-        if (D <= 4) QARIG_BMU_SMALL(1, 2);
-        else if (D <= 8) QARIG_BMU_SMALL(1, 4);
-        else if (D <= 16) QARIG_BMU_SMALL(1, 8);
-        else if (D <= 32) QARIG_BMU_SMALL(2, 8);
+        if (D <= 32) QARIG_BMU_SMALL(2, 8);      // (D <= 16 never gets here: the resident / coarse kernels take it)
         else {
             static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once
             if (!attr_set) {

@@ -1158,8 +1158,7 @@ static int launch_conv(const float* wmat, const ConvGeom& g, const ConvOut& o, h
 // input below 2 GB (32-bit buffer offsets).  w element (m, c, tap) at w[m * sm + c * sc + tap];
 // flip: the data gradient's tap order.  `packed`: M * 9 * C floats.  QARIG_CONV_RING=0 disables.
 static bool conv3x3_ring_ok(int N, int C, int H, int W, int M, const void* x, const void* packed) {
-    const char* ring_e = getenv("QARIG_CONV_RING");     // read per call: tools/conv_bench.py --ab alternates it
-    const bool on = !(ring_e && ring_e[0] == '0');
+    const bool on = g_qarig_opt.conv_ring != 0;          // option conv_ring = 0: the gather kernels (cross-check)
     const int64_t P = (int64_t)N * H * W, xb = P * C * 4;
     return on && packed && C % 16 == 0 && C >= 16 && M % BM == 0 && P % BN == 0 && W % 4 == 0 && xb < (1LL << 31) &&
            (int64_t)9 * C < (1 << 20) && (((uintptr_t)x | (uintptr_t)packed) & 15) == 0;
@@ -1207,9 +1206,8 @@ static int conv2d_fwd_impl(const float* x, int N, int Cin, int H, int W, const f
         return launch_conv3x3_ring(w, (int64_t)Cin * 9, 9, 0, x, N, Cin, H, W, Cout, o, (float*)workspace,
                                    (hipStream_t)stream);
     {   // stride 2: the same kernel with a strided im2col (four 4-B loads per k row)
-        const char* ring_e = getenv("QARIG_CONV_RING");
         const int64_t P = (int64_t)N * Ho * Wo, xb = (int64_t)N * Cin * H * W * 4;
-        if (!(ring_e && ring_e[0] == '0') && k == 3 && stride == 2 && pad == 1 && H == 2 * Ho && W == 2 * Wo && workspace &&
+        if (g_qarig_opt.conv_ring != 0 && k == 3 && stride == 2 && pad == 1 && H == 2 * Ho && W == 2 * Wo && workspace &&
             ws_bytes >= (size_t)Cout * 9 * Cin * sizeof(float) && Cin % 16 == 0 && Cout % BM == 0 && P % BN == 0 &&
             Wo % 4 == 0 && xb < (1LL << 31) && (((uintptr_t)x | (uintptr_t)workspace) & 15) == 0) {
             hipStream_t st = (hipStream_t)stream;
@@ -1293,7 +1291,7 @@ extern "C" int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H,
     QARIG_CHECK_LAUNCH("conv_transpose2d pack");
     // both column parities per launch (8-B stores) where the MFMA kernel applies and y / preact
     // rows are 8-B aligned; QARIG_CONVT_PAIR=0 restores one class per launch
-    static const bool pair_on = []() { const char* e = getenv("QARIG_CONVT_PAIR"); return !(e && e[0] == '0'); }();
+    const bool pair_on = g_qarig_opt.convt_pair != 0;
     // ... and where one class per launch would leave the chip half empty (< 512 workgroups per class:
     // the 512 -> 256 layer at 16 images ran 61.7 TF that way, 88.4 TF paired; at 32 images one class
     // per launch is the faster form, 94.6 against 90.9 TF for the whole decoder)
@@ -1431,9 +1429,8 @@ static int convt_bwd_data_impl(const float* dT, int N, int Cout, int H, int W, c
     ConvGeom g{dT, N, Cout, 2 * H, 2 * W, H, W, 2, 4, 4, -1, 1, -1, 1, Cout * 16, N * H * W};
     ConvOut o{dx, nullptr, nullptr, Cin, H, W, 1, 0, 0, ACT_NONE};
     {   // Conv2d(4, stride 2, padding 1) over dT on the strided ring: 16 taps at offsets -1 .. 2
-        const char* ring_e = getenv("QARIG_CONV_RING");
         const int64_t P = (int64_t)N * H * W, xb = (int64_t)N * Cout * 4 * H * W * 4;
-        if (!(ring_e && ring_e[0] == '0') && workspace && ws_bytes >= (size_t)16 * Cin * Cout * sizeof(float) &&
+        if (g_qarig_opt.conv_ring != 0 && workspace && ws_bytes >= (size_t)16 * Cin * Cout * sizeof(float) &&
             Cout % 16 == 0 && Cin % BM == 0 && P % BN == 0 && W % 4 == 0 && xb < (1LL << 31) &&
             (((uintptr_t)dT | (uintptr_t)workspace) & 15) == 0) {
             hipStream_t st = (hipStream_t)stream;
@@ -1588,9 +1585,8 @@ extern "C" int qarig_conv_wgrad(const float* G, int N, int Cg, int Gh, int Gw, c
     }
     const int splits = wgrad_splits(Cg, g.K2, g.P);
     {   // 3x3 / stride 1 / padding 1 with whole tiles: the ring kernel (QARIG_CONV_RING=0 disables)
-        const char* ring_e = getenv("QARIG_CONV_RING");
         const int64_t gb = (int64_t)N * Cg * Gh * Gw * 4, xb = (int64_t)N * Cx * H * W * 4;
-        if (!(ring_e && ring_e[0] == '0') && k == 3 && stride == 1 && pad == 1 && Gh == H && Gw == W && W % BK == 0 &&
+        if (g_qarig_opt.conv_ring != 0 && k == 3 && stride == 1 && pad == 1 && Gh == H && Gw == W && W % BK == 0 &&
             Cg % BM == 0 && Cx % BN == 0 && gb < (1LL << 31) && xb < (1LL << 31) && (int64_t)H * W < (1 << 22) &&
             ((((uintptr_t)G | (uintptr_t)X)) & 15) == 0) {
             const int ktiles = g.P / BK;

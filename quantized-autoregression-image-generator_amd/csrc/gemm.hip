@@ -29,35 +29,13 @@ struct RowSumHook {
     }
 };
 
-// Co-resident workgroups of the first dispatch round start together, run their k-loops in
-// lockstep and so reach their epilogues together: the 2 x 64 KB of stores per tile (C and the
-// saved pre-activation) then hit HBM from every CU at once while every matrix pipe idles, and
-// the following rounds inherit the phase (measured: MFMA pipe busy 0.71-0.76 of the kernel's
-// cycles, profiles/r02a_sq_by_kernel.csv).  De-phase them once: a wave in SIMD wave slot s
-// (HW_ID.wave_id, 0..3 with four resident workgroups per CU) sleeps s * `units` * 8128 cycles
-// before its first load, first round only; the epilogue of one workgroup then runs under the
-// MFMAs of the other three for the rest of the launch.  Placement only changes speed.
-__device__ __forceinline__ void stagger_first_round(int units) {
-    if (units < 0) {     // experiment: static issue priority by SIMD wave slot instead of a delay
-        const int slot = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3);
-        if (slot == 1) __builtin_amdgcn_s_setprio(1);
-        else if (slot == 2) __builtin_amdgcn_s_setprio(2);
-        else if (slot == 3) __builtin_amdgcn_s_setprio(3);
-        return;
-    }
-    if (units <= 0 || blockIdx.x >= 1024u) return;
-    const int slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15;   // HW_REG_HW_ID[3:0]
-    for (int i = 0; i < slot * units; ++i) __builtin_amdgcn_s_sleep(127);
-}
-
 // FAST: every tile interior (M,N multiples of 128, every K split a multiple of 16,
 // vector-loadable operands) -- branch-free main loop, unguarded epilogue.
 template <class SA, class SB, bool FAST>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpilogue ep, int M,
                                                            int N, int K, int tiles_n, int splitk,
-                                                           float* slabs, int vec_epi, int stagger) {
+                                                           float* slabs, int vec_epi) {
     __shared__ __attribute__((aligned(16))) float lds[GEMM_LDS_FLOATS];
-    if (FAST) stagger_first_round(stagger);
     const int nwg = gridDim.x;
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
@@ -126,156 +104,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpi
 // order, nothing else.  Fragment reads are inline asm: hipcc otherwise drains every
 // outstanding DMA (vmcnt(0)) in front of any LDS read.
 // ---------------------------------------------------------------------------------
-// Issue this wave's share (2 x 1 KiB) of one operand tile.
-template <bool KC>
-__device__ __forceinline__ void dma_tile(const float* __restrict__ P, int64_t ld, int x0, int k0,
-                                         float* tile, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = wave * 2 + i;
-        const float* src;
-        if (KC) {   // [x][k]: 16 rows x 64 B per instruction, chunk-swizzled
-            const int r = 16 * q + (lane >> 2);
-            const int c = (lane & 3) ^ ((r >> 2) & 3);
-            src = P + (int64_t)(x0 + r) * ld + k0 + 4 * c;
-        } else {    // [k][x]: 2 k-rows x 512 B per instruction
-            const int k = 2 * q + (lane >> 5);
-            src = P + (int64_t)(k0 + k) * ld + x0 + (lane & 31) * 4;
-        }
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + q * 256), 16, 0, 0);
-    }
-}
-
-// The 8 k-values (k = 8h .. 8h+7) of tile row/column `x` for this lane, as two f32x4.
-template <bool KC>
-__device__ __forceinline__ void frag_read(const float* tile, int x, int h, f32x4& lo, f32x4& hi) {
-    if (KC) {
-        const int sw = (x >> 2) & 3;
-        const unsigned base = lds_addr(tile + x * 16);
-        const unsigned a0 = base + (((2 * h) ^ sw) << 4), a1 = base + (((2 * h + 1) ^ sw) << 4);
-        asm volatile("ds_read_b128 %0, %1" : "=v"(lo) : "v"(a0));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(hi) : "v"(a1));
-    } else {
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const unsigned base = lds_addr(tile + (8 * h) * 128 + x);   // rows are 512 B = 2 x 64 dwords
-        f32x2 p0, p1, p2, p3;
-        asm volatile("ds_read2st64_b32 %0, %1 offset0:0 offset1:2" : "=v"(p0) : "v"(base));
-        asm volatile("ds_read2st64_b32 %0, %1 offset0:4 offset1:6" : "=v"(p1) : "v"(base));
-        asm volatile("ds_read2st64_b32 %0, %1 offset0:8 offset1:10" : "=v"(p2) : "v"(base));
-        asm volatile("ds_read2st64_b32 %0, %1 offset0:12 offset1:14" : "=v"(p3) : "v"(base));
-        lo = f32x4{p0.x, p0.y, p1.x, p1.y};
-        hi = f32x4{p2.x, p2.y, p3.x, p3.y};
-    }
-}
-
-// STAGES = 2: tile t+1 is requested while tile t is multiplied (one k-tile of latency cover);
-// STAGES = 3: two tiles in flight, the wait before the barrier is a counted vmcnt(4) that leaves
-// the younger one outstanding (48 KB of LDS: three workgroups per CU).
-template <bool AKC, bool BKC, int STAGES>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_kernel(const float* __restrict__ A,
-                                                               int64_t lda,
-                                                               const float* __restrict__ B,
-                                                               int64_t ldb, GemmEpilogue ep, int M,
-                                                               int N, int K, int tiles_n, int splitk,
-                                                               float* slabs, int stagger) {
-    __shared__ __attribute__((aligned(16))) float lds[STAGES * DMA_STAGE_FLOATS];   // 32 / 48 KB
-    stagger_first_round(stagger);
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    int k_begin = 0, k_end = K;
-    if (splitk > 1) {
-        const int per = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
-        k_begin = blockIdx.z * per;
-        k_end = min(K, k_begin + per);
-    }
-    const int nk = (k_end - k_begin) / BK;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int x = lane & 31, h = lane >> 5;
-    const int last = k_begin + (nk - 1) * BK;
-
-    Acc acc;
-    acc_zero(acc);
-    // bias gradient riding on the dW GEMM: sum_k A(m0 + tid, k), k ascending (A = dT^T, [k][x])
-    float rs = 0.0f;
-    const bool do_rs = !AKC && ep.rowsum != nullptr && tn == 0 && tid < 128;
-    if (nk > 0) {
-#pragma unroll
-        for (int p = 0; p < STAGES - 1; ++p) {          // tiles 0 .. STAGES-2 (tail: harmless re-load)
-            const int kp = min(k_begin + p * BK, last);
-            dma_tile<AKC>(A, lda, m0, kp, lds + p * DMA_STAGE_FLOATS, wave, lane);
-            dma_tile<BKC>(B, ldb, n0, kp, lds + p * DMA_STAGE_FLOATS + DMA_OP_FLOATS, wave, lane);
-        }
-        int st = 0;                       // stage of tile kt
-        for (int kt = 0; kt < nk; ++kt) {
-            // this wave's DMAs of tile kt have landed (the STAGES-2 younger tiles stay in flight),
-            // then (barrier) everybody's; the same barrier retires all reads of tile kt-1, whose
-            // stage is refilled right after it
-            if (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const int kn = min(k_begin + (kt + STAGES - 1) * BK, last);        // tail: harmless re-load
-            const int sn = st == 0 ? STAGES - 1 : st - 1;                      // stage of tile kt-1
-            dma_tile<AKC>(A, lda, m0, kn, lds + sn * DMA_STAGE_FLOATS, wave, lane);
-            dma_tile<BKC>(B, ldb, n0, kn, lds + sn * DMA_STAGE_FLOATS + DMA_OP_FLOATS, wave, lane);
-            const float* ta = lds + st * DMA_STAGE_FLOATS;
-            const float* tb = ta + DMA_OP_FLOATS;
-            f32x4 a0l, a0h, a1l, a1h, b0l, b0h, b1l, b1h;
-            frag_read<AKC>(ta, wm * 64 + x, h, a0l, a0h);
-            frag_read<BKC>(tb, wn * 64 + x, h, b0l, b0h);
-            frag_read<AKC>(ta, wm * 64 + 32 + x, h, a1l, a1h);
-            frag_read<BKC>(tb, wn * 64 + 32 + x, h, b1l, b1h);
-            f32x4 r0, r1, r2, r3;
-            if (do_rs) {
-                frag_read<false>(ta, tid, 0, r0, r1);
-                frag_read<false>(ta, tid, 1, r2, r3);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (do_rs) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rs += r0[q];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rs += r1[q];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rs += r2[q];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rs += r3[q];
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const float a0 = s < 4 ? a0l[s & 3] : a0h[s & 3];
-                const float a1 = s < 4 ? a1l[s & 3] : a1h[s & 3];
-                const float b0 = s < 4 ? b0l[s & 3] : b0h[s & 3];
-                const float b1 = s < 4 ? b1l[s & 3] : b1h[s & 3];
-                acc.t[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc.t[0][0], 0, 0, 0);
-                acc.t[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc.t[0][1], 0, 0, 0);
-                acc.t[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc.t[1][0], 0, 0, 0);
-                acc.t[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc.t[1][1], 0, 0, 0);
-            }
-            st = st + 1 == STAGES ? 0 : st + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    if (do_rs) ep.rowsum[(int64_t)blockIdx.z * M + m0 + tid] = rs;
-    __syncthreads();                      // ring no longer in use: the epilogue stages through it
-    gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, slabs);
-}
-
-// The same ring (3 stages) with the fragments of tile t+1 read from LDS into a second register
+// The ring (4 stages) with the fragments of tile t+1 read from LDS into a second register
 // set WHILE tile t's 32 MFMAs issue: the LDS round trip (8 x ds_read_b128 + latency behind the
 // other waves' LDS traffic) leaves the k-loop's critical path; what remains between two MFMA
 // slabs is the barrier and the issue of 4 DMAs and 8 reads.  (Counters on the 2-stage kernel:
 // waves spend 19 % of their cycles in s_waitcnt / s_barrier and the matrix pipe idles 24 %.)
-template <bool AKC, bool BKC>
-__device__ __forceinline__ void frags_read(Frags8& f, const float* ta, const float* tb, int wm, int wn,
-                                           int x, int h) {
-    frag_read<AKC>(ta, wm * 64 + x, h, f.a0l, f.a0h);
-    frag_read<BKC>(tb, wn * 64 + x, h, f.b0l, f.b0h);
-    frag_read<AKC>(ta, wm * 64 + 32 + x, h, f.a1l, f.a1h);
-    frag_read<BKC>(tb, wn * 64 + 32 + x, h, f.b1l, f.b1h);
-}
 // The k-loop of the prefetch kernels: tiles [0, nk) of BK from k_begin, of the 128 x 128 block at
 // (m0, n0), through the 4-stage ring at `lds` (64 KB); `tt` = thread index among the ring's 256.
 // Contains workgroup barriers: every wave of the workgroup runs it with the same nk.
@@ -849,34 +682,13 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     auto ok4 = [&](const void* p, int64_t ld) { return !p || (al16(p) && ld % 4 == 0); };
     const int vec_epi = ok4(C, ldc) && ok4(bias, 4) && ok4(residual, ldr) && ok4(preact, ldp) &&
                         ok4(gradz, ldz) && ok4(slabs, 4);
-    // LDS-DMA kernel: interior shapes, 16-B epilogue, no row-sum hook; QARIG_GEMM_DMA=0 disables
-    static const bool dma_on = []() { const char* e = getenv("QARIG_GEMM_DMA"); return !(e && e[0] == '0'); }();
-    // every interior shape: since the ring's k-loop carries no vector-ALU address arithmetic it beats
-    // the register-staged kernel on the short-K wide outputs too (dH 512 -> 2048: 131.9 vs 121.8 TF)
-    const bool dma_shape = true;
-    // stagger (units of 8128-cycle sleeps per wave slot) only where the grid spans more than
-    // one dispatch round of ~4 workgroups per CU; QARIG_GEMM_STAGGER overrides (0 = off)
-    const char* stagger_e = getenv("QARIG_GEMM_STAGGER");
-    const int stagger_env = stagger_e ? atoi(stagger_e) : 0;
-    // measured: the delay is worth nothing (+-1 %: profiles/README.md), so it is off by default;
-    // QARIG_GEMM_STAGGER = -1 selects the static-priority experiment
-    const int stagger = stagger_env == -2 ? -1 : ((long)grid.x * grid.z >= 1024 && stagger_env > 0 ? stagger_env : 0);
-    // ring depth: 3 stages where the grid leaves at most three workgroups per CU anyway (the
-    // split-K weight gradients and the N = 512 outputs: 512 workgroups); QARIG_GEMM_STAGES overrides
-    const char* stages_e = getenv("QARIG_GEMM_STAGES");
-    const int stages = stages_e ? atoi(stages_e) : ((long)grid.x * grid.z <= 768 ? 3 : 2);
-#define QARIG_LAUNCH_DMA(AK, BK_, ...)                                                        \
-    do {                                                                                      \
-        if (stages == 3) hipLaunchKernelGGL((gemm_dma_kernel<AK, BK_, 3>), __VA_ARGS__);      \
-        else hipLaunchKernelGGL((gemm_dma_kernel<AK, BK_, 2>), __VA_ARGS__);                  \
-    } while (0)
-    // fragment-prefetch form of the ring (4 stages, addresses off the vector ALU: gemm_dma_pf_kernel);
-    // QARIG_GEMM_PF=0 restores the plain 2/3-stage ring
-    const char* pf_e = getenv("QARIG_GEMM_PF");
-    const bool pf = pf_e ? pf_e[0] == '1' || (pf_e[0] != '0' && dma_shape) : (dma_on && dma_shape);
+    const bool dma_on = g_qarig_opt.gemm_dma != 0;
+    // every interior shape runs the fragment-prefetch ring (gemm_dma_pf_kernel: 4 stages, addresses off
+    // the vector ALU); qarig_set_option("gemm_dma", 0) sends them to the register-staged kernel instead
+    const bool pf = dma_on;
     // paired form (two 4-wave teams per tile, 128 KB of LDS): launches that would leave one
-    // workgroup per CU; QARIG_GEMM_PAIR=0 disables, =1 forces it wherever it is eligible
-    static const int pair_env = []() { const char* e = getenv("QARIG_GEMM_PAIR"); return e ? atoi(e) : -1; }();
+    // workgroup per CU; option gemm_pair = 0 disables it, 1 forces it wherever it is eligible
+    const int pair_env = g_qarig_opt.gemm_pair;
     const int nk_block = per / BK;
     const bool pair_ok = dma_on && fast && vec_epi && !(a_rowsum && a_kcontig) && !(!a_kcontig && b_kcontig) &&
                          nk_block % 2 == 0 && nk_block >= 4;
@@ -912,17 +724,6 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
         else
             hipLaunchKernelGGL((gemm_dma_pf_kernel<false, false>), grid, block, 0, st, A, lda, B, ldb, ep,
                                M, N, K, tiles_n, splitk, slabs);
-    } else if (dma_on && dma_shape && fast && vec_epi && !(a_rowsum && a_kcontig) &&
-        !(!a_kcontig && b_kcontig)) {
-        if (a_kcontig && b_kcontig)
-            QARIG_LAUNCH_DMA(true, true, grid, block, 0, st, A, lda, B, ldb, ep, M,
-                               N, K, tiles_n, splitk, slabs, stagger);
-        else if (a_kcontig)
-            QARIG_LAUNCH_DMA(true, false, grid, block, 0, st, A, lda, B, ldb, ep, M,
-                               N, K, tiles_n, splitk, slabs, stagger);
-        else
-            QARIG_LAUNCH_DMA(false, false, grid, block, 0, st, A, lda, B, ldb, ep,
-                               M, N, K, tiles_n, splitk, slabs, stagger);
     } else {
 #define QARIG_LAUNCH_GEMM(TA, TB)                                                              \
     do {                                                                                       \
@@ -930,10 +731,10 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
         TB sb{B, ldb, N, K, 1.0f, vb};                                                         \
         if (fast)                                                                              \
             hipLaunchKernelGGL((gemm_kernel<TA, TB, true>), grid, block, 0, st, sa, sb, ep, M, \
-                               N, K, tiles_n, splitk, slabs, vec_epi, stagger);                \
+                               N, K, tiles_n, splitk, slabs, vec_epi);                         \
         else                                                                                   \
             hipLaunchKernelGGL((gemm_kernel<TA, TB, false>), grid, block, 0, st, sa, sb, ep, M,\
-                               N, K, tiles_n, splitk, slabs, 0, 0);                            \
+                               N, K, tiles_n, splitk, slabs, 0);                               \
     } while (0)
     if (a_kcontig && b_kcontig) QARIG_LAUNCH_GEMM(SrcKContig, SrcKContig);
     else if (a_kcontig && !b_kcontig) QARIG_LAUNCH_GEMM(SrcKContig, SrcXContig);

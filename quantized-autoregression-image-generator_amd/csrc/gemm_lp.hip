@@ -880,8 +880,8 @@ extern "C" int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t 
                     (unsigned short*)Cb, ldcb, (unsigned short*)Pb, ldpb,
                     gradz_is_bf16 ? (const unsigned short*)gradz : nullptr, ldz};
     hipStream_t st = (hipStream_t)stream;
-    // 256 x 256 tiles where they still give every CU a workgroup; QARIG_LP_BIG=0/1 overrides
-    static const int big_env = []() { const char* e = getenv("QARIG_LP_BIG"); return e ? atoi(e) : -1; }();
+    // 256 x 256 tiles where they still give every CU a workgroup; option lp_big = 0 / 1 overrides
+    const int big_env = g_qarig_opt.lp_big;
     const long big_tiles = (long)(M / LPB) * (N / LPB) * splitk;
     if (M % LPB == 0 && N % LPB == 0 && big_env != 0 && (big_env == 1 || big_tiles >= 224)) {
         constexpr int BIG_LDS = 2 * LPB_STAGE * (int)sizeof(bf16_t);
@@ -897,7 +897,7 @@ extern "C" int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t 
         }
         dim3 gridb((M / LPB) * (N / LPB), 1, splitk), blockb(1024);
         const int tnb = N / LPB;
-        static const int m16_env = []() { const char* e = getenv("QARIG_LP_MFMA16"); return e ? atoi(e) : 1; }();
+        const int m16_env = g_qarig_opt.lp_mfma16;
         if (m16_env) {
             static bool attr16 = false;
             if (!attr16) {
@@ -937,7 +937,7 @@ extern "C" int qarig_gemm_lp(const void* A, int64_t lda, const void* B, int64_t 
             return qarig_slab_reduce_f32((const float*)workspace, C, ldc, M, N, splitk, accumulate, stream);
         return QARIG_OK;
     }
-    static const int m16_small = []() { const char* e = getenv("QARIG_LP_MFMA16"); return e ? atoi(e) : 1; }();
+    const int m16_small = g_qarig_opt.lp_mfma16;
     if (m16_small) {
         if (layout == 0)
             hipLaunchKernelGGL((gemm_lp16_kernel<false, false>), grid, block, 0, st, (const bf16_t*)A, lda,
@@ -1017,7 +1017,7 @@ extern "C" int qarig_gemm_f8(const void* A, int64_t lda, const void* B, int64_t 
     const int tiles_m = M / BM, tiles_n = N / BN;
     GemmEpilogue ep{C, ldc, bias, residual, ldr, preact, ldp, act, nullptr, 0, 0, nullptr,
                     (unsigned short*)Cb, ldcb, (unsigned short*)Pb, ldpb, nullptr, 0, inv_a, inv_b};
-    static const int big_env = []() { const char* e = getenv("QARIG_LP_BIG"); return e ? atoi(e) : -1; }();
+    const int big_env = g_qarig_opt.lp_big;
     if (M % LPB == 0 && N % LPB == 0 && big_env != 0 && (big_env == 1 || (long)(M / LPB) * (N / LPB) >= 224)) {
         constexpr int BIG_LDS = 2 * LPB_STAGE * (int)sizeof(bf16_t);
         static bool attr_set = false;

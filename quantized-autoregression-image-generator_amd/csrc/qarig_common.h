@@ -17,6 +17,23 @@
 
 extern "C" void qarig_set_error(const char* fmt, ...);
 
+// Kernel-selection options (qarig_set_option): every one only chooses between kernels that must give
+// the same results; -1 / 0 = the library's own choice where stated.  Defined in capi.hip.
+struct QarigOptions {
+    int gemm_dma = 1;      // 0: interior GEMM shapes on the register-staged kernel instead of the LDS-DMA ring
+    int gemm_pair = -1;    // paired (two-team) GEMM kernel: -1 auto (<= 256 workgroups), 0 never, 1 wherever eligible
+    int bmu_cs = 0;        // resident BMU kernel, waves sharing a row tile: 0 auto, else 1 / 2 / 4
+    int bmu_groups = -1;   // resident BMU kernel, group-minimum scan: -1 auto, 0 / 1
+    int bmu_coarse = -1;   // coarse-pass BMU kernel: -1 auto (>= 24,576 rows), 0 never, 1 wherever it applies
+    int attn_qw = 0;       // attention forward, waves per head: 0 auto, else 1 / 2 / 4
+    int attn_bw = 0;       // attention backward, waves per head: 0 auto, else 1 / 2 / 4
+    int lp_big = -1;       // reduced precision, 256 x 256 tiles: -1 auto (>= 224 tiles), 0 / 1
+    int lp_mfma16 = 1;     // reduced precision, v_mfma_f32_16x16x32_bf16 (1) or 32x32x16 (0)
+    int convt_pair = 1;    // ConvTranspose parity classes paired per workgroup where a class is < 512 workgroups
+    int conv_ring = 1;     // 0: every convolution on the gather (im2col-in-registers) kernels, none on the LDS-DMA ring
+};
+extern QarigOptions g_qarig_opt;
+
 #define QARIG_CHECK_ARG(cond, ...)                 \
     do {                                           \
         if (!(cond)) {                             \

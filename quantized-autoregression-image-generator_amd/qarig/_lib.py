@@ -25,6 +25,7 @@ SIGNATURES = {
     "qarig_version": (I, []),
     "qarig_target_arch": (c_char_p, []),
     "qarig_last_error": (I, [c_char_p, Z]),
+    "qarig_set_option": (I, [c_char_p, I]),
     "qarig_bmu_workspace_bytes": (Z, [L, I]),
     "qarig_bmu_fwd": (I, [P, I, I, I, I, I, I, P, I, I, P, P, Z, P]),
     "qarig_bmu_fwd_coarse": (I, [P, I, I, I, I, I, I, P, I, I, P, P, P, P]),
@@ -115,7 +116,23 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    for name in OPTIONS:      # QARIG_<OPTION>=<int> in the environment seeds an option (tools, A/B runs)
+        v = os.environ.get("QARIG_" + name.upper())
+        if v is not None:
+            lib.qarig_set_option(name.encode(), int(v))
     return lib
+
+
+OPTIONS = ("gemm_dma", "gemm_pair", "bmu_cs", "bmu_groups", "bmu_coarse", "attn_qw", "attn_bw", "lp_big",
+           "lp_mfma16", "convt_pair", "conv_ring")
+
+
+def set_option(name, value):
+    """Kernel-selection option (include/qarig.h qarig_set_option); returns the previous value."""
+    old = load().qarig_set_option(name.encode(), int(value))
+    if old == -2 ** 31:
+        raise KeyError(f"{name}: {last_error()}")
+    return old
 
 
 def last_error():

@@ -1,0 +1,126 @@
+"""Every kernel-selection option (qarig_set_option) against the parity tests of the kernels it
+chooses between: an option only picks among kernels that must give the same results, so the same
+assertions must hold under each value.  (Round 2 ran this as tools/switch_matrix.sh outside pytest;
+the options are settable in-process now, so the driver's `pytest -m gpu` covers every surviving path.)
+Superseded forms were deleted instead of switched: the 2/3-stage GEMM ring, the first-round stagger,
+the resident-off BMU path for D <= 16, the four-chain BMU scan."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def option():
+    from qarig import _lib
+    saved = []
+
+    def set_(name, value):
+        saved.append((name, _lib.set_option(name, value)))
+
+    yield set_
+    for name, old in reversed(saved):
+        _lib.set_option(name, old)
+
+
+def test_unknown_option_is_refused():
+    from qarig import _lib
+    with pytest.raises(KeyError, match="unknown option"):
+        _lib.set_option("no_such_switch", 1)
+    assert _lib.set_option("gemm_dma", 1) == 1      # default, and the call returns the previous value
+
+
+@pytest.mark.parametrize("name,value", [("gemm_dma", 0), ("gemm_pair", 0), ("gemm_pair", 1)])
+def test_gemm_options(option, name, value):
+    import test_gpu_core as core
+    import test_gpu_grouped as grouped
+    option(name, value)
+    for ak, bk in ((True, True), (True, False), (False, False)):
+        core.test_gemm_layouts(2048, 512, 2048, ak, bk)
+        core.test_gemm_interior_dma_path(ak, bk)
+    core.test_gemm_epilogues()
+    core.test_gemm_splitk_and_colsum()
+    core.test_gemm_paired_teams(2048, 2048, 512, True, True, 1)
+    core.test_gemm_paired_teams(2048, 512, 2048, False, False, 4)
+    grouped.test_grouped_mlp_node_matches_separate_mlps_and_fp64(3, 256, 128, 256, 0, True)
+
+
+@pytest.mark.parametrize("name,value", [("bmu_cs", 1), ("bmu_cs", 2), ("bmu_cs", 4), ("bmu_groups", 0),
+                                        ("bmu_groups", 1), ("bmu_coarse", 0), ("bmu_coarse", 1)])
+def test_bmu_options(option, name, value):
+    import test_gpu_core as core
+    option(name, value)
+    for case in ("trained_p1", "trained_p2", "ragged", "fresh_p4", "ties"):
+        core.test_bmu_vs_oracle_and_golden(case)
+    core.test_bmu_seeded_vs_oracle(64, 4, 32, 32, 2, 512)
+    core.test_bmu_seeded_vs_oracle(16, 4, 64, 64, 1, 8192)
+    core.test_bmu_random_shapes_bit_exact()
+
+
+@pytest.mark.parametrize("name,value", [("attn_qw", 1), ("attn_qw", 4), ("attn_bw", 1)])
+def test_attention_options(option, name, value):
+    from conftest import rel_err
+    from qarig import ops
+    option(name, value)
+    g = torch.Generator().manual_seed(3)
+    for (N, Sq, Sk, H, d, causal) in ((2, 256, 256, 64, 8, True), (1, 130, 77, 6, 16, False), (2, 64, 64, 4, 64, True)):
+        q, k, v, do = (torch.randn(s, generator=g) for s in ((N, Sq, H * d), (N, Sk, H * d), (N, Sk, H * d),
+                                                              (N, Sq, H * d)))
+        qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+        s_ = torch.einsum("nqhd,nkhd->nhqk", qd.view(N, Sq, H, d), kd.view(N, Sk, H, d)) / d ** 0.5
+        if causal:
+            s_ = s_.masked_fill(torch.ones(Sq, Sk).triu(1).bool(), float("-inf"))
+        od = torch.einsum("nhqk,nkhd->nqhd", torch.softmax(s_, -1), vd.view(N, Sk, H, d)).reshape(N, Sq, H * d)
+        od.backward(do.double())
+        o, lse = ops.attention_fwd(q.cuda(), k.cuda(), v.cuda(), H, causal)
+        dq, dk, dv = ops.attention_bwd(q.cuda(), k.cuda(), v.cuda(), o, do.cuda(), lse, H, causal)
+        assert rel_err(o, od) < 2e-6
+        for got, want in ((dq, qd.grad), (dk, kd.grad), (dv, vd.grad)):
+            assert rel_err(got, want) < 5e-6
+
+
+@pytest.mark.parametrize("name,value", [("lp_big", 0), ("lp_big", 1), ("lp_mfma16", 0)])
+def test_reduced_precision_options(option, name, value):
+    import test_gpu_bf16 as bf
+    from qarig import ops
+    option(name, value)
+    for layout in (0, 1, 2):
+        bf.test_lp_fragment_maps_on_exact_integer_data(layout, 4096, 4096, 192)
+        bf.test_lp_fragment_maps_on_exact_integer_data(layout, 256, 384, 192)
+    old, ops.PRECISION = ops.PRECISION, "bf16"
+    try:
+        for ak, bk in ((True, True), (True, False), (False, False)):
+            bf.test_bf16_gemm_is_exact_on_rounded_operands(ops, 256, 384, 512, 1, ak, bk)
+        bf.test_bf16_gemm_epilogues_and_accumulate(ops)
+    finally:
+        ops.PRECISION = old
+    bf.test_lp_big_tile_kernel_epilogues()
+
+
+@pytest.mark.parametrize("name,value", [("convt_pair", 0), ("conv_ring", 0)])
+def test_conv_options(option, name, value):
+    """conv_ring = 0 sends every convolution to the gather kernels: the ring kernels' parity tests then
+    pin the gather kernels on the same shapes (the cross-check of round 2's switch matrix)."""
+    import inspect
+
+    import test_gpu_conv as conv
+    option(name, value)
+    ran = 0
+    for fname, fn in sorted(vars(conv).items()):
+        if not fname.startswith("test_") or not callable(fn):
+            continue
+        marks = [m for m in getattr(fn, "pytestmark", []) if m.name == "parametrize"]
+        if marks or inspect.signature(fn).parameters:
+            continue                      # parametrised / fixture-taking tests keep to their own runs
+        fn()
+        ran += 1
+    assert ran >= 5, ran
+    # the ring kernels' own shapes, now on the other kernel family
+    conv.test_conv3x3_ring_kernel_fwd_bwd_vs_fp64(2, 32, 8, 8, 128, 1)
+    conv.test_conv3x3_ring_kernel_fwd_bwd_vs_fp64(1, 48, 16, 24, 256, 2)
+    conv.test_conv_transpose2d_ring_kernel_vs_fp64(2, 32, 8, 8, 128)
+    conv.test_conv2d_stride2_input_gradient_ring_vs_fp64(2, 128, 16, 16, 32)
+    conv.test_conv2d_stride2_forward_ring_vs_fp64(2, 32, 16, 16, 128, 1)
+    conv.test_conv_transpose2d_input_gradient_ring_vs_fp64(8, 128, 4, 4, 16)
+    conv.test_conv2d_readme_channels_fwd_bwd_vs_fp64(256, 512, 2)
+    conv.test_conv_transpose2d_readme_channels_fwd_bwd_vs_fp64(512, 256)

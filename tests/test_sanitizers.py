@@ -28,8 +28,8 @@ def table(p):
 for name, (res, args) in sorted(_lib.SIGNATURES.items()):
     fn = getattr(lib, name)
     fn.restype, fn.argtypes = res, args
-    if name in ("qarig_last_error", "qarig_target_arch", "qarig_version"):
-        continue
+    if name in ("qarig_last_error", "qarig_target_arch", "qarig_version", "qarig_set_option"):
+        continue      # (qarig_set_option returns a previous VALUE, not a status: exercised by hand below)
     ints = [i for i, a in enumerate(args) if a in (I, L, Z)]
     def build(ptr, ival, fval):
         out = []
@@ -105,6 +105,12 @@ for (N, Cin, H, W, Cout) in ((16, 256, 128, 128, 256), (16, 512, 32, 32, 512), (
 call("qarig_conv_transpose2d_fwd", X, 16, 256, 64, 64, X, X, 256, 1, X, X, X, 1 << 40, None)
 call("qarig_som_band", X, 8192, 4, 1779.0, 222, X2, None)
 call("qarig_som_band", X, 512, 16, 0.43, 4, X2, None)
+so = lib.qarig_set_option
+so.restype, so.argtypes = I, [ctypes.c_char_p, I]
+assert so(None, 1) == -2**31 and so(b"no_such_option", 1) == -2**31 and so(b"", 0) == -2**31
+assert so(b"gemm_pair", 1) == -1 and so(b"gemm_pair", -1) == 1
+assert so(b"x" * 4000, 7) == -2**31           # a long unknown name must not overrun the error string
+calls += 6
 buf = ctypes.create_string_buffer(8)          # a too-short buffer must be respected
 lib.qarig_last_error.argtypes = [ctypes.c_char_p, Z]
 lib.qarig_last_error(buf, 8)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BMU launch time without host overhead (run on the GPU box: `python tools/bmu_bench.py`).
 Each shape is timed twice: N eager calls between two events (what a Python caller sees) and the
-same N launches replayed from one HIP graph (GPU time per launch).  QARIG_BMU_RESIDENT=0 selects
+same N launches replayed from one HIP graph (GPU time per launch).  QARIG_BMU_COARSE=0 (option bmu_coarse) selects
 the streamed-codebook kernels for an A/B."""
 import os
 import sys

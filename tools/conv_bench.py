@@ -9,6 +9,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "quantized-autoregression-image-generator_amd"))
 import torch  # noqa: E402
+from qarig import _lib  # noqa: E402
 from models.FC_Decoder import FC_Decoder  # noqa: E402
 from models.FC_Encoder import FC_Encoder  # noqa: E402
 from qarig import ops  # noqa: E402
@@ -130,12 +131,12 @@ def ab():
         with grad:
             for rnd in range(7):
                 for mode in ("1", "0"):
-                    os.environ["QARIG_CONV_RING"] = mode
+                    _lib.set_option("conv_ring", int(mode))
                     res[mode].append(timeit(fn, reps=3))
         a, b_ = statistics.median(res["1"]), statistics.median(res["0"])
         print(f"{name:32s} ring {a * 1e3:8.3f} ms {fl / a / 1e12:6.1f} {unit}   gather kernel {b_ * 1e3:8.3f} ms "
               f"{fl / b_ / 1e12:6.1f} {unit}   ({b_ / a:.3f}x)", flush=True)
-    os.environ.pop("QARIG_CONV_RING", None)
+    _lib.set_option("conv_ring", 1)
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "quantized-autoregression-image-generator_amd"))
 import torch  # noqa: E402
-from qarig import ops  # noqa: E402
+from qarig import _lib, ops  # noqa: E402
 
 M = int(os.environ.get("ROWS", "16384"))   # ROWS=2048: the 8-sequence shard of BASELINE config 4
 SHAPES = [  # (name, M, N, K, a_kcontig, b_kcontig, kwargs)
@@ -45,9 +45,9 @@ def main():
         cases.append((name, m, n, k, dict(A=A, B=B, a_kcontig=ak, b_kcontig=bk, bias=bias,
                                           want_preact=kw.get("pre", False), act=kw.get("act", 0),
                                           gradz=gz, gact=1 if gz is not None else 0, splitk=sk)))
-    # SWEEP="ENV_NAME=v0,v1,...": A/B of a kernel knob read from the environment per launch
-    # (csrc/gemm.hip), interleaved rounds in one process
-    sweep_env, sweep = "QARIG_GEMM_STAGGER", []
+    # SWEEP="option=v0,v1,...": A/B of a kernel-selection option (qarig_set_option: gemm_dma, gemm_pair),
+    # interleaved rounds in one process
+    sweep_env, sweep = "gemm_pair", []
     if os.environ.get("SWEEP"):
         sweep_env, vals = os.environ["SWEEP"].split("=")
         sweep = vals.split(",")
@@ -55,7 +55,7 @@ def main():
         res = {}
         for rnd in range(5):
             for st in sweep:
-                os.environ[sweep_env] = str(st)
+                _lib.set_option(sweep_env, int(st))
                 for name, m, n, k, kw in cases[:10]:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ops.gemm(**kw)
