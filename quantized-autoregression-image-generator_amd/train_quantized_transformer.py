@@ -61,8 +61,10 @@ def parse_args():
                    help="File path to load json config file.")
     p.add_argument("--out-dir", required=True, type=pathlib.Path, help="File path to output directory.")
     p.add_argument("--graph-step", action="store_true",
-                   help="(additive) replay the training step from a captured HIP graph: removes the "
-                        "Python launch overhead for small per-GPU batches; single process, full batches only")
+                   help="(additive) replay the training step from captured HIP graphs: removes the Python "
+                        "launch overhead for small per-GPU batches; full batches only.  Under torchrun the "
+                        "capture is a chain of segments cut at the gradient buckets, the bucket all-reduces "
+                        "issued between them")
     p.add_argument("--packed-dataset", default=None,
                    help="(additive) one (N,C,H,W) float32 .npy holding every latent of --dataset-path "
                         "(dataset_loader.prefetch.pack_feature_maps): read through one mmap instead of "
@@ -233,7 +235,7 @@ def main():
     lr_pH, lr_pW = lr_d["patch_dim"]
     # tokens per sequence before windowing: the LR tokens (base model) or <start>, then the HR tokens
     graphed_seq = total_hr_Seq + ((img_H // lr_pH) * (img_W // lr_pW) if train_base_model else 1)
-    if args["graph_step"] and world == 1:
+    if args["graph_step"]:
         graphed = pipeline.GraphedTrainStep(model, optim, lr_codebook, hr_codebook, train_base_model,
                                             sliding_window if use_sliding_window else None)
     global_steps = 0
@@ -249,7 +251,8 @@ def main():
                 rand = None
                 if use_sliding_window:
                     rand = torch.randint(low=0, high=pipeline.num_windows(graphed_seq, sliding_window),
-                                         size=(N,))                     # CPU global RNG
+                                         size=(N * world,))             # CPU global RNG, drawn globally
+                    rand = parallel.shard(parallel.broadcast_host_tensor(rand))
                 loss = graphed(feature_map, rand)
             else:
                 seq_total = graphed_seq
