@@ -44,7 +44,7 @@ int qarig_last_error(char* buf, size_t n);
 /* Kernel-selection options: each only chooses between kernels that must give the same results
  * (tests/test_gpu_switches.py runs the parity tests under every one).  Names: gemm_dma (1), gemm_pair
  * (-1 auto), bmu_cs (0 auto), bmu_groups (-1 auto), bmu_coarse (-1 auto), attn_qw / attn_bw (0 auto),
- * lp_big (-1 auto), lp_mfma16 (1), convt_pair (1), conv_ring (1).  Returns the previous value, INT_MIN
+ * lp_big (-1 auto), lp_mfma16 (1), convt_pair (1), conv_ring (1), gemm_xcd_splits (1).  Returns the previous value, INT_MIN
  * for an unknown name.  No reference counterpart. */
 int qarig_set_option(const char* name, int value);
 

@@ -199,15 +199,32 @@ template <bool AKC, bool BKC>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_pf_kernel(const float* __restrict__ A, int64_t lda,
                                                                   const float* __restrict__ B, int64_t ldb,
                                                                   GemmEpilogue ep, int M, int N, int K,
-                                                                  int tiles_n, int splitk, float* slabs) {
+                                                                  int tiles_n, int splitk, float* slabs,
+                                                                  int xcd_splits) {
     __shared__ __attribute__((aligned(16))) float lds[PF_STAGES * DMA_STAGE_FLOATS];   // 64 KB: two workgroups per CU
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int tile, z;
+    if (xcd_splits) {
+        // Split reductions over few tiles (weight gradients: 64 tiles x 8 splits): the grid is flat and a
+        // reduction split belongs to ONE XCD -- workgroup b runs on XCD b % 8 (round-robin dispatch), takes
+        // split (b % 8) * (splitk / 8) + ... and walks every tile of it -- so that an XCD's L2 streams ONE
+        // k-range of both operands instead of every k-range of an eighth of the tiles (fabric reads of the
+        // 2048 x 512 gradient over 16,384 rows: 474 MB -> the algorithmic 168 MB).  Placement only changes
+        // which L2 serves a line, never a result.
+        const int tiles = gridDim.x / splitk;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;        // j-th workgroup of this XCD
+        const int per_xcd = splitk >> 3;                             // host: splitk % 8 == 0
+        z = xcd * per_xcd + j / tiles;
+        tile = j - (j / tiles) * tiles;
+    } else {
+        tile = xcd_remap(blockIdx.x, gridDim.x);
+        z = blockIdx.z;
+    }
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     int k_begin = 0, k_end = K;
     if (splitk > 1) {
         const int per = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
-        k_begin = blockIdx.z * per;
+        k_begin = z * per;
         k_end = min(K, k_begin + per);
     }
     const int nk = (k_end - k_begin) / BK;
@@ -219,9 +236,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_pf_kernel(const float* _
     float rs = 0.0f;
     const bool do_rs = !AKC && ep.rowsum != nullptr && tn == 0 && tid < 128;
     pf_ring<AKC, BKC>(acc, rs, do_rs, lds, A, lda, B, ldb, m0, n0, k_begin, nk, wave, lane, tid);
-    if (do_rs) ep.rowsum[(int64_t)blockIdx.z * M + m0 + tid] = rs;
+    if (do_rs) ep.rowsum[(int64_t)z * M + m0 + tid] = rs;
     __syncthreads();                      // ring no longer in use: the epilogue stages through it
-    gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, slabs);
+    // (flat grid: blockIdx.z == 0, the slab offset is folded into the pointer)
+    gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, xcd_splits && slabs ? slabs + (int64_t)z * M * N : slabs);
 }
 
 // ---------------------------------------------------------------------------------
@@ -715,15 +733,18 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
             hipLaunchKernelGGL((gemm_dma_pf2_kernel<false, false>), grid, block2, PAIR_LDS, st, A, lda, B, ldb, ep,
                                M, N, K, tiles_n, splitk, slabs);
     } else if (pf && fast && vec_epi && !(a_rowsum && a_kcontig) && !(!a_kcontig && b_kcontig)) {
+        // one reduction split per XCD (see the kernel) where the splits are a multiple of the 8 XCDs
+        const int xs = (splitk % 8 == 0 && g_qarig_opt.gemm_xcd_splits != 0) ? 1 : 0;
+        const dim3 pgrid = xs ? dim3(grid.x * splitk, 1, 1) : grid;
         if (a_kcontig && b_kcontig)
-            hipLaunchKernelGGL((gemm_dma_pf_kernel<true, true>), grid, block, 0, st, A, lda, B, ldb, ep, M,
-                               N, K, tiles_n, splitk, slabs);
+            hipLaunchKernelGGL((gemm_dma_pf_kernel<true, true>), pgrid, block, 0, st, A, lda, B, ldb, ep, M,
+                               N, K, tiles_n, splitk, slabs, xs);
         else if (a_kcontig)
-            hipLaunchKernelGGL((gemm_dma_pf_kernel<true, false>), grid, block, 0, st, A, lda, B, ldb, ep, M,
-                               N, K, tiles_n, splitk, slabs);
+            hipLaunchKernelGGL((gemm_dma_pf_kernel<true, false>), pgrid, block, 0, st, A, lda, B, ldb, ep, M,
+                               N, K, tiles_n, splitk, slabs, xs);
         else
-            hipLaunchKernelGGL((gemm_dma_pf_kernel<false, false>), grid, block, 0, st, A, lda, B, ldb, ep,
-                               M, N, K, tiles_n, splitk, slabs);
+            hipLaunchKernelGGL((gemm_dma_pf_kernel<false, false>), pgrid, block, 0, st, A, lda, B, ldb, ep,
+                               M, N, K, tiles_n, splitk, slabs, xs);
     } else {
 #define QARIG_LAUNCH_GEMM(TA, TB)                                                              \
     do {                                                                                       \

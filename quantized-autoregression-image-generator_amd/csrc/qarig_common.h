@@ -21,6 +21,7 @@ extern "C" void qarig_set_error(const char* fmt, ...);
 // the same results; -1 / 0 = the library's own choice where stated.  Defined in capi.hip.
 struct QarigOptions {
     int gemm_dma = 1;      // 0: interior GEMM shapes on the register-staged kernel instead of the LDS-DMA ring
+    int gemm_xcd_splits = 1;   // split reductions of a multiple of 8 splits: one split per XCD (1) or tiles per XCD (0)
     int gemm_pair = -1;    // paired (two-team) GEMM kernel: -1 auto (<= 256 workgroups), 0 never, 1 wherever eligible
     int bmu_cs = 0;        // resident BMU kernel, waves sharing a row tile: 0 auto, else 1 / 2 / 4
     int bmu_groups = -1;   // resident BMU kernel, group-minimum scan: -1 auto, 0 / 1

@@ -124,7 +124,7 @@ def load():
 
 
 OPTIONS = ("gemm_dma", "gemm_pair", "bmu_cs", "bmu_groups", "bmu_coarse", "attn_qw", "attn_bw", "lp_big",
-           "lp_mfma16", "convt_pair", "conv_ring")
+           "lp_mfma16", "convt_pair", "conv_ring", "gemm_xcd_splits")
 
 
 def set_option(name, value):

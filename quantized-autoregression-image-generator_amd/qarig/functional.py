@@ -756,7 +756,7 @@ class CondTable:
             group = list(group)
             # tables of up to 512 rows: the weight-streaming grouped kernel; longer ones (sequences of
             # more than ~500 tokens: BASELINE config 4's 1,025) the grouped 128 x 128-tile launches
-            fits = (P <= 512 and D % 256 == 0) or ops.gemm_grouped_supported(P, D, D)
+            fits = (P <= 512 and D % 256 == 0) or ops.gemm_grouped_supported(P, D, D, any_precision=True)
             if (group and fits
                     and all(l.weight.shape == (D, D) and l.bias is not None for l in group)):
                 for l in group:

@@ -437,8 +437,12 @@ def grouped_splitk(groups, M, N, K):
     return best
 
 
-def gemm_grouped_supported(M, N, K, splitk=1):
-    return not lp_mode() and bool(_lib.load().qarig_gemm_grouped_supported(M, N, K, splitk))
+def gemm_grouped_supported(M, N, K, splitk=1, any_precision=False):
+    """any_precision: callers whose products stay on the fp32 grouped kernel in the reduced-precision mode
+    too (the conditioning projections of a position table: a few thousand rows, where 63 separate bf16
+    nodes -- a cast, a product, two gradient products, a reduce and an accumulation add each -- cost twice
+    what the twelve fp32 grouped launches do)."""
+    return (any_precision or not lp_mode()) and bool(_lib.load().qarig_gemm_grouped_supported(M, N, K, splitk))
 
 
 def _ptr_table(tensors, G):
@@ -483,7 +487,7 @@ def gemm_grouped(A, B, C, M, N, K, a_kcontig=True, b_kcontig=True, bias=None, re
     if GEMM_EVENTS is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        GEMM_EVENTS.append((2.0 * G * M * N * K, ev0, ev1))
+        GEMM_EVENTS.append((2.0 * G * M * N * K, ev0, ev1, "f32g" if lp_mode() else ""))
 
 
 def colsum(X, out=None, accumulate=False):

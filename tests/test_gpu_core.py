@@ -146,6 +146,36 @@ def test_gemm_paired_teams(M, N, K, ak, bk, splitk):
         assert rel_err(rs, A.double().cpu().sum(0)) < 2e-6 * max(1, K / 512) ** 0.5
 
 
+def test_gemm_xcd_split_mapping():
+    """Split reductions whose split count is a multiple of 8 run one split per XCD on a flat grid (placement
+    only): the weight-gradient shapes of the bench step with 8 and 16 splits, row sums riding, accumulate --
+    against fp64 and bit-identical to the tiles-per-XCD mapping."""
+    from qarig import _lib, ops
+    g = torch.Generator().manual_seed(21)
+    for (M, N, K, sk) in ((2048, 512, 16384, 8), (512, 2048, 4096, 16), (256, 384, 2048, 8)):
+        A = torch.randn((K, M), generator=g).cuda()
+        B = (torch.randn((K, N), generator=g) * 0.1).cuda()
+        ref = _ref_gemm(A, B, False, False)
+        rs = torch.zeros(M, device="cuda")
+        C = ops.gemm(A, B, False, False, splitk=sk, a_rowsum=rs)
+        assert rel_err(C, ref) < GEMM_TOL * (K / 512) ** 0.5
+        assert rel_err(rs, A.double().cpu().sum(0)) < 2e-6 * (K / 512) ** 0.5
+        old = _lib.set_option("gemm_xcd_splits", 0)
+        try:
+            rs0 = torch.zeros(M, device="cuda")
+            C0 = ops.gemm(A, B, False, False, splitk=sk, a_rowsum=rs0)
+        finally:
+            _lib.set_option("gemm_xcd_splits", old)
+        assert torch.equal(C, C0) and torch.equal(rs, rs0)
+        out = torch.randn((M, N), generator=g).cuda()
+        want = out.double().cpu() + ref
+        ops.gemm(A, B, False, False, splitk=sk, out=out, accumulate=True)
+        assert rel_err(out, want) < GEMM_TOL * (K / 512) ** 0.5
+        Af = torch.randn((M, K), generator=g).cuda()          # a forward-shaped product with 8 splits
+        Bf = (torch.randn((N, K), generator=g) * 0.1).cuda()
+        assert rel_err(ops.gemm(Af, Bf, splitk=8), _ref_gemm(Af, Bf, True, True)) < GEMM_TOL * (K / 512) ** 0.5
+
+
 def test_gemm_strided_views():
     from qarig import ops
     g = torch.Generator().manual_seed(2)

@@ -30,7 +30,7 @@ def test_unknown_option_is_refused():
     assert _lib.set_option("gemm_dma", 1) == 1      # default, and the call returns the previous value
 
 
-@pytest.mark.parametrize("name,value", [("gemm_dma", 0), ("gemm_pair", 0), ("gemm_pair", 1)])
+@pytest.mark.parametrize("name,value", [("gemm_dma", 0), ("gemm_pair", 0), ("gemm_pair", 1), ("gemm_xcd_splits", 0)])
 def test_gemm_options(option, name, value):
     import test_gpu_core as core
     import test_gpu_grouped as grouped
@@ -40,6 +40,7 @@ def test_gemm_options(option, name, value):
         core.test_gemm_interior_dma_path(ak, bk)
     core.test_gemm_epilogues()
     core.test_gemm_splitk_and_colsum()
+    core.test_gemm_xcd_split_mapping()
     core.test_gemm_paired_teams(2048, 2048, 512, True, True, 1)
     core.test_gemm_paired_teams(2048, 512, 2048, False, False, 4)
     grouped.test_grouped_mlp_node_matches_separate_mlps_and_fp64(3, 256, 128, 256, 0, True)
