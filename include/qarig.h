@@ -175,6 +175,22 @@ int qarig_gemm_grouped_skinny_f32(const float* A, int64_t lda, int64_t a_gs, con
                                   const float* bias, int64_t bias_gs, int groups, int M, int N,
                                   int K, int act, void* stream);
 
+/* The decode step's fused form of the launch above: C_g = act(LN(X) W_g^T + bias_g) [* mul].
+ * The activations X (M, K) are shared by the groups and LayerNorm'ed over K on the way in
+ * (biased variance, eps) -- nn.LayerNorm's affine form (gamma, beta: K) or the AdaLN form
+ * scale(cond) * LN(x) + shift(cond) (scale, shift: (M, K) rows at ldmod; reference
+ * models/layers.py:130-153); all four null = no normalisation.  mul (M, N) at ldmul, optional, is
+ * an elementwise factor on the output, the same for every group (ResidualLinearLayer's
+ * x * scale(cond), models/layers.py:258-304).  Replaces the LayerNorm launch in front of a block's
+ * first Linear and the gate multiply behind its last (generate_images.py:283-290 evaluates these
+ * per generated token).  Same shape rules as qarig_gemm_grouped_skinny_f32. */
+int qarig_gemm_skinny_ln_f32(const float* X, int64_t ldx, float eps, const float* gamma,
+                             const float* beta, const float* scale, const float* shift,
+                             int64_t ldmod, const float* W, int64_t ldw, int64_t w_gs, float* C,
+                             int64_t ldc, int64_t c_gs, const float* bias, int64_t bias_gs,
+                             const float* mul, int64_t ldmul, int groups, int M, int N, int K,
+                             int act, void* stream);
+
 /* out[N] = column sums of X[M][N] in a fixed order (bias / LayerNorm-affine grads). */
 size_t qarig_colsum_workspace_bytes(int M, int N);
 int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,
@@ -343,16 +359,27 @@ int qarig_conv2d_fwd(const float* x, int N, int Cin, int H, int W, const float* 
  * the LDS-DMA ring kernel; every other geometry takes the path of qarig_conv2d_fwd.  Results differ
  * by the summation order only (tap-major instead of channel-major). */
 size_t qarig_conv2d_fwd_workspace_bytes(int Cin, int Cout, int k);
+/* ... plus, at few images (generate_images.py:366 decodes the 1-8 images just sampled), room for the
+ * partial sums of a launch whose reduction is split 2-8 ways because its tiles alone would leave CUs
+ * idle (<= 256 workgroups): given this much scratch the call splits, given only the size above it
+ * does not.  The split changes the summation order (parts added in order after the k-loop). */
+size_t qarig_conv2d_fwd_workspace_bytes_n(int N, int Cin, int H, int W, int Cout, int k);
+/* flags: QARIG_CONV_PACKED_VALID = the head of `workspace` still holds the re-ordered weights an earlier
+ * call with the same w, geometry and workspace wrote there (inference: the weights do not change between
+ * calls) -- the re-ordering launch is skipped.  0 otherwise. */
+#define QARIG_CONV_PACKED_VALID 1
 int qarig_conv2d_fwd_ws(const float* x, int N, int Cin, int H, int W, const float* w,
                         const float* bias, int Cout, int k, int stride, int pad, int act, float* y,
-                        float* preact, void* workspace, size_t ws_bytes, void* stream);
+                        float* preact, void* workspace, size_t ws_bytes, int flags, void* stream);
 
 /* nn.ConvTranspose2d(4, stride 2, padding 1) + bias + activation -- UpsampleConvLayer,
  * models/layers.py:188-207.  x (N,Cin,H,W); w (Cin,Cout,4,4); y (N,Cout,2H,2W). */
 size_t qarig_conv_transpose2d_workspace_bytes(int Cin, int Cout);
+/* the same plus the split launch's slabs at few images (see qarig_conv2d_fwd_workspace_bytes_n) */
+size_t qarig_conv_transpose2d_workspace_bytes_n(int N, int Cin, int H, int W, int Cout);
 int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H, int W, const float* w,
                                const float* bias, int Cout, int act, float* y, float* preact,
-                               void* workspace, size_t ws_bytes, void* stream);
+                               void* workspace, size_t ws_bytes, int flags, void* stream);
 
 /* autograd of the conv layers (dT = dy * act'(preact), via qarig_act_bwd, first) */
 size_t qarig_conv2d_bwd_data_workspace_bytes(int Cin, int Cout, int k);

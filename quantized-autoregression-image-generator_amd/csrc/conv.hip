@@ -300,21 +300,11 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvGeom g, const floa
 // FLIP: taps walk the input backwards (offset 1 - t instead of t - 1): the stride-1 data
 // gradient of the same layers, whose packed weights are already in that tap order.
 template <int COUT, bool FLIP>
-__global__ __launch_bounds__(64) void conv_direct4_kernel(ConvGeom g, const float* __restrict__ w,
-                                                          ConvOut o) {
-    const int p = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (p >= g.P) return;
-    const int per = g.Ho * g.Wo;
-    const int n = p / per, rem = p - n * per;
-    const int oy = rem / g.Wo, ox = rem - oy * g.Wo;      // ox % 4 == 0, W == Wo
-    const float* xb = g.x + (int64_t)n * g.C * g.H * g.W;
-    float acc[COUT][4];
-#pragma unroll
-    for (int c = 0; c < COUT; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[c][j] = 0.0f;
+__device__ __forceinline__ void conv_direct4_channels(const ConvGeom& g, const float* __restrict__ w,
+                                                      const float* __restrict__ xb, int oy, int ox, int c_begin,
+                                                      int c_end, float (&acc)[COUT][4]) {
     const bool left = ox > 0, right = ox + 4 < g.W;
-    for (int ci = 0; ci < g.C; ++ci) {
+    for (int ci = c_begin; ci < c_end; ++ci) {
 #pragma unroll
         for (int ty = 0; ty < 3; ++ty) {
             const int iy = FLIP ? oy + 1 - ty : oy - 1 + ty;
@@ -337,6 +327,46 @@ __global__ __launch_bounds__(64) void conv_direct4_kernel(ConvGeom g, const floa
                         acc[c][j] = fmaf(wv, v[j + (FLIP ? 2 - tx : tx)], acc[c][j]);
                 }
         }
+    }
+}
+
+// CS == 1: one wave per 256 pixels walks all input channels.  CS > 1 (few images: a 4-image 128 x 128 output
+// is 256 waves, one per CU, each a chain of 768 dependent row loads -- 171 us for 0.9 GFLOP): the workgroup's
+// CS waves take C / CS channels each, the partial sums meet in LDS and are added in wave order.
+template <int COUT, bool FLIP, int CS>
+__global__ __launch_bounds__(64 * CS) void conv_direct4_kernel(ConvGeom g, const float* __restrict__ w,
+                                                               ConvOut o) {
+    __shared__ float part[CS > 1 ? CS : 1][COUT * 4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = (blockIdx.x * 64 + lane) * 4;
+    const bool live = p < g.P;
+    if (CS == 1 && !live) return;
+    const int per = g.Ho * g.Wo;
+    const int n = live ? p / per : 0, rem = live ? p - n * per : 0;
+    const int oy = rem / g.Wo, ox = rem - oy * g.Wo;      // ox % 4 == 0, W == Wo
+    const float* xb = g.x + (int64_t)n * g.C * g.H * g.W;
+    float acc[COUT][4];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = 0.0f;
+    const int cper = g.C / CS;
+    if (live) conv_direct4_channels<COUT, FLIP>(g, w, xb, oy, ox, wave * cper, (wave + 1) * cper, acc);
+    if (CS > 1) {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[wave][c * 4 + j][lane] = acc[c][j];
+        __syncthreads();
+        if (wave != 0 || !live) return;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = part[0][c * 4 + j][lane];
+                for (int z = 1; z < CS; ++z) t += part[z][c * 4 + j][lane];
+                acc[c][j] = t;
+            }
     }
     const int64_t plane = (int64_t)o.HoP * o.WoP;
     const int64_t pix = (int64_t)oy * o.WoP + ox;
@@ -702,7 +732,7 @@ __device__ __forceinline__ float buffer_load4(unsigned voff, u32x4_t rsrc) {
 }
 template <bool T3, bool S2 = false>
 __device__ __forceinline__ void conv_ring_pass(Acc& acc, float* lds, const float* __restrict__ wp, const ConvGeom& g,
-                                               int c0m, int p0, unsigned x_bytes) {
+                                               int c0m, int p0, unsigned x_bytes, int t0 = 0, int nk_part = 0) {
     const int nty = T3 ? 3 : g.nty, ntx = T3 ? 3 : g.ntx;
     const int oy0 = T3 ? -1 : g.oy0, oys = T3 ? 1 : g.oys, ox0 = T3 ? -1 : g.ox0, oxs = T3 ? 1 : g.oxs;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -710,11 +740,12 @@ __device__ __forceinline__ void conv_ring_pass(Acc& acc, float* lds, const float
     const int wm = wave >> 1, wn = wave & 1;
     const int x = lane & 31, h = lane >> 5;
     const int C = g.C, H = g.H, W = g.W;
-    const int nk = g.K / BK;                 // taps * C / 16 tiles
+    // k-tiles [t0, t0 + nk) of the taps * C / 16 of the whole reduction (a split launch reduces a part)
+    const int nk = nk_part > 0 ? nk_part : g.K / BK;
     const int64_t lda = g.K;
 
     // ---- A: this wave's two DMA instructions per tile (as pf_ring)
-    const float* a_org = wp + (int64_t)c0m * lda;
+    const float* a_org = wp + (int64_t)c0m * lda + (int64_t)t0 * BK;
     const unsigned oa0 = dma_lane_off<true>(lda, wave * 2, lane), oa1 = dma_lane_off<true>(lda, wave * 2 + 1, lane);
     const unsigned my_dma_addr = __builtin_amdgcn_readfirstlane(lds_addr(lds + wave * 512));
     auto issue_a = [&](int t, int stage) {
@@ -741,6 +772,12 @@ __device__ __forceinline__ void conv_ring_pass(Acc& acc, float* lds, const float
     const unsigned b_dst = lds_addr(lds + DMA_OP_FLOATS + kr * 128 + grp * 4);
     // scalar state of the tile whose B loads are issued next: tap (ty, tx), channel base cb
     int ty = 0, tx = 0, cb = 0;
+    if (t0) {                                // a split's first tile: t0 = (ty * ntx + tx) * C / 16 + cb / 16
+        const int ct = C >> 4, tap = t0 / ct;
+        cb = (t0 - tap * ct) * 16;
+        ty = tap / ntx;
+        tx = tap - ty * ntx;
+    }
     struct BRegs { f32x4 r0, r1; };          // one tile's two k rows in flight
     int U_dx = 0, V_dx = 0;                   // ... and the column offset they were loaded for (scalars: kept apart from the vectors)
     auto load_b = [&](BRegs& br, int& br_dx) {   // issues the two loads of tile (ty, tx, cb), then advances the state
@@ -851,8 +888,14 @@ __device__ __forceinline__ void conv_ring_pass(Acc& acc, float* lds, const float
 template <bool PAIR, bool S2 = false, bool T3K = true>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* __restrict__ wp, ConvGeom g,
                                                                    ConvOut o, int tiles_p, unsigned x_bytes,
-                                                                   int64_t class_stride, int mode) {
+                                                                   int64_t class_stride, int mode, int splits,
+                                                                   int64_t slab_stride) {
     __shared__ __attribute__((aligned(16))) float lds[PF_STAGES * DMA_STAGE_FLOATS];   // 64 KB
+    // splits > 1 (few images: too few tiles to fill the chip): blockIdx.z reduces k-tiles
+    // [z, z + 1) * K / 16 / splits into its own slab of raw sums (o.y = slab 0, bias / activation / preact
+    // left to conv_split_reduce_kernel)
+    const int kz = splits > 1 ? (int)blockIdx.z : 0;
+    o.y += kz * slab_stride;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tc = tile / tiles_p, tp = tile - tc * tiles_p;   // pixel tile fastest
     const int c0m = tc * BM, p0 = tp * BN;
@@ -863,7 +906,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* 
     if constexpr (!PAIR) {
         Acc acc;
         acc_zero(acc);
-        conv_ring_pass<T3K, S2>(acc, lds, wp, g, c0m, p0, x_bytes);
+        const int nkp = splits > 1 ? g.K / BK / splits : 0;
+        conv_ring_pass<T3K, S2>(acc, lds, wp, g, c0m, p0, x_bytes, kz * nkp, nkp);
         // epilogue: as conv_mma_kernel (32 consecutive pixels of one output channel per store instruction)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -903,7 +947,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_ring_kernel(const float* 
                 woff = (int64_t)o.Cout * g.C * (cls == 0 ? 0 : (cls == 1 ? 1 : (cls == 2 ? 3 : 5)));
             }
             acc_zero(acc[px]);
-            conv_ring_pass<false>(acc[px], lds, wp + woff, g, c0m, p0, x_bytes);
+            const int nkp = splits > 1 ? g.K / BK / splits : 0;     // (mode 0 only: equal classes)
+            conv_ring_pass<false>(acc[px], lds, wp + woff, g, c0m, p0, x_bytes, kz * nkp, nkp);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1110,6 +1155,48 @@ using namespace qarig;
 extern "C" int qarig_slab_reduce_f32(const float* slabs, float* out, int64_t ldc, int M, int N,
                                      int nslab, int accumulate, void* stream);
 
+// Sum of the split launches' slabs (fixed order) + bias + activation, NCHW: element i belongs to output
+// channel (i / plane) % Cout; 16 B per lane (plane % 4 == 0).
+__global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* __restrict__ slabs, int nslab,
+                                                                int64_t total, int plane, int Cout,
+                                                                const float* __restrict__ bias, int act,
+                                                                float* __restrict__ y, float* __restrict__ preact) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    float4 t = *reinterpret_cast<const float4*>(slabs + i);
+    for (int z = 1; z < nslab; ++z) {
+        const float4 u = *reinterpret_cast<const float4*>(slabs + (int64_t)z * total + i);
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    if (bias) {
+        const float b = bias[(i / plane) % Cout];
+        t.x += b; t.y += b; t.z += b; t.w += b;
+    }
+    if (preact) *reinterpret_cast<float4*>(preact + i) = t;
+    *reinterpret_cast<float4*>(y + i) = make_float4(act_fwd(t.x, act), act_fwd(t.y, act), act_fwd(t.z, act), act_fwd(t.w, act));
+}
+
+// Reduction splits of a ring launch of `wgs` workgroups over `nk` k-tiles: 1 when the launch fills the
+// chip by itself, else enough to put two workgroups on every CU (measured at 4 images: the 512 -> 512
+// layer at 32 x 32 runs 128 tiles; 355 us unsplit).  Parts are whole and at least 16 k-tiles long.
+static int conv_ring_splits(long wgs, int nk) {
+    if (wgs > 256) return 1;
+    for (int s = 2; s <= 8; ++s)
+        if (wgs * s >= 512 && nk % s == 0 && nk / s >= 16) return s;
+    for (int s = 8; s >= 2; --s)
+        if (nk % s == 0 && nk / s >= 16) return s;
+    return 1;
+}
+static int launch_conv_split_reduce(const float* slabs, int splits, const ConvOut& o, int N, hipStream_t st) {
+    const int plane = o.HoP * o.WoP;
+    const int64_t total = (int64_t)N * o.Cout * plane;
+    hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, slabs,
+                       splits, total, plane, o.Cout, o.bias, o.act, o.y, o.preact);
+    QARIG_CHECK_LAUNCH("conv split reduce");
+    return QARIG_OK;
+}
+
+
 static int launch_conv(const float* wmat, const ConvGeom& g, const ConvOut& o, hipStream_t st) {
     const bool fwd_taps = g.oy0 == -1 && g.ox0 == -1 && g.oys == 1 && g.oxs == 1;
     const bool flip_taps = g.oy0 == 1 && g.ox0 == 1 && g.oys == -1 && g.oxs == -1;
@@ -1118,11 +1205,19 @@ static int launch_conv(const float* wmat, const ConvGeom& g, const ConvOut& o, h
                           o.os == 1 && o.py == 0 && o.px == 0 && o.WoP == g.Wo && o.HoP == g.Ho &&
                           (((uintptr_t)g.x | (uintptr_t)o.y | (uintptr_t)o.preact) & 15) == 0;
     if (o.Cout <= 4 && plain3x3) {
-        dim3 grid((g.P / 4 + 63) / 64), block(64);
+        // fewer than four waves per CU: split the channels over the 8 waves of a workgroup
+        const bool cs8 = (g.P / 4 + 63) / 64 < 1024 && g.C % 8 == 0 && g.C >= 64;
+        dim3 grid((g.P / 4 + 63) / 64), block(cs8 ? 512 : 64);
         switch (o.Cout * 2 + (flip_taps ? 1 : 0)) {
-#define QARIG_DC4(n) \
-    case 2 * n: hipLaunchKernelGGL((conv_direct4_kernel<n, false>), grid, block, 0, st, g, wmat, o); break; \
-    case 2 * n + 1: hipLaunchKernelGGL((conv_direct4_kernel<n, true>), grid, block, 0, st, g, wmat, o); break;
+#define QARIG_DC4(n)                                                                                             \
+    case 2 * n:                                                                                                  \
+        if (cs8) hipLaunchKernelGGL((conv_direct4_kernel<n, false, 8>), grid, block, 0, st, g, wmat, o);         \
+        else hipLaunchKernelGGL((conv_direct4_kernel<n, false, 1>), grid, block, 0, st, g, wmat, o);             \
+        break;                                                                                                   \
+    case 2 * n + 1:                                                                                              \
+        if (cs8) hipLaunchKernelGGL((conv_direct4_kernel<n, true, 8>), grid, block, 0, st, g, wmat, o);          \
+        else hipLaunchKernelGGL((conv_direct4_kernel<n, true, 1>), grid, block, 0, st, g, wmat, o);              \
+        break;
             QARIG_DC4(1) QARIG_DC4(2) QARIG_DC4(3) QARIG_DC4(4)
 #undef QARIG_DC4
         }
@@ -1163,17 +1258,35 @@ static bool conv3x3_ring_ok(int N, int C, int H, int W, int M, const void* x, co
     return on && packed && C % 16 == 0 && C >= 16 && M % BM == 0 && P % BN == 0 && W % 4 == 0 && xb < (1LL << 31) &&
            (int64_t)9 * C < (1 << 20) && (((uintptr_t)x | (uintptr_t)packed) & 15) == 0;
 }
+// `slabs` / `slab_bytes`: scratch behind the packed weights for a split launch (conv_ring_splits), else
+// the launch is not split.
 static int launch_conv3x3_ring(const float* w, int64_t sm, int64_t sc, int flip, const float* x, int N, int C,
-                               int H, int W, int M, const ConvOut& o, float* packed, hipStream_t st) {
-    const int64_t total = (int64_t)M * 9 * C;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(conv_pack_tap_kernel, dim3(blocks), dim3(256), 0, st, w, M, C, sm, sc, flip, packed);
-    QARIG_CHECK_LAUNCH("conv3x3 pack");
+                               int H, int W, int M, const ConvOut& o, float* packed, hipStream_t st,
+                               float* slabs = nullptr, size_t slab_bytes = 0, bool packed_valid = false) {
+    if (!packed_valid) {
+        const int64_t total = (int64_t)M * 9 * C;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv_pack_tap_kernel, dim3(blocks), dim3(256), 0, st, w, M, C, sm, sc, flip, packed);
+        QARIG_CHECK_LAUNCH("conv3x3 pack");
+    }
     ConvGeom g{x, N, C, H, W, H, W, 1, 3, 3, -1, 1, -1, 1, 9 * C, N * H * W};
     const int tiles_c = M / BM, tiles_p = g.P / BN;
+    const int64_t out_elems = (int64_t)N * M * H * W;
+    int splits = conv_ring_splits((long)tiles_c * tiles_p, g.K / BK);
+    if (splits > 1 && (!slabs || slab_bytes < (size_t)splits * out_elems * sizeof(float) ||
+                       o.os != 1 || o.HoP != H || o.WoP != W || (((uintptr_t)o.y | (uintptr_t)o.preact) & 15)))
+        splits = 1;
+    if (splits > 1) {
+        ConvOut raw{slabs, nullptr, nullptr, o.Cout, o.HoP, o.WoP, o.os, o.py, o.px, ACT_NONE};
+        hipLaunchKernelGGL((conv3x3_ring_kernel<false>), dim3(tiles_c * tiles_p, 1, splits), dim3(NTHREADS), 0, st,
+                           packed, g, raw, tiles_p, (unsigned)((int64_t)N * C * H * W * 4), (int64_t)0, 0, splits,
+                           out_elems);
+        QARIG_CHECK_LAUNCH("conv3x3 ring (split)");
+        return launch_conv_split_reduce(slabs, splits, o, N, st);
+    }
     hipLaunchKernelGGL((conv3x3_ring_kernel<false>), dim3(tiles_c * tiles_p), dim3(NTHREADS), 0, st, packed, g, o,
-                       tiles_p, (unsigned)((int64_t)N * C * H * W * 4), (int64_t)0, 0);
+                       tiles_p, (unsigned)((int64_t)N * C * H * W * 4), (int64_t)0, 0, 1, (int64_t)0);
     QARIG_CHECK_LAUNCH("conv3x3 ring");
     return QARIG_OK;
 }
@@ -1183,8 +1296,10 @@ static int launch_conv3x3_ring(const float* w, int64_t sm, int64_t sc, int flip,
 // preact (same shape as y) receives the pre-activation when non-null.
 static int conv2d_fwd_impl(const float* x, int N, int Cin, int H, int W, const float* w,
                            const float* bias, int Cout, int k, int stride, int pad, int act,
-                           float* y, float* preact, void* workspace, size_t ws_bytes, void* stream) {
+                           float* y, float* preact, void* workspace, size_t ws_bytes, int flags, void* stream) {
     QARIG_CHECK_ARG(x && w && y, "conv2d: null pointer");
+    QARIG_CHECK_ARG((flags & ~1) == 0, "conv2d: unknown flags %d", flags);
+    const bool packed_valid = flags & 1;
     QARIG_CHECK_ARG(N > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv2d: bad extents");
     QARIG_CHECK_ARG(k >= 1 && k <= 4 && stride >= 1 && stride <= 4 && pad >= 0 && pad <= 4,
                     "conv2d: kernel size 1..4, stride 1..4, padding 0..4 only");
@@ -1202,9 +1317,12 @@ static int conv2d_fwd_impl(const float* x, int N, int Cin, int H, int W, const f
     ConvOut o{y, preact, bias, Cout, Ho, Wo, 1, 0, 0, act};
     if (k == 3 && stride == 1 && pad == 1 && workspace &&
         ws_bytes >= (size_t)Cout * 9 * Cin * sizeof(float) &&
-        conv3x3_ring_ok(N, Cin, H, W, Cout, x, workspace))
+        conv3x3_ring_ok(N, Cin, H, W, Cout, x, workspace)) {
+        const size_t packed_bytes = (size_t)Cout * 9 * Cin * sizeof(float);     // a multiple of 16 B
         return launch_conv3x3_ring(w, (int64_t)Cin * 9, 9, 0, x, N, Cin, H, W, Cout, o, (float*)workspace,
-                                   (hipStream_t)stream);
+                                   (hipStream_t)stream, (float*)((char*)workspace + packed_bytes),
+                                   ws_bytes - packed_bytes, packed_valid);
+    }
     {   // stride 2: the same kernel with a strided im2col (four 4-B loads per k row)
         const int64_t P = (int64_t)N * Ho * Wo, xb = (int64_t)N * Cin * H * W * 4;
         if (g_qarig_opt.conv_ring != 0 && k == 3 && stride == 2 && pad == 1 && H == 2 * Ho && W == 2 * Wo && workspace &&
@@ -1215,12 +1333,14 @@ static int conv2d_fwd_impl(const float* x, int N, int Cin, int H, int W, const f
             const int64_t total = (int64_t)Cout * 9 * Cin;
             int blocks = (int)((total + 255) / 256);
             if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(conv_pack_tap_kernel, dim3(blocks), dim3(256), 0, st, w, Cout, Cin, (int64_t)Cin * 9,
-                               (int64_t)9, 0, packed);
-            QARIG_CHECK_LAUNCH("conv3x3 pack");
+            if (!packed_valid) {
+                hipLaunchKernelGGL(conv_pack_tap_kernel, dim3(blocks), dim3(256), 0, st, w, Cout, Cin, (int64_t)Cin * 9,
+                                   (int64_t)9, 0, packed);
+                QARIG_CHECK_LAUNCH("conv3x3 pack");
+            }
             const int tiles_p = (int)(P / BN);
             hipLaunchKernelGGL((conv3x3_ring_kernel<false, true>), dim3((Cout / BM) * tiles_p), dim3(NTHREADS), 0, st,
-                               packed, g, o, tiles_p, (unsigned)xb, (int64_t)0, 0);
+                               packed, g, o, tiles_p, (unsigned)xb, (int64_t)0, 0, 1, (int64_t)0);
             QARIG_CHECK_LAUNCH("conv3x3 stride-2 ring");
             return QARIG_OK;
         }
@@ -1231,7 +1351,7 @@ static int conv2d_fwd_impl(const float* x, int N, int Cin, int H, int W, const f
 extern "C" int qarig_conv2d_fwd(const float* x, int N, int Cin, int H, int W, const float* w,
                                 const float* bias, int Cout, int k, int stride, int pad, int act,
                                 float* y, float* preact, void* stream) {
-    return conv2d_fwd_impl(x, N, Cin, H, W, w, bias, Cout, k, stride, pad, act, y, preact, nullptr, 0, stream);
+    return conv2d_fwd_impl(x, N, Cin, H, W, w, bias, Cout, k, stride, pad, act, y, preact, nullptr, 0, 0, stream);
 }
 
 // The same with a scratch buffer (Cout * Cin * k * k floats) for a re-ordered copy of the weights:
@@ -1240,16 +1360,37 @@ extern "C" size_t qarig_conv2d_fwd_workspace_bytes(int Cin, int Cout, int k) {
     if (Cin < 1 || Cout < 1 || k < 1 || k > 4 || Cin > (1 << 20) || Cout > (1 << 20)) return 0;
     return (size_t)Cin * Cout * k * k * sizeof(float);
 }
+// ... and, at few images, room for the split launch's slabs (conv_ring_splits): the 3x3 / stride 1 / padding 1
+// layers of a <= 8-image decoder run their reduction in 2-4 parts to fill the chip.
+static size_t conv_split_slab_bytes(long wgs, int nk, int64_t out_elems) {
+    const int s = conv_ring_splits(wgs, nk);
+    return s > 1 ? (size_t)s * out_elems * sizeof(float) : 0;
+}
+extern "C" size_t qarig_conv2d_fwd_workspace_bytes_n(int N, int Cin, int H, int W, int Cout, int k) {
+    const size_t base = qarig_conv2d_fwd_workspace_bytes(Cin, Cout, k);
+    if (!base || N < 1 || H < 1 || W < 1 || !qarig_dims_ok({N, Cout, H, W}, 1LL << 20, 1LL << 31)) return base;
+    if (k != 3 || Cin % 16 || Cout % BM || ((int64_t)N * H * W) % BN) return base;
+    return base + conv_split_slab_bytes((long)(Cout / BM) * ((int64_t)N * H * W / BN), 9 * Cin / BK,
+                                        (int64_t)N * Cout * H * W);
+}
 extern "C" int qarig_conv2d_fwd_ws(const float* x, int N, int Cin, int H, int W, const float* w,
                                    const float* bias, int Cout, int k, int stride, int pad, int act,
-                                   float* y, float* preact, void* workspace, size_t ws_bytes, void* stream) {
+                                   float* y, float* preact, void* workspace, size_t ws_bytes, int flags,
+                                   void* stream) {
     return conv2d_fwd_impl(x, N, Cin, H, W, w, bias, Cout, k, stride, pad, act, y, preact, workspace, ws_bytes,
-                           stream);
+                           flags, stream);
 }
 
 extern "C" size_t qarig_conv_transpose2d_workspace_bytes(int Cin, int Cout) {
     if (Cin < 1 || Cout < 1 || Cin > (1 << 20) || Cout > (1 << 20)) return 0;
     return (size_t)16 * Cin * Cout * sizeof(float);
+}
+extern "C" size_t qarig_conv_transpose2d_workspace_bytes_n(int N, int Cin, int H, int W, int Cout) {
+    const size_t base = qarig_conv_transpose2d_workspace_bytes(Cin, Cout);
+    if (!base || N < 1 || H < 1 || W < 1 || !qarig_dims_ok({N, Cout, H, W, 4}, 1LL << 20, 1LL << 31)) return base;
+    if (Cin % 16 || Cout % BM || ((int64_t)N * H * W) % BN) return base;
+    return base + conv_split_slab_bytes(2L * (Cout / BM) * ((int64_t)N * H * W / BN), 4 * Cin / BK,
+                                        (int64_t)N * Cout * H * W * 4);
 }
 
 // nn.ConvTranspose2d(Cin, Cout, 4, stride 2, padding 1) + bias + activation.
@@ -1257,8 +1398,10 @@ extern "C" size_t qarig_conv_transpose2d_workspace_bytes(int Cin, int Cout) {
 extern "C" int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H, int W,
                                           const float* w, const float* bias, int Cout, int act,
                                           float* y, float* preact, void* workspace,
-                                          size_t ws_bytes, void* stream) {
+                                          size_t ws_bytes, int flags, void* stream) {
     QARIG_CHECK_ARG(x && w && y, "conv_transpose2d: null pointer");
+    QARIG_CHECK_ARG((flags & ~1) == 0, "conv_transpose2d: unknown flags %d", flags);
+    const bool packed_valid = flags & 1;
     QARIG_CHECK_ARG(N > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv_transpose2d: bad extents");
     QARIG_CHECK_ARG(qarig_dims_ok({N, Cin, H, W, 4}, 1LL << 20, 1LL << 31), "conv_transpose2d: extents too large");
     QARIG_CHECK_ARG(qarig_dims_ok({N, Cout, H, W, 4}, 1LL << 20, 1LL << 31), "conv_transpose2d: extents too large");
@@ -1276,19 +1419,38 @@ extern "C" int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H,
     if (blocks > 4096) blocks = 4096;
     // the four parity classes as 2x2-tap stride-1 products on the LDS-DMA ring, two column parities per workgroup
     if (conv3x3_ring_ok(N, Cin, H, W, Cout, x, packed) && (((uintptr_t)y | (uintptr_t)preact) & 7) == 0) {
-        hipLaunchKernelGGL(convt_pack_tap_kernel, dim3(blocks), dim3(256), 0, st, w, Cin, Cout, packed);
-        QARIG_CHECK_LAUNCH("conv_transpose2d pack");
+        if (!packed_valid) {
+            hipLaunchKernelGGL(convt_pack_tap_kernel, dim3(blocks), dim3(256), 0, st, w, Cin, Cout, packed);
+            QARIG_CHECK_LAUNCH("conv_transpose2d pack");
+        }
         const int K = Cin * 4, P = N * H * W;
         ConvGeom g{x, N, Cin, H, W, H, W, 1, 2, 2, 0, -1, 0, -1, K, P};
         ConvOut o{y, preact, bias, Cout, 2 * H, 2 * W, 2, 0, 0, act};
         const int tiles_p = P / BN;
+        const size_t packed_bytes = qarig_conv_transpose2d_workspace_bytes(Cin, Cout);
+        const int64_t out_elems = (int64_t)N * Cout * H * W * 4;
+        int splits = conv_ring_splits(2L * (Cout / BM) * tiles_p, K / BK);
+        if (splits > 1 && (ws_bytes < packed_bytes + (size_t)splits * out_elems * sizeof(float) ||
+                           (((uintptr_t)y | (uintptr_t)preact) & 15) || W % 2))
+            splits = 1;
+        if (splits > 1) {
+            float* slabs = (float*)((char*)workspace + packed_bytes);
+            ConvOut raw{slabs, nullptr, nullptr, Cout, 2 * H, 2 * W, 2, 0, 0, ACT_NONE};
+            hipLaunchKernelGGL((conv3x3_ring_kernel<true>), dim3((Cout / BM) * tiles_p, 2, splits), dim3(NTHREADS), 0,
+                               st, packed, g, raw, tiles_p, (unsigned)((int64_t)N * Cin * H * W * 4),
+                               (int64_t)Cout * K, 0, splits, out_elems);
+            QARIG_CHECK_LAUNCH("conv_transpose2d ring (split)");
+            return launch_conv_split_reduce(slabs, splits, o, N, st);
+        }
         hipLaunchKernelGGL((conv3x3_ring_kernel<true>), dim3((Cout / BM) * tiles_p, 2), dim3(NTHREADS), 0, st, packed, g,
-                           o, tiles_p, (unsigned)((int64_t)N * Cin * H * W * 4), (int64_t)Cout * K, 0);
+                           o, tiles_p, (unsigned)((int64_t)N * Cin * H * W * 4), (int64_t)Cout * K, 0, 1, (int64_t)0);
         QARIG_CHECK_LAUNCH("conv_transpose2d ring");
         return QARIG_OK;
     }
-    hipLaunchKernelGGL(convt_pack_kernel, dim3(blocks), dim3(256), 0, st, w, Cin, Cout, packed);
-    QARIG_CHECK_LAUNCH("conv_transpose2d pack");
+    if (!packed_valid) {
+        hipLaunchKernelGGL(convt_pack_kernel, dim3(blocks), dim3(256), 0, st, w, Cin, Cout, packed);
+        QARIG_CHECK_LAUNCH("conv_transpose2d pack");
+    }
     // both column parities per launch (8-B stores) where the MFMA kernel applies and y / preact
     // rows are 8-B aligned; QARIG_CONVT_PAIR=0 restores one class per launch
     const bool pair_on = g_qarig_opt.convt_pair != 0;
@@ -1378,7 +1540,7 @@ extern "C" int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, i
         ConvOut o{dx, nullptr, nullptr, Cin, H, W, 2, 0, 0, ACT_NONE};
         const int tiles_p = P / BN;
         hipLaunchKernelGGL((conv3x3_ring_kernel<true>), dim3((Cin / BM) * tiles_p, 2), dim3(NTHREADS), 0, st, packed, g,
-                           o, tiles_p, (unsigned)((int64_t)N * Cout * Ho * Wo * 4), (int64_t)0, 1);
+                           o, tiles_p, (unsigned)((int64_t)N * Cout * Ho * Wo * 4), (int64_t)0, 1, 1, (int64_t)0);
         QARIG_CHECK_LAUNCH("conv2d_bwd_data ring");
         return QARIG_OK;
     }
@@ -1444,7 +1606,7 @@ static int convt_bwd_data_impl(const float* dT, int N, int Cout, int H, int W, c
             QARIG_CHECK_LAUNCH("conv_transpose2d_bwd_data pack");
             const int tiles_p = (int)(P / BN);
             hipLaunchKernelGGL((conv3x3_ring_kernel<false, true, false>), dim3((Cin / BM) * tiles_p), dim3(NTHREADS), 0,
-                               st, packed, g, o, tiles_p, (unsigned)xb, (int64_t)0, 0);
+                               st, packed, g, o, tiles_p, (unsigned)xb, (int64_t)0, 0, 1, (int64_t)0);
             QARIG_CHECK_LAUNCH("conv_transpose2d_bwd_data ring");
             return QARIG_OK;
         }

@@ -540,13 +540,36 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // (deterministic), then the usual epilogue runs on 256 threads per 16-row tile.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template <int MT>
+// Decode-step fusions (the step is a chain of dependent ~5 us launches, so every launch removed is
+// time): LN != 0 normalises the A rows on the way in -- LayerNorm over the K columns (K = the model
+// width) in nn.LayerNorm's affine form (gamma/beta) or the AdaLN form scale(cond) * LN(x) + shift(cond)
+// (csrc/norm.hip, same arithmetic: one wave per row, same summation order) -- so the LayerNorm launch
+// in front of a block's first Linear disappears; `mul` multiplies the output elementwise (the
+// residual layer's x * scale(cond) of the reference's ResidualLinearLayer, models/layers.py:258-304).
+struct SkinnyFuse {
+    const float* gamma;   // LN affine form (K)
+    const float* beta;
+    const float* scale;   // LN AdaLN form (M, K) rows at ldmod
+    const float* shift;
+    int64_t ldmod;
+    float eps;
+    const float* mul;     // (M, N) rows at ldmul, or null
+    int64_t ldmul;
+};
+
+__device__ __forceinline__ float4 ln_apply(float4 a, float mean, float rstd, float4 g, float4 b) {
+    return make_float4(((a.x - mean) * rstd) * g.x + b.x, ((a.y - mean) * rstd) * g.y + b.y,
+                       ((a.z - mean) * rstd) * g.z + b.z, ((a.w - mean) * rstd) * g.w + b.w);
+}
+
+template <int MT, int LN>   // LN: 0 none, 1 gamma/beta, 2 scale/shift rows
 __global__ __launch_bounds__(1024) void gemm_skinny_kernel(const float* __restrict__ A, int64_t lda,
                                                            const float* __restrict__ B, int64_t ldb,
                                                            GemmEpilogue ep, int M, int N, int K,
                                                            int64_t a_gs, int64_t b_gs, int64_t c_gs,
-                                                           int64_t bias_gs) {
+                                                           int64_t bias_gs, SkinnyFuse fz) {
     __shared__ float part[16][MT * 256];
+    __shared__ float stat[64][2];
     // grouped form: blockIdx.y selects an independent problem at fixed operand strides
     A += blockIdx.y * a_gs;
     B += blockIdx.y * b_gs;
@@ -559,6 +582,8 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(const float* __restri
     if (ep.residual) ep.residual += (int64_t)mz * ep.ldr;
     if (ep.preact) ep.preact += (int64_t)mz * ep.ldp;
     if (ep.gradz) ep.gradz += (int64_t)mz * ep.ldz;
+    if (LN == 2) { fz.scale += (int64_t)mz * fz.ldmod; fz.shift += (int64_t)mz * fz.ldmod; }
+    if (fz.mul) fz.mul += (int64_t)mz * fz.ldmul;
     M = min(M - mz, 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 16;
@@ -578,18 +603,69 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(const float* __restri
     }
     // U k-steps of loads are issued back to back before their MFMAs: the kernel is pure
     // memory latency (a wave's whole K slice is 2..8 such steps), so the loads must overlap
-    constexpr int U = MT == 1 ? 8 : (MT == 2 ? 4 : 2);
+    constexpr int U = LN ? (MT <= 2 ? 2 : 1) : (MT == 1 ? 8 : (MT == 2 ? 4 : 2));
+    float mean[MT], rstd[MT];
+    float4 bpre[U];       // the first k-steps' weights: in flight while the row statistics are computed
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        bpre[u] = 16 * u < kslice ? *reinterpret_cast<const float4*>(bp + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (LN) {
+        // row statistics, one wave per row as layernorm_fwd_kernel does them (rows of this 64-row
+        // slab round-robin over the 16 waves)
+        for (int r = wave; r < M; r += 16) {
+            const float* xr = A + (int64_t)r * lda;
+            float s = 0.0f;
+            for (int c = lane * 4; c < K; c += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(xr + c);
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+            const float mu = wave_sum(s) / (float)K;
+            float q = 0.0f;
+            for (int c = lane * 4; c < K; c += 256) {
+                float4 v = *reinterpret_cast<const float4*>(xr + c);
+                v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu;
+                q = fmaf(v.x, v.x, q); q = fmaf(v.y, v.y, q);
+                q = fmaf(v.z, v.z, q); q = fmaf(v.w, v.w, q);
+            }
+            const float rs = 1.0f / sqrtf(wave_sum(q) / (float)K + fz.eps);
+            if (lane == 0) { stat[r][0] = mu; stat[r][1] = rs; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            mean[t] = aok[t] ? stat[t * 16 + col][0] : 0.0f;
+            rstd[t] = aok[t] ? stat[t * 16 + col][1] : 0.0f;
+        }
+    }
     for (int k0 = 0; k0 < kslice; k0 += 16 * U) {
         float4 b[U], a[MT][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = k0 + 16 * u;
             const bool in = k < kslice;          // wave-uniform
-            b[u] = in ? *reinterpret_cast<const float4*>(bp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[u] = k0 == 0 ? bpre[u]
+                           : (in ? *reinterpret_cast<const float4*>(bp + k) : make_float4(0.f, 0.f, 0.f, 0.f));
 #pragma unroll
             for (int t = 0; t < MT; ++t)
                 a[t][u] = (in && aok[t]) ? *reinterpret_cast<const float4*>(ap[t] + k)
                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (LN == 1 && in) {
+                const float4 g = *reinterpret_cast<const float4*>(fz.gamma + koff + k);
+                const float4 h = *reinterpret_cast<const float4*>(fz.beta + koff + k);
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    if (aok[t]) a[t][u] = ln_apply(a[t][u], mean[t], rstd[t], g, h);
+            }
+            if (LN == 2 && in) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    if (aok[t]) {
+                        const int64_t mo = (int64_t)(t * 16 + col) * fz.ldmod + koff + k;
+                        const float4 g = *reinterpret_cast<const float4*>(fz.scale + mo);
+                        const float4 h = *reinterpret_cast<const float4*>(fz.shift + mo);
+                        a[t][u] = ln_apply(a[t][u], mean[t], rstd[t], g, h);
+                    }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -618,6 +694,7 @@ __global__ __launch_bounds__(1024) void gemm_skinny_kernel(const float* __restri
         if (ep.preact) ep.preact[(int64_t)m * ep.ldp + n] = v;
         float y = act_fwd(v, ep.act);
         if (ep.gradz) y *= act_grad(ep.gradz[(int64_t)m * ep.ldz + n], ep.gact);
+        if (fz.mul) y *= fz.mul[(int64_t)m * fz.ldmul + n];
         ep.C[(int64_t)m * ep.ldc + n] = y;
     }
 }
@@ -639,14 +716,23 @@ static constexpr int SKINNY_MAX_ROWS = 512;
 
 static void launch_skinny(const float* A, int64_t lda, const float* B, int64_t ldb, const GemmEpilogue& eps,
                           int M, int N, int K, int64_t a_gs, int64_t b_gs, int64_t c_gs,
-                          int64_t bias_gs, int groups, hipStream_t st) {
+                          int64_t bias_gs, int groups, hipStream_t st, const SkinnyFuse& fz = SkinnyFuse{}) {
     dim3 sgrid((N + 15) / 16, groups, (M + 63) / 64), sblock(1024);
-    switch (M > 64 ? 4 : (M + 15) / 16) {
-        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K, a_gs, b_gs, c_gs, bias_gs); break;
-        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K, a_gs, b_gs, c_gs, bias_gs); break;
-        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K, a_gs, b_gs, c_gs, bias_gs); break;
-        default: hipLaunchKernelGGL((gemm_skinny_kernel<4>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K, a_gs, b_gs, c_gs, bias_gs); break;
+    const int mt = M > 64 ? 4 : (M + 15) / 16;
+    const int ln = fz.gamma ? 1 : (fz.scale ? 2 : 0);
+#define QARIG_SKINNY(MT, LN)                                                                           \
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, LN>), sgrid, sblock, 0, st, A, lda, B, ldb, eps, M, N, K, \
+                       a_gs, b_gs, c_gs, bias_gs, fz)
+#define QARIG_SKINNY_MT(LN)                                                                            \
+    switch (mt) {                                                                                      \
+        case 1: QARIG_SKINNY(1, LN); break;                                                            \
+        case 2: QARIG_SKINNY(2, LN); break;                                                            \
+        case 3: QARIG_SKINNY(3, LN); break;                                                            \
+        default: QARIG_SKINNY(4, LN); break;                                                           \
     }
+    if (ln == 0) { QARIG_SKINNY_MT(0) } else if (ln == 1) { QARIG_SKINNY_MT(1) } else { QARIG_SKINNY_MT(2) }
+#undef QARIG_SKINNY_MT
+#undef QARIG_SKINNY
 }
 
 static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float* B,
@@ -972,5 +1058,36 @@ extern "C" int qarig_gemm_grouped_skinny_f32(const float* A, int64_t lda, int64_
     GemmEpilogue eps{C, ldc, bias, nullptr, 0, nullptr, 0, act, nullptr, 0, 0, nullptr};
     launch_skinny(A, lda, W, ldw, eps, M, N, K, a_gs, w_gs, c_gs, bias_gs, groups, (hipStream_t)stream);
     QARIG_CHECK_LAUNCH("gemm_grouped_skinny");
+    return QARIG_OK;
+}
+
+// The decode step's fused form of the same launch: C_g = act(LN(X) W_g^T + bias_g) [* mul], the
+// activations X (M, K) shared by the groups and LayerNorm'ed over K on the way in -- affine form
+// (gamma, beta) or AdaLN form (scale, shift rows at ldmod), models/layers.py:130-153 / nn.LayerNorm;
+// all four null: no normalisation.  mul (M, N) at ldmul, optional: elementwise factor on the output
+// (ResidualLinearLayer's x * scale(cond), models/layers.py:258-304), the same for every group.
+extern "C" int qarig_gemm_skinny_ln_f32(const float* X, int64_t ldx, float eps, const float* gamma,
+                                        const float* beta, const float* scale, const float* shift,
+                                        int64_t ldmod, const float* W, int64_t ldw, int64_t w_gs,
+                                        float* C, int64_t ldc, int64_t c_gs, const float* bias,
+                                        int64_t bias_gs, const float* mul, int64_t ldmul, int groups,
+                                        int M, int N, int K, int act, void* stream) {
+    QARIG_CHECK_ARG(X && W && C, "gemm_skinny_ln: null operand");
+    QARIG_CHECK_ARG(groups > 0 && groups <= 65535 && M > 0 && M <= SKINNY_MAX_ROWS && N > 0 && K > 0 && K % 256 == 0,
+                    "gemm_skinny_ln: needs 0 < M <= 512, K %% 256 == 0 (M=%d N=%d K=%d groups=%d)",
+                    M, N, K, groups);
+    QARIG_CHECK_ARG(act >= 0 && act <= 3, "gemm_skinny_ln: bad activation id");
+    QARIG_CHECK_ARG((gamma == nullptr) == (beta == nullptr), "gemm_skinny_ln: gamma/beta pair");
+    QARIG_CHECK_ARG((scale == nullptr) == (shift == nullptr), "gemm_skinny_ln: scale/shift pair");
+    QARIG_CHECK_ARG(!(gamma && scale), "gemm_skinny_ln: affine and AdaLN forms are exclusive");
+    QARIG_CHECK_ARG((((uintptr_t)X | (uintptr_t)W | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)scale |
+                      (uintptr_t)shift) & 15) == 0 && ldx % 4 == 0 && ldw % 4 == 0 && w_gs % 4 == 0 &&
+                        (!scale || ldmod % 4 == 0),
+                    "gemm_skinny_ln: operands must be 16-B aligned");
+    QARIG_CHECK_ARG(!(gamma || scale) || eps > 0.0f, "gemm_skinny_ln: eps must be positive");
+    GemmEpilogue eps_{C, ldc, bias, nullptr, 0, nullptr, 0, act, nullptr, 0, 0, nullptr};
+    SkinnyFuse fz{gamma, beta, scale, shift, ldmod, eps, mul, ldmul};
+    launch_skinny(X, ldx, W, ldw, eps_, M, N, K, 0, w_gs, c_gs, bias_gs, groups, (hipStream_t)stream, fz);
+    QARIG_CHECK_LAUNCH("gemm_skinny_ln");
     return QARIG_OK;
 }

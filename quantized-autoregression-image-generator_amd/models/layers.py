@@ -237,12 +237,14 @@ class AttentionLayer(nn.Module):
     def __init__(self, heads=8, in_dim=512, cross_cond_dim=512, hidden_dim=2_048,
                  use_cross_attn=True, use_masked_attn=True, activation_type="silu"):
         super().__init__()
-        if in_dim % heads or (in_dim // heads) not in ops.ATTENTION_HEAD_DIMS:
-            # the reference accepts any divisor; the HIP attention kernels are built for these
+        if in_dim % heads or ops.attention_head_dim(in_dim // heads) is None:
+            # the reference accepts any divisor of in_dim; head dims that are not instantiated run
+            # zero-padded on the next one (QF.attention), only heads wider than 64 have no kernel
             raise ValueError(f"AttentionLayer: in_dim {in_dim} / heads {heads} gives head dim "
-                             f"{in_dim / heads:g}; the MI355X kernels support head dims "
-                             f"{ops.ATTENTION_HEAD_DIMS}")
+                             f"{in_dim / heads:g}; the MI355X kernels serve head dims up to "
+                             f"{ops.ATTENTION_HEAD_DIMS[-1]} that divide in_dim")
         self.heads = heads
+        self.head_dim = in_dim // heads
         self.use_cross_attn = use_cross_attn
         self.use_masked_attn = use_masked_attn
         if not self.use_cross_attn:

@@ -73,6 +73,7 @@ SIGNATURES = {
     "qarig_attention_lp_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P, P, P, P, P]),
     "qarig_attention_decode": (I, [P, P, P, P, P, I, I, I, I, P, I, L, F, P, P, P]),
     "qarig_gemm_grouped_skinny_f32": (I, [P, L, L, P, L, L, P, L, L, P, L, I, I, I, I, I, P]),
+    "qarig_gemm_skinny_ln_f32": (I, [P, L, F, P, P, P, P, L, P, L, L, P, L, L, P, L, P, L, I, I, I, I, I, P]),
     "qarig_attention_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P, P, P, P, P]),
     "qarig_cross_entropy_fwd": (I, [P, P, I, I, P, P, P, P, P]),
     "qarig_mse_workspace_bytes": (Z, []),
@@ -85,9 +86,11 @@ SIGNATURES = {
     "qarig_scale_by": (I, [P, P, P, L, P]),
     "qarig_conv2d_fwd": (I, [P, I, I, I, I, P, P, I, I, I, I, I, P, P, P]),
     "qarig_conv2d_fwd_workspace_bytes": (Z, [I, I, I]),
-    "qarig_conv2d_fwd_ws": (I, [P, I, I, I, I, P, P, I, I, I, I, I, P, P, P, Z, P]),
+    "qarig_conv2d_fwd_workspace_bytes_n": (Z, [I, I, I, I, I, I]),
+    "qarig_conv2d_fwd_ws": (I, [P, I, I, I, I, P, P, I, I, I, I, I, P, P, P, Z, I, P]),
     "qarig_conv_transpose2d_workspace_bytes": (Z, [I, I]),
-    "qarig_conv_transpose2d_fwd": (I, [P, I, I, I, I, P, P, I, I, P, P, P, Z, P]),
+    "qarig_conv_transpose2d_workspace_bytes_n": (Z, [I, I, I, I, I]),
+    "qarig_conv_transpose2d_fwd": (I, [P, I, I, I, I, P, P, I, I, P, P, P, Z, I, P]),
     "qarig_conv2d_bwd_data_workspace_bytes": (Z, [I, I, I]),
     "qarig_conv2d_bwd_data": (I, [P, I, I, I, I, P, I, I, I, I, I, I, P, P, Z, P]),
     "qarig_conv_transpose2d_bwd_data": (I, [P, I, I, I, I, P, I, P, P]),

@@ -540,25 +540,51 @@ def layernorm_mod(x, scale, shift, eps=1e-5, with_skip=False):
 
 class _Attention(torch.autograd.Function):
     """softmax(QK^T/sqrt(d) [causal]) V per head on (N,S,H*d) tensors
-    (reference models/layers.py:433-474)."""
+    (reference models/layers.py:433-474).  scale_dim: the model's head dim when the heads arrive
+    zero-padded to a kernel head dim (see `attention`)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, causal):
+    def forward(ctx, q, k, v, heads, causal, scale_dim=None):
         require_cuda(q, k, v)
         q, k, v = f32c(q), f32c(k), f32c(v)
-        o, lse = ops.attention_fwd(q, k, v, heads, causal)
+        o, lse = ops.attention_fwd(q, k, v, heads, causal, scale_dim)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.heads, ctx.causal = heads, causal
+        ctx.heads, ctx.causal, ctx.scale_dim = heads, causal, scale_dim
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
-        dq, dk, dv = ops.attention_bwd(q, k, v, o, f32c(do), lse, ctx.heads, ctx.causal)
-        return dq, dk, dv, None, None
+        dq, dk, dv = ops.attention_bwd(q, k, v, o, f32c(do), lse, ctx.heads, ctx.causal, ctx.scale_dim)
+        return dq, dk, dv, None, None, None
+
+
+def _pad_heads(t, heads, d, dp):
+    """(N,S,H*d) -> (N,S,H*dp), every head zero-padded from d to dp columns."""
+    N, S, _ = t.shape
+    return torch.nn.functional.pad(t.reshape(N, S, heads, d), (0, dp - d)).reshape(N, S, heads * dp)
 
 
 def attention(q, k, v, heads, causal):
+    """The reference accepts any `heads` that divides the model width (models/layers.py:433); the kernels
+    are instantiated for head dims 4, 8, 16, 32 and 64.  Any other head dim up to 64 runs on the next
+    instantiated one with every head zero-padded: the extra columns add exact zeros to q.k and produce
+    output columns that are dropped again (softmax scale from the model's head dim), so the result is the
+    reference's; pad and slice are torch ops (a rare shape: not a hot path)."""
+    d = q.shape[-1] // heads
+    dp = ops.attention_head_dim(d)
+    if dp is None:
+        raise ValueError(f"attention: head dim {d} (= {q.shape[-1]} / {heads} heads) is wider than the widest "
+                         f"MI355X kernel ({ops.ATTENTION_HEAD_DIMS[-1]})")
+    if dp != d:
+        qp, kp, vp = (_pad_heads(t, heads, d, dp) for t in (q, k, v))
+        if _no_grad():
+            require_cuda(q, k, v)
+            o = ops.attention_fwd(f32c(qp), f32c(kp), f32c(vp), heads, causal, d)[0]
+        else:
+            o = _Attention.apply(qp, kp, vp, heads, causal, d)
+        N, S, _ = o.shape
+        return o.reshape(N, S, heads, dp)[..., :d].reshape(N, S, heads * d)
     if _no_grad():
         require_cuda(q, k, v)
         return ops.attention_fwd(f32c(q), f32c(k), f32c(v), heads, causal)[0]

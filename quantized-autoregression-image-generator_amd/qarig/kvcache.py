@@ -28,6 +28,11 @@ from models.layers import _lin_params, _mlp2_forward
 from . import functional as QF
 from . import ops
 
+# LayerNorm (affine or AdaLN form) inside the launch of the Linear that reads it, the feed-forward
+# gate multiply inside the launch of the Linear that produces its operand: 15 -> 11 dependent launches
+# per encoder-decoder layer and token.  False: the separate launches (the tests compare both).
+FUSE_NORMS = True
+
 
 class DecodeCache:
     def __init__(self, model, enc, batch, max_len, graph=None):
@@ -187,6 +192,30 @@ class DecodeCache:
             return QF.layernorm_mod(x, scale.reshape(x.shape), shift.reshape(x.shape), norm.norm.eps)
         return QF.layernorm_affine(x, norm.weight, norm.bias, norm.eps)
 
+    def _ln_mlp(self, norm, x, proj, key, use_adaln0, seq, mul=None, stacked=None):
+        """The block's two-layer MLP on LayerNorm(x): the norm rides in the first Linear's launch
+        (qarig_gemm_skinny_ln_f32) and `mul` -- the residual layer's scale(cond) -- in the second's.
+        stacked: (w1, b1, w2, b2, act1, act2) with a leading group dimension (the q/k/v MLPs).
+        Returns (B, D), or (G, B, D) for a stacked MLP; None when the shapes do not fit the fused launch."""
+        B, D = self.batch, self.dim
+        if stacked is not None:
+            w1, b1, w2, b2, act1, act2 = stacked
+        else:
+            (w1, b1), (w2, b2) = _lin_params(seq[0]), _lin_params(seq[1])
+            act1, act2 = seq[0]._act, seq[1]._act
+        if D % 256 or B > 512 or w1.shape[-1] != D or w2.shape[-1] % 256 or b1 is None or b2 is None:
+            return None
+        x2 = x.reshape(B, D)
+        if use_adaln0:
+            scale, shift = proj[key]
+            hid = ops.gemm_skinny_ln(x2, w1, b1, act1, scale=scale.reshape(B, D), shift=shift.reshape(B, D),
+                                     eps=norm.norm.eps)
+        else:
+            hid = ops.gemm_skinny_ln(x2, w1, b1, act1, gamma=norm.weight, beta=norm.bias, eps=norm.eps)
+        if stacked is not None:
+            return ops.gemm_grouped_skinny(hid, w2, b2, act=act2)
+        return ops.gemm_skinny_ln(hid, w2, b2, act2, mul=None if mul is None else mul.reshape(B, D))
+
     def _residual(self, res, x, x_skip, proj, key, scaled=False):
         """ResidualLinearLayer.forward with the scale projection supplied (`scaled`: the
         producer of x already applied it)."""
@@ -207,15 +236,20 @@ class DecodeCache:
             proj = projections[li]
             sab = layer.self_attn_block
             at = sab.self_attn
-            h = self._norm(sab.self_attn_norm, x, proj, "self_norm", sab.use_adaln0)
-            if self._stacked:
-                w1, b1, w2, b2, act1, act2 = self._qkv[li]
-                hid = ops.gemm_grouped_skinny(h.reshape(B, D), w1, b1, act=act1, shared_a=True)
-                q, k, v = ops.gemm_grouped_skinny(hid, w2, b2, act=act2)
+            qkv = self._ln_mlp(sab.self_attn_norm, x, proj, "self_norm", sab.use_adaln0, None,
+                               stacked=self._qkv[li]) if self._stacked and FUSE_NORMS else None
+            if qkv is not None:
+                q, k, v = qkv
             else:
-                q = _mlp2_forward(at.q_block, h).reshape(B, D)
-                k = _mlp2_forward(at.k_block, h).reshape(B, D)
-                v = _mlp2_forward(at.v_block, h).reshape(B, D)
+                h = self._norm(sab.self_attn_norm, x, proj, "self_norm", sab.use_adaln0)
+                if self._stacked:
+                    w1, b1, w2, b2, act1, act2 = self._qkv[li]
+                    hid = ops.gemm_grouped_skinny(h.reshape(B, D), w1, b1, act=act1, shared_a=True)
+                    q, k, v = ops.gemm_grouped_skinny(hid, w2, b2, act=act2)
+                else:
+                    q = _mlp2_forward(at.q_block, h).reshape(B, D)
+                    k = _mlp2_forward(at.k_block, h).reshape(B, D)
+                    v = _mlp2_forward(at.v_block, h).reshape(B, D)
             o_mul = proj["self_scale"].reshape(B, D) if "self_scale" in proj else None
             o = ops.attention_decode(q, k, v, self.kv[li, 0], self.kv[li, 1], length, at.heads,
                                      len_dev=len_dev, o_mul=o_mul)
@@ -224,16 +258,25 @@ class DecodeCache:
                 cab = layer.cross_attn_block
                 at = cab.cross_attn
                 ck, cv = self.cross[li]
-                h = self._norm(cab.cross_attn_norm, x, proj, "cross_norm", cab.use_adaln0)
-                q = _mlp2_forward(at.q_block, h).reshape(B, D)
+                q = self._ln_mlp(cab.cross_attn_norm, x, proj, "cross_norm", cab.use_adaln0, at.q_block) \
+                    if FUSE_NORMS else None
+                if q is None:
+                    h = self._norm(cab.cross_attn_norm, x, proj, "cross_norm", cab.use_adaln0)
+                    q = _mlp2_forward(at.q_block, h).reshape(B, D)
                 o_mul = proj["cross_scale"].reshape(B, D) if "cross_scale" in proj else None
                 o = ops.attention_decode(q, None, None, ck, cv, ck.shape[1], at.heads, o_mul=o_mul)
                 x = self._residual(cab.cross_attn_res, o.reshape(B, 1, D), x, proj, "cross_scale",
                                    scaled=True)
             fb = layer.feedforward_block
-            h = self._norm(fb.feedforward_norm, x, proj, "ffn_norm", fb.use_adaln0)
-            h = _mlp2_forward(fb.feedforward, h)
-            x = self._residual(fb.feedforward_res, h, x, proj, "ffn_scale")
+            gate = proj["ffn_scale"] if fb.feedforward_res.use_scale_layer else None
+            h = self._ln_mlp(fb.feedforward_norm, x, proj, "ffn_norm", fb.use_adaln0, fb.feedforward, mul=gate) \
+                if FUSE_NORMS else None
+            if h is not None:
+                x = self._residual(fb.feedforward_res, h.reshape(B, 1, D), x, proj, "ffn_scale", scaled=True)
+            else:
+                h = self._norm(fb.feedforward_norm, x, proj, "ffn_norm", fb.use_adaln0)
+                h = _mlp2_forward(fb.feedforward, h)
+                x = self._residual(fb.feedforward_res, h, x, proj, "ffn_scale")
         return _mlp2_forward(model.classifier, x).reshape(B, -1)
 
     def rows(self, lo, hi):

@@ -413,6 +413,30 @@ def gemm_grouped_skinny(A, W, bias=None, act=0, shared_a=False):
     return C
 
 
+def gemm_skinny_ln(x, W, bias=None, act=0, gamma=None, beta=None, scale=None, shift=None, eps=1e-5, mul=None):
+    """out[g] = act(LN(x) @ W[g].T + bias[g]) [* mul]: the decode step's Linear with the LayerNorm in
+    front of it (affine gamma/beta (K,) or AdaLN scale/shift (M, K); neither: none) and the gate
+    multiply behind it (mul (M, N)) inside the same launch.  x: (M, K); W: (G, N, K) or (N, K);
+    bias: like W without K.  Returns (G, M, N), or (M, N) for a 2-D W."""
+    require_cuda(x, W, bias, gamma, beta, scale, shift, mul)
+    single = W.dim() == 2
+    G, (N, K) = (1 if single else W.shape[0]), W.shape[-2:]
+    M = x.shape[0]
+    assert x.shape == (M, K) and x.is_contiguous() and W.is_contiguous() and x.dtype == W.dtype == torch.float32
+    if bias is not None:
+        assert bias.numel() == G * N and bias.is_contiguous()
+    for t in (gamma, beta):
+        assert t is None or (t.shape == (K,) and t.is_contiguous())
+    for t in (scale, shift):
+        assert t is None or (t.shape == (M, K) and t.is_contiguous())
+    assert mul is None or (mul.shape == (M, N) and mul.is_contiguous() and G == 1)
+    C = torch.empty((G, M, N), dtype=torch.float32, device=x.device)
+    check(_lib.load().qarig_gemm_skinny_ln_f32(
+        ptr(x), K, float(eps), ptr(gamma), ptr(beta), ptr(scale), ptr(shift), K, ptr(W), K, N * K, ptr(C), N,
+        M * N, ptr(bias), N, ptr(mul), N, G, M, N, K, act, stream()), "qarig_gemm_skinny_ln_f32")
+    return C[0] if single else C
+
+
 GEMM_MAX_GROUPS = 16          # csrc/gemm.hip GEMM_MAX_GROUPS
 
 
@@ -814,7 +838,18 @@ def mul_rows_bwd(dy, a, tab, idx):
 ATTENTION_HEAD_DIMS = (4, 8, 16, 32, 64)   # csrc/attention.hip instantiations
 
 
-def attention_fwd(q, k, v, heads, causal):
+def attention_head_dim(d):
+    """The kernel head dim that serves a model head dim d: d itself, or the next instantiated one (the
+    caller zero-pads every head: extra zero columns add nothing to q.k and yield zero output columns),
+    or None above the widest."""
+    for hd in ATTENTION_HEAD_DIMS:
+        if hd >= d:
+            return hd
+    return None
+
+
+def attention_fwd(q, k, v, heads, causal, scale_dim=None):
+    """scale_dim: the model's head dim when the tensors carry zero-padded heads (softmax scale 1/sqrt(scale_dim))."""
     N, Sq, D = q.shape
     Sk = k.shape[1]
     d = D // heads
@@ -822,8 +857,8 @@ def attention_fwd(q, k, v, heads, causal):
     lse = torch.empty((N, heads, Sq), dtype=torch.float32, device=q.device)
     lib = _lib.load()
     fn = lib.qarig_attention_lp_fwd if lp_mode() else lib.qarig_attention_fwd
-    check(fn(ptr(q), ptr(k), ptr(v), N, Sq, Sk, heads, d, int(causal), float(d ** 0.5), ptr(o), ptr(lse),
-             stream()), "qarig_attention_fwd")
+    check(fn(ptr(q), ptr(k), ptr(v), N, Sq, Sk, heads, d, int(causal), float((scale_dim or d) ** 0.5), ptr(o),
+             ptr(lse), stream()), "qarig_attention_fwd")
     return o, lse
 
 
@@ -845,7 +880,7 @@ def attention_decode(q, k_new, v_new, kcache, vcache, length, heads, len_dev=Non
     return o
 
 
-def attention_bwd(q, k, v, o, dO, lse, heads, causal):
+def attention_bwd(q, k, v, o, dO, lse, heads, causal, scale_dim=None):
     N, Sq, D = q.shape
     Sk = k.shape[1]
     d = D // heads
@@ -856,7 +891,7 @@ def attention_bwd(q, k, v, o, dO, lse, heads, causal):
     lib = _lib.load()
     fn = lib.qarig_attention_lp_bwd if lp_mode() else lib.qarig_attention_bwd
     check(fn(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), N, Sq, Sk, heads, d, int(causal),
-             float(d ** 0.5), ptr(dq), ptr(dk), ptr(dv), ptr(delta), stream()), "qarig_attention_bwd")
+             float((scale_dim or d) ** 0.5), ptr(dq), ptr(dk), ptr(dv), ptr(delta), stream()), "qarig_attention_bwd")
     return dq, dk, dv
 
 
@@ -911,6 +946,24 @@ def scale_by(x, s):
 
 
 # -------------------------------------------------------------------------- conv
+def _conv_workspace(weight, nbytes, geom, tag):
+    """(scratch tensor, flags) of a conv forward.  Training: the shared scratch, weights re-ordered in
+    every call.  Inference (no grad: the weights are constants between optimiser steps): one scratch per
+    weight and geometry, kept while the weight is unchanged (address / version / LP_EPOCH, as the bf16
+    shadows), so the re-ordering launch runs once (QARIG_CONV_PACKED_VALID)."""
+    if torch.is_grad_enabled():
+        return workspace(nbytes, weight.device, tag), 0
+    key = (tag, weight.data_ptr(), tuple(weight.shape), weight._version, LP_EPOCH, geom)
+    hit = _lp_get(key, weight)
+    if hit is not None:
+        return hit, 1
+    if torch.cuda.is_current_stream_capturing():      # no allocation inside a capture
+        return workspace(nbytes, weight.device, tag), 0
+    ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=weight.device)
+    _lp_put(key, weight, ws)
+    return ws, 0
+
+
 def conv2d_fwd(x, weight, bias, stride, pad, act, want_preact=False):
     """nn.Conv2d + bias + activation (reference models/layers.py:157-184, 211-230)."""
     require_cuda(x, weight, bias)
@@ -922,9 +975,11 @@ def conv2d_fwd(x, weight, bias, stride, pad, act, want_preact=False):
     y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if want_preact else None
     lib = _lib.load()
-    ws = workspace(lib.qarig_conv2d_fwd_workspace_bytes(Cin, Cout, k), x.device, "convfwd")
+    ws, flags = _conv_workspace(weight, lib.qarig_conv2d_fwd_workspace_bytes_n(N, Cin, H, W, Cout, k),
+                                (N, H, W, stride, pad), "convfwd")
     check(lib.qarig_conv2d_fwd_ws(ptr(x), N, Cin, H, W, ptr(weight), ptr(bias), Cout, k, stride,
-                                  pad, act, ptr(y), ptr(pre), ptr(ws), ws.numel(), stream()), "qarig_conv2d_fwd_ws")
+                                  pad, act, ptr(y), ptr(pre), ptr(ws), ws.numel(), flags, stream()),
+          "qarig_conv2d_fwd_ws")
     return (y, pre) if want_preact else y
 
 
@@ -938,9 +993,10 @@ def conv_transpose2d_fwd(x, weight, bias, act, want_preact=False):
     y = torch.empty((N, Cout, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if want_preact else None
     lib = _lib.load()
-    ws = workspace(lib.qarig_conv_transpose2d_workspace_bytes(Cin, Cout), x.device, "convt")
+    ws, flags = _conv_workspace(weight, lib.qarig_conv_transpose2d_workspace_bytes_n(N, Cin, H, W, Cout),
+                                (N, H, W, bool(want_preact)), "convt")
     check(lib.qarig_conv_transpose2d_fwd(ptr(x), N, Cin, H, W, ptr(weight), ptr(bias), Cout, act,
-                                         ptr(y), ptr(pre), ptr(ws), ws.numel(), stream()),
+                                         ptr(y), ptr(pre), ptr(ws), ws.numel(), flags, stream()),
           "qarig_conv_transpose2d_fwd")
     return (y, pre) if want_preact else y
 

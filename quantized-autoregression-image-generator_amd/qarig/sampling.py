@@ -30,7 +30,11 @@ def _sample(logits, temperature, end_token, mode, rows, comb):
 
 
 def _cacheable(model, hr_input, use_sliding_window):
-    return (hr_input.shape[1] == 1 and hasattr(model, "decoder_layers")
+    # head dims that run zero-padded (QF.attention) keep the full-window loop: the cache kernel takes the
+    # instantiated head dims only
+    from . import ops
+    dims_ok = all(m.head_dim in ops.ATTENTION_HEAD_DIMS for m in model.modules() if hasattr(m, "head_dim"))
+    return (dims_ok and hr_input.shape[1] == 1 and hasattr(model, "decoder_layers")
             and bool(model.use_pos_cond) == bool(use_sliding_window)
             and all(l.self_attn_block.self_attn.use_masked_attn for l in model.decoder_layers))
 

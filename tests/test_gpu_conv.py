@@ -97,7 +97,8 @@ def test_decoder_readme_shape_pixels_vs_oracle_fp64():
 
 @pytest.mark.parametrize("N,Cin,H,W,Cout,stride,act", [
     (2, 3, 16, 16, 8, 1, 1), (1, 16, 9, 13, 20, 1, 0), (2, 8, 16, 16, 16, 2, 1),
-    (1, 32, 8, 8, 3, 1, 2), (2, 130, 12, 10, 140, 1, 1), (1, 4, 7, 9, 12, 2, 3)])
+    (1, 32, 8, 8, 3, 1, 2), (2, 130, 12, 10, 140, 1, 1), (1, 4, 7, 9, 12, 2, 3),
+    (1, 3, 32, 32, 64, 1, 1)])      # input gradient to 3 channels: the direct kernel's channel-split form, flipped taps
 def test_conv2d_bwd(N, Cin, H, W, Cout, stride, act):
     from conftest import grad_err
     from qarig import functional as QF
@@ -362,3 +363,98 @@ def test_conv_transpose2d_input_gradient_ring_vs_fp64(N, Cin, H, W, Cout):
     (yc * dy.cuda()).sum().backward()
     for p, q in zip(c, a):
         assert grad_err(p.grad, q.grad) < 1e-5
+
+
+@pytest.mark.parametrize("kind,N,Cin,H,W,Cout", [
+    ("conv", 1, 64, 16, 16, 128),       # 2 tiles, 36 k-tiles: 2 parts
+    ("conv", 4, 256, 32, 32, 128),      # 32 tiles: 8 parts of 18 k-tiles, parts start inside a tap
+    ("conv", 2, 512, 16, 16, 256),      # 8 tiles: 8 parts of 36
+    ("convt", 4, 256, 16, 16, 128),     # 16 workgroups x 2 column parities, 4 parts of 16 k-tiles
+    ("convt", 1, 512, 32, 32, 256),     # the README upsampling layer at one image: 8 parts
+    ("direct", 4, 256, 64, 64, 3),      # the decoder's last layer: channels split over 8 waves
+    ("direct", 1, 64, 16, 16, 4)])
+def test_few_image_launches_split_the_reduction(kind, N, Cin, H, W, Cout):
+    """At few images (generate_images.py:366 decodes the handful just sampled) the ring launches have too
+    few tiles to fill the chip: the reduction is split over blockIdx.z into slabs that
+    conv_split_reduce_kernel adds in order (+ bias, activation, saved pre-activation); the <= 4-channel
+    output layer splits its channels over the waves of a workgroup.  Against fp64, and against the
+    unsplit launch (a workspace without room for the slabs), which it must match to rounding but not
+    bit for bit (proof that the split form ran)."""
+    from qarig import ops, _lib
+    from qarig._lib import ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(N * 3 + Cin + Cout)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    b = torch.randn(Cout, generator=g)
+    if kind == "convt":
+        w = torch.randn((Cin, Cout, 4, 4), generator=g) / (4 * Cin ** 0.5)
+        ref = torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+        y, pre = ops.conv_transpose2d_fwd(x.cuda(), w.cuda(), b.cuda(), 1, want_preact=True)
+        small, big = (lib.qarig_conv_transpose2d_workspace_bytes(Cin, Cout),
+                      lib.qarig_conv_transpose2d_workspace_bytes_n(N, Cin, H, W, Cout))
+    else:
+        w = torch.randn((Cout, Cin, 3, 3), generator=g) / (3 * Cin ** 0.5)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+        y, pre = ops.conv2d_fwd(x.cuda(), w.cuda(), b.cuda(), 1, 1, 1, want_preact=True)
+        small, big = (lib.qarig_conv2d_fwd_workspace_bytes(Cin, Cout, 3),
+                      lib.qarig_conv2d_fwd_workspace_bytes_n(N, Cin, H, W, Cout, 3))
+    assert rel_err(pre, ref) < 2e-6
+    assert rel_err(y, torch.nn.functional.silu(ref)) < 4e-6
+    if kind == "direct":
+        assert big == small
+        return
+    assert big > small
+    xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+    y1 = torch.empty_like(y)
+    ws = torch.empty(small, dtype=torch.uint8, device="cuda")
+    if kind == "convt":
+        rc = lib.qarig_conv_transpose2d_fwd(ptr(xc), N, Cin, H, W, ptr(wc), ptr(bc), Cout, 1, ptr(y1), None,
+                                            ptr(ws), small, 0, _lib.stream())
+    else:
+        rc = lib.qarig_conv2d_fwd_ws(ptr(xc), N, Cin, H, W, ptr(wc), ptr(bc), Cout, 3, 1, 1, 1, ptr(y1), None,
+                                     ptr(ws), small, 0, _lib.stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and rel_err(y1, y) < 5e-6 and not torch.equal(y1, y)
+
+
+def test_decoder_four_images_readme_shape_vs_oracle_fp64():
+    """The configuration tools/bench_generate.py times (4 latents of 32 x 32 x 4 -> 4 images): every layer of
+    the README decoder takes a few-image launch form; pixels against the fp64 oracle at the 1e-5 target."""
+    from models.FC_Decoder import FC_Decoder
+    from oracle import ref_models as rm
+    torch.manual_seed(5)
+    dec = FC_Decoder(num_layers=2, image_channel=3, min_channel=256, max_channel=512, latent_channel=4)
+    z = torch.tanh(torch.randn((4, 4, 32, 32), generator=torch.Generator().manual_seed(2)))
+    sd64 = {k: v.double() for k, v in dec.state_dict().items()}
+    ref = rm.fc_decoder(sd64, z.double())
+    with torch.no_grad():
+        y = dec.cuda()(z.cuda())
+    assert y.shape == (4, 3, 128, 128) and rel_err(y, ref) < PIX_TOL
+
+
+def test_inference_weight_copies_are_cached_and_follow_the_weights():
+    """Under no_grad the tap-major weight copies are made once per weight and geometry
+    (QARIG_CONV_PACKED_VALID on later calls); an in-place update of the weight (optimizer step,
+    load_state_dict) must be seen by the next call."""
+    from models.FC_Decoder import FC_Decoder
+    from qarig import ops
+    torch.manual_seed(7)
+    dec = FC_Decoder(num_layers=1, image_channel=3, min_channel=128, max_channel=128, latent_channel=4).cuda().eval()
+    z = torch.tanh(torch.randn(2, 4, 16, 16, device="cuda"))
+    with torch.no_grad():
+        y0 = dec(z)
+        n_cached = len(ops._lp_cache)
+        y1 = dec(z)                                  # second call: cached copies
+        assert torch.equal(y0, y1) and len(ops._lp_cache) == n_cached and n_cached > 0
+        assert dec(z[:1]).shape == (1, 3, 32, 32) and len(ops._lp_cache) > n_cached      # another geometry: its own copies
+        for p in dec.parameters():
+            p.mul_(1.5)                              # in place: version bump
+        y2 = dec(z)
+    fresh = FC_Decoder(num_layers=1, image_channel=3, min_channel=128, max_channel=128, latent_channel=4).cuda().eval()
+    fresh.load_state_dict(dec.state_dict())
+    with torch.no_grad():
+        assert torch.equal(fresh(z), y2) and not torch.equal(y2, y0)
+    # training mode (grad enabled) never uses the cache
+    n = len(ops._lp_cache)
+    dec(z).sum().backward()
+    assert len(ops._lp_cache) == n

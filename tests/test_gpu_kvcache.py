@@ -9,10 +9,10 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _model(use_encoder, adaln0=False, heads=8, dim=64, hidden=128, layers=2, vocab=41):
+def _model(use_encoder, adaln0=False, heads=8, dim=64, hidden=128, layers=2, vocab=41, pos_cond=True):
     from models.Transformer import Transformer
     torch.manual_seed(3)
-    kw = dict(use_encoder=use_encoder, use_pos_cond=True, num_enc_layers=2 if use_encoder else None,
+    kw = dict(use_encoder=use_encoder, use_pos_cond=pos_cond, num_enc_layers=2 if use_encoder else None,
               num_dec_layers=layers, num_enc_embedding=vocab if use_encoder else None,
               num_dec_embedding=vocab, self_attn_heads=heads,
               cross_attn_heads=heads if use_encoder else None, transformer_in_dim=dim,
@@ -76,6 +76,83 @@ def test_grouped_skinny_gemm():
         ops.gemm_grouped_skinny(torch.randn(2, 8, 96).cuda(), torch.randn(2, 16, 96).cuda())
 
 
+@pytest.mark.parametrize("M,G,N,K,form,gate", [
+    (4, 1, 2048, 512, "adaln", False), (4, 3, 2048, 512, "adaln", False), (16, 1, 512, 2048, "none", True),
+    (1, 1, 513, 256, "affine", True), (20, 3, 200, 512, "affine", False), (64, 1, 96, 1024, "adaln", True),
+    (100, 2, 48, 256, "adaln", False), (33, 1, 2048, 512, "affine", False), (48, 1, 64, 512, "adaln", True)])
+def test_skinny_gemm_with_layernorm_prologue_and_gate(M, G, N, K, form, gate):
+    """qarig_gemm_skinny_ln_f32: act(LN(x) W_g^T + b_g) * gate in one launch against fp64 -- both
+    LayerNorm forms of the decoder blocks (nn.LayerNorm affine; AdaLN scale(cond) * LN(x) + shift(cond),
+    reference models/layers.py:130-153), every row-tile count of the kernel and the 64-row slabs."""
+    from qarig import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = (torch.randn((M, K), generator=g) * 1.5 + 0.3).cuda()
+    W = (torch.randn((G, N, K), generator=g) * 0.05).cuda()
+    b = torch.randn((G, N), generator=g).cuda()
+    gam, bet = torch.randn(K, generator=g).cuda(), torch.randn(K, generator=g).cuda()
+    sc, sh = torch.randn((M, K), generator=g).cuda(), torch.randn((M, K), generator=g).cuda()
+    mul = torch.randn((M, N), generator=g).cuda() if gate else None
+    kw = {"affine": dict(gamma=gam, beta=bet), "adaln": dict(scale=sc, shift=sh), "none": {}}[form]
+    if G == 1:
+        got = ops.gemm_skinny_ln(x, W[0], b[0], act=1, mul=mul, **kw)[None]
+    else:
+        got = ops.gemm_skinny_ln(x, W, b, act=1, **kw)
+    xd = x.double()
+    h = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-5)
+    if form == "affine":
+        h = h * gam.double() + bet.double()
+    elif form == "adaln":
+        h = sc.double() * h + sh.double()
+    else:
+        h = xd
+    want = torch.nn.functional.silu(torch.einsum("mk,gnk->gmn", h, W.double()) + b.double()[:, None])
+    if gate:
+        want = want * mul.double()
+    assert got.shape == (G, M, N) and rel_err(got, want) < 5e-6
+    # the two-launch form it replaces (same kernels otherwise)
+    from qarig import functional as QF
+    with torch.no_grad():
+        hn = QF.layernorm_affine(x, gam, bet) if form == "affine" else \
+            (QF.layernorm_mod(x, sc, sh) if form == "adaln" else x)
+        two = ops.gemm_grouped_skinny(hn, W, b, act=1, shared_a=True)
+    if gate:
+        two = two * mul
+    assert rel_err(got, two) < 2e-6
+    with pytest.raises(RuntimeError, match="pair"):
+        ops.gemm_skinny_ln(x, W, b, gamma=gam)
+    with pytest.raises(RuntimeError, match="exclusive"):
+        ops.gemm_skinny_ln(x, W, b, gamma=gam, beta=bet, scale=sc, shift=sh)
+
+
+@pytest.mark.parametrize("use_encoder,pos_cond", [(False, True), (True, True), (True, False)])
+def test_decode_step_fused_norm_launches_equal_separate_launches(use_encoder, pos_cond, monkeypatch):
+    """The step with LayerNorm / gate folded into the Linear launches (kvcache.FUSE_NORMS) against the
+    step with the separate launches and against the full-window decoder; AdaLN blocks (pos_cond) and
+    affine LayerNorm blocks."""
+    from qarig import kvcache, _lib
+    m = _model(use_encoder, heads=32, dim=256, hidden=512, pos_cond=pos_cond)
+    B, S = 3, 9
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(0, 41, (B, S), generator=g).cuda()
+    pos = torch.rand(B, S, generator=g).cuda() * 20 if pos_cond else None
+    outs, calls = {}, {}
+    with torch.no_grad():
+        enc = m.encode(torch.randint(0, 41, (B, 7), generator=g).cuda()) if use_encoder else None
+        for fused in (True, False):
+            monkeypatch.setattr(kvcache, "FUSE_NORMS", fused)
+            cache = kvcache.DecodeCache(m, enc, B, S, graph=False)
+            n0 = _lib.N_CALLS
+            outs[fused] = [cache.step(ids[:, t], None if pos is None else pos[:, t], t) for t in range(S)]
+            calls[fused] = _lib.N_CALLS - n0
+        for t in range(S):
+            want = m.decode(ids[:, :t + 1].contiguous(), enc,
+                            None if pos is None else pos[:, :t + 1].contiguous())[:, -1]
+            assert rel_err(outs[True][t], outs[False][t]) < 2e-6, t
+            assert rel_err(outs[True][t], want) < 1e-5, t
+    per_layer = (calls[False] - calls[True]) / (S * len(m.decoder_layers))
+    assert per_layer >= (4 if use_encoder else 3) - (0 if pos_cond else 1)   # the launches that went away
+
+
 def test_attention_decode_rejects_bad_length():
     from qarig import ops
     q = torch.randn(2, 32, device="cuda")
@@ -133,6 +210,24 @@ def test_cached_generation_matches_full_window_loop(use_encoder, num_beam, bw, b
                                              batch_beams=batch_beams, use_kv_cache=cached))
     assert outs[0].shape[1] >= total       # the loop overshoots to 1 + k*beam_width
     assert torch.equal(outs[0], outs[1])
+
+
+def test_generation_with_head_dim_without_a_cache_kernel():
+    """heads=4 on a 48-wide model (head dim 12, served zero-padded by the window kernels): the
+    generation loop keeps the reference's full-window evaluation instead of the cache (whose kernel takes
+    the instantiated head dims) and emits the same tokens whether or not the cache was asked for."""
+    from qarig import sampling
+    m = _model(True, heads=4, dim=48, hidden=96)
+    first = torch.randint(0, 40, (2, 1), generator=torch.Generator().manual_seed(9)).cuda()
+    lr_in = torch.randint(0, 40, (2, 5), generator=torch.Generator().manual_seed(10)).cuda()
+    assert not sampling._cacheable(m, first, True)
+    assert sampling._cacheable(_model(True, heads=4, dim=64, hidden=96), first, True)
+    outs = []
+    for cached in (False, True):
+        torch.manual_seed(5)
+        outs.append(sampling.generate_tokens(m, first, lr_in, 12, 0.05, True, 16, end_token=40,
+                                             mode="generate", use_kv_cache=cached))
+    assert torch.equal(outs[0], outs[1]) and outs[0].shape[1] >= 12
 
 
 def test_cached_train_mode_sampling_matches():

@@ -93,8 +93,13 @@ def test_layernorm_with_skip_adds_both_gradients_of_x(M, D):
 @pytest.mark.parametrize("N,Sq,Sk,H,d,causal", [(2, 12, 12, 4, 8, True), (3, 70, 70, 2, 16, True),
                                                 (2, 256, 256, 8, 8, True), (2, 33, 5, 4, 8, False),
                                                 (1, 130, 130, 2, 64, False), (2, 9, 1, 2, 4, False),
-                                                (1, 64, 200, 3, 32, False)])
+                                                (1, 64, 200, 3, 32, False),
+                                                # head dims without an instantiation run zero-padded on the next one
+                                                (2, 70, 70, 4, 12, True), (1, 40, 90, 3, 24, False),
+                                                (2, 33, 33, 2, 48, True), (2, 20, 20, 5, 2, True),
+                                                (1, 17, 17, 6, 1, False), (1, 50, 50, 2, 60, True)])
 def test_attention_fwd_bwd(N, Sq, Sk, H, d, causal):
+    """The reference's attention takes any heads | in_dim (models/layers.py:433-474)."""
     from qarig import functional as QF
     g = torch.Generator().manual_seed(Sq * 3 + Sk)
     D = H * d
@@ -118,6 +123,26 @@ def test_attention_fwd_bwd(N, Sq, Sk, H, d, causal):
     assert rel_err(o, ref(*a)) < 2e-6
     for x, y in zip(b, a):
         assert rel_err(x.grad, y.grad) < 5e-6
+
+
+def test_attention_layer_any_head_count_that_divides_the_width():
+    """heads=4 on a 48-wide model (head dim 12): the layer builds, trains and matches fp64
+    attention; heads wider than the widest kernel raise with the reason."""
+    from models.layers import AttentionLayer
+    torch.manual_seed(3)
+    lay = AttentionLayer(heads=4, in_dim=48, hidden_dim=64, use_cross_attn=False, use_masked_attn=True).cuda()
+    assert lay.head_dim == 12
+    x = torch.randn(2, 19, 48).cuda().requires_grad_(True)
+    y = lay(x)
+    y.square().sum().backward()
+    # fp64 restatement over the layer's own q/k/v MLP outputs
+    with torch.no_grad():
+        q, k, v = (blk(x.detach()) for blk in (lay.q_block, lay.k_block, lay.v_block))
+    want = _attn_ref64(q.double(), k.double(), v.double(), 4, True)
+    assert rel_err(y, want) < 2e-6
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    with pytest.raises(ValueError, match="head dim 128"):
+        AttentionLayer(heads=2, in_dim=256, hidden_dim=64, use_cross_attn=False)
 
 
 def _attn_ref64(q, k, v, H, causal):

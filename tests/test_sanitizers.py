@@ -95,14 +95,27 @@ for (N, Sq, Sk, H, d, causal) in ((64, 256, 256, 64, 8, 1), (2, 4096, 4096, 64, 
 for (N, Cin, H, W, Cout, k, st) in ((4, 3, 128, 128, 256, 3, 1), (4, 256, 128, 128, 512, 3, 2), (4, 512, 32, 32, 4, 3, 1)):
     call("qarig_conv2d_fwd", X, N, Cin, H, W, X, X, Cout, k, st, 1, 1, X, X, None)
     call("qarig_conv_wgrad", X, N, Cout, H // st, W // st, X, Cin, H, W, k, st, 1, X, X, 1 << 40, None)
-call("qarig_conv_transpose2d_fwd", X, 4, 512, 32, 32, X, X, 256, 1, X, X, X, 1 << 40, None)
+call("qarig_conv_transpose2d_fwd", X, 4, 512, 32, 32, X, X, 256, 1, X, X, X, 1 << 40, 0, None)
 # the ring kernels' launch geometry: 3x3 forward with a scratch buffer, its input gradient, ConvTranspose at a
 # batch of 16, the band form of the Gaussian neighbourhood
 for (N, Cin, H, W, Cout) in ((16, 256, 128, 128, 256), (16, 512, 32, 32, 512), (1, 48, 16, 24, 256), (2, 130, 12, 10, 140)):
-    call("qarig_conv2d_fwd_ws", X, N, Cin, H, W, X, X, Cout, 3, 1, 1, 1, X, X, X, 1 << 40, None)
+    call("qarig_conv2d_fwd_ws", X, N, Cin, H, W, X, X, Cout, 3, 1, 1, 1, X, X, X, 1 << 40, 0, None)
     call("qarig_conv2d_bwd_data", X, N, Cout, H, W, X, Cin, 3, 1, 1, H, W, X, X, 1 << 40, None)
     call("qarig_conv_wgrad", X, N, Cout, H, W, X, Cin, H, W, 3, 1, 1, X, X, 1 << 40, None)
-call("qarig_conv_transpose2d_fwd", X, 16, 256, 64, 64, X, X, 256, 1, X, X, X, 1 << 40, None)
+call("qarig_conv_transpose2d_fwd", X, 16, 256, 64, 64, X, X, 256, 1, X, X, X, 1 << 40, 0, None)
+# few images: split reductions (slabs behind the packed weights), the re-ordering launch skipped
+call("qarig_conv2d_fwd_ws", X, 4, 512, 32, 32, X, X, 512, 3, 1, 1, 1, X, X, X, 1 << 40, 1, None)
+call("qarig_conv2d_fwd_ws", X, 4, 256, 128, 128, X, X, 3, 3, 1, 1, 2, X, None, X, 1 << 40, 0, None)
+assert lib.qarig_conv2d_fwd_workspace_bytes_n(4, 512, 32, 32, 512, 3) == 512 * 512 * 9 * 4 + 4 * 4 * 512 * 1024 * 4
+assert lib.qarig_conv2d_fwd_workspace_bytes_n(16, 512, 32, 32, 512, 3) == 512 * 512 * 9 * 4
+assert lib.qarig_conv_transpose2d_workspace_bytes_n(4, 512, 32, 32, 256) == 16 * 512 * 256 * 4 + 4 * 4 * 256 * 4096 * 4
+# the decode step's fused Linear launches: AdaLN form on 3 stacked weights, affine form, gate multiply
+call("qarig_gemm_skinny_ln_f32", X, 512, 1e-5, None, None, X, X, 512, X, 512, 2048 * 512, X, 2048, 4 * 2048, X, 2048,
+     None, 0, 3, 4, 2048, 512, 1, None)
+call("qarig_gemm_skinny_ln_f32", X, 512, 1e-5, X, X, None, None, 0, X, 512, 0, X, 2048, 0, X, 0, None, 0, 1, 64, 2048,
+     512, 1, None)
+call("qarig_gemm_skinny_ln_f32", X, 2048, 0.0, None, None, None, None, 0, X, 2048, 0, X, 512, 0, X, 0, X, 512, 1, 16,
+     512, 2048, 1, None)
 call("qarig_som_band", X, 8192, 4, 1779.0, 222, X2, None)
 call("qarig_som_band", X, 512, 16, 0.43, 4, X2, None)
 so = lib.qarig_set_option

@@ -85,9 +85,10 @@ def main():
     tot_tokens = sum(N * st["seq"] for st in out["stages"])
     tot_time = sum(st["seconds"] for st in out["stages"])
     with torch.no_grad():
+        img = dec(cbs[args.stages].get_quantized_image(prev))     # first call: re-ordered weight copies are cached
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        reps = 5
+        reps = 20
         for _ in range(reps):
             img = dec(cbs[args.stages].get_quantized_image(prev))
         torch.cuda.synchronize()
