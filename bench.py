@@ -382,6 +382,20 @@ def main():
     if allreduce is not None:
         out["allreduce"] = allreduce
     if rank == 0:
+        if events and os.environ.get("QARIG_GEMM_SHAPES") == "1":
+            # per-shape table of the event pass (stderr): launches, mean us, TFLOP/s, algorithmic HBM bytes and
+            # the time those take at 8 TB/s
+            agg = {}
+            for e in events:
+                if len(e) > 4:
+                    a = agg.setdefault(e[4], [0, 0.0, e[0], e[5]])
+                    a[0] += 1
+                    a[1] += e[1].elapsed_time(e[2])
+            for k, (n, ms, fl, hbm) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                us = ms / n * 1e3
+                print(f"{k:64s} n={n // ev_steps:4d}/step {us:8.1f} us {fl / us / 1e6:7.1f} TF  "
+                      f"{hbm / 1e6:7.1f} MB = {hbm / 8e6:6.1f} us at 8 TB/s  total {ms / ev_steps:6.2f} ms/step",
+                      file=sys.stderr)
         if events:
             times = [(e[0], e[1].elapsed_time(e[2]), e[3] if len(e) > 3 else "") for e in events]
             # dominant kernel = the 128x128-tile GEMM family on the model's (N*S)-row operands;

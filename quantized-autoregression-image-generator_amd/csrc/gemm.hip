@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(SA sa, SB sb, GemmEpi
     const int cl = lane & 31;
 
     if (FAST && vec_epi) {
-        gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, slabs);
+        gemm_epilogue_wide<2>(acc, ep, lds, m0, n0, M, N, splitk, slabs);
         return;
     }
 #pragma unroll
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_pf_kernel(const float* _
     if (do_rs) ep.rowsum[(int64_t)z * M + m0 + tid] = rs;
     __syncthreads();                      // ring no longer in use: the epilogue stages through it
     // (flat grid: blockIdx.z == 0, the slab offset is folded into the pointer)
-    gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, splitk, xcd_splits && slabs ? slabs + (int64_t)z * M * N : slabs);
+    gemm_epilogue_wide<2>(acc, ep, lds, m0, n0, M, N, splitk, xcd_splits && slabs ? slabs + (int64_t)z * M * N : slabs);
 }
 
 // ---------------------------------------------------------------------------------
@@ -317,8 +317,8 @@ __global__ __launch_bounds__(2 * NTHREADS, 1) void gemm_dma_pf2_kernel(const flo
     }
     if (do_rs && team == 0) ep.rowsum[(int64_t)blockIdx.z * M + m0 + tt] = rs + rsx[tt];
     __syncthreads();                      // exchange buffer read: the epilogue stages through it
-    gemm_epilogue_wave(acc, ep, lds2 + wave8 * (32 * 64), m0 + wm * 64, n0 + wn * 64, M, N, splitk, slabs,
-                       team, team + 1);
+    gemm_epilogue_wave<2, Acc, 2>(acc, ep, lds2 + wave8 * (32 * 64), m0 + wm * 64, n0 + wn * 64, M, N, splitk, slabs,
+                                  team, team + 1);
 }
 
 // ---------------------------------------------------------------------------------
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_pf_grouped_kernel(GemmGr
     if (do_rs) rs_part[(int64_t)slab * M + m0 + tid] = rs;
     __syncthreads();                      // ring no longer in use: the epilogue stages through it
     // (1-D grid: blockIdx.z == 0, so the epilogue's slab offset is the one folded into my_slab)
-    gemm_epilogue_wide(acc, ep, lds, m0, n0, M, N, my_slab ? 2 : 1, my_slab);
+    gemm_epilogue_wide<2>(acc, ep, lds, m0, n0, M, N, my_slab ? 2 : 1, my_slab);
 }
 
 // Reduce pass of a grouped launch.  blockIdx.y = output o, whose slabs are [o * nslab, (o + 1) *

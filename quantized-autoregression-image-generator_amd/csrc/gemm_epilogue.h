@@ -3,6 +3,7 @@
 // through a 16-B-wide LDS-staged store path.  Accumulators are the 2x2 32x32 MFMA tiles of a
 // wave's 64x64 sub-tile (the C/D register map is the same for the f32 and bf16 MFMAs).
 #pragma once
+#include <type_traits>
 #include "qarig_common.h"
 
 namespace qarig {
@@ -68,7 +69,10 @@ __device__ __forceinline__ void acc_stage_half(const Acc16& acc, int i, float* s
                 stage[(h * 16 + 4 * (lane >> 4) + r) * 64 + tj * 16 + (lane & 15)] = acc.t[2 * i + h][tj][r];
 }
 
-template <int NJ = 2, class AccT = Acc>
+// PRE: what the epilogue requests from memory BEFORE it stages a half's accumulators (see
+// gemm_epilogue_wave_t): 0 nothing, 1 a bf16 saved pre-activation (16 registers: the 16-wave kernels with
+// 128 registers per lane), 2 also fp32 pre-activations and the residual (64 more: 4-wave kernels).
+template <int NJ = 2, class AccT = Acc, int PRE = 0>
 __device__ __forceinline__ void gemm_epilogue_wave(const AccT& acc, const GemmEpilogue& ep, float* stage,
                                                    int mb, int nb, int M, int N, int splitk,
                                                    float* slabs, int i_begin = 0, int i_end = 2);
@@ -93,38 +97,39 @@ __device__ __forceinline__ float act_grad_t(float x, int act) {
         return sg * (1.0f + x * (1.0f - sg));
     } else return 1.0f;
 }
-template <int NJ, int A, int GA, class AccT>
+template <int NJ, int A, int GA, class AccT, int PRE>
 __device__ __forceinline__ void gemm_epilogue_wave_t(const AccT& acc, const GemmEpilogue& ep, float* stage,
                                                      int mb, int nb, int M, int N, int splitk,
                                                      float* slabs, int i_begin, int i_end);
 
+template <int PRE = 0>
 __device__ __forceinline__ void gemm_epilogue_wide(const Acc& acc, const GemmEpilogue& ep, float* lds,
                                                    int m0, int n0, int M, int N, int splitk,
                                                    float* slabs) {
     const int wave = threadIdx.x >> 6;
     // 4 waves x 32 x 64 floats = 32 KB
-    gemm_epilogue_wave(acc, ep, lds + wave * (32 * 64), m0 + (wave >> 1) * 64, n0 + (wave & 1) * 64, M, N,
-                       splitk, slabs);
+    gemm_epilogue_wave<2, Acc, PRE>(acc, ep, lds + wave * (32 * 64), m0 + (wave >> 1) * 64, n0 + (wave & 1) * 64,
+                                    M, N, splitk, slabs);
 }
 
 // [i_begin, i_end): which 32-row halves of the wave's tile this call stores (wave-uniform; the
 // paired kernel gives each of its two waves per tile one half).
-template <int NJ, class AccT>
+template <int NJ, class AccT, int PRE>
 __device__ __forceinline__ void gemm_epilogue_wave(const AccT& acc, const GemmEpilogue& ep, float* stage,
                                                    int mb, int nb, int M, int N, int splitk,
                                                    float* slabs, int i_begin, int i_end) {
     const bool grad = ep.gradz != nullptr || ep.gradzb != nullptr;
     if (ep.act == ACT_NONE && !grad)
-        gemm_epilogue_wave_t<NJ, ACT_NONE, ACT_NONE, AccT>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
+        gemm_epilogue_wave_t<NJ, ACT_NONE, ACT_NONE, AccT, PRE>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
     else if (ep.act == ACT_SILU && !grad)
-        gemm_epilogue_wave_t<NJ, ACT_SILU, ACT_NONE, AccT>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
+        gemm_epilogue_wave_t<NJ, ACT_SILU, ACT_NONE, AccT, PRE>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
     else if (ep.act == ACT_NONE && ep.gact == ACT_SILU)
-        gemm_epilogue_wave_t<NJ, ACT_NONE, ACT_SILU, AccT>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
+        gemm_epilogue_wave_t<NJ, ACT_NONE, ACT_SILU, AccT, PRE>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
     else
-        gemm_epilogue_wave_t<NJ, ACT_RUNTIME, ACT_RUNTIME, AccT>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
+        gemm_epilogue_wave_t<NJ, ACT_RUNTIME, ACT_RUNTIME, AccT, PRE>(acc, ep, stage, mb, nb, M, N, splitk, slabs, i_begin, i_end);
 }
 
-template <int NJ, int A, int GA, class AccT>
+template <int NJ, int A, int GA, class AccT, int PRE>
 __device__ __forceinline__ void gemm_epilogue_wave_t(const AccT& acc, const GemmEpilogue& ep, float* stage,
                                                      int mb, int nb, int M, int N, int splitk,
                                                      float* slabs, int i_begin, int i_end) {
@@ -138,13 +143,42 @@ __device__ __forceinline__ void gemm_epilogue_wave_t(const AccT& acc, const Gemm
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ep.bias && splitk == 1) bv = *reinterpret_cast<const float4*>(ep.bias + gc);
     const float alpha = ep.alpha_a ? *ep.alpha_a * *ep.alpha_b : 1.0f;
+    // Operands the epilogue READS (the saved pre-activation of the backward fusion, the residual) are
+    // requested before a half's accumulators are staged, all its rows at once: issued inside the row loop
+    // each load waits out its own HBM latency, and a one-workgroup-per-CU kernel has nothing else to run
+    // meanwhile (dH = dY W2 * act'(t1) at 32768 x 2048 x 512 in bf16: 164 us against 109 us for the
+    // forward product of the same shape, which reads nothing here).
+    constexpr int NIT = 4 * NJ;
+    constexpr bool WIDE_PRE = PRE >= 2;
+    const bool ingest = splitk == 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         if (i < i_begin || i >= i_end) continue;
+        uint2 zb[PRE >= 1 ? NIT : 1];
+        float4 zf[WIDE_PRE ? NIT : 1], rf[WIDE_PRE ? NIT : 1];
+        if constexpr (PRE >= 1 && GA != ACT_NONE) {
+            if (ingest && ep.gradzb && !ep.gradz) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    zb[it] = *reinterpret_cast<const uint2*>(
+                        ep.gradzb + (int64_t)(mb + i * 32 + it * (64 / LPR) + er) * ep.ldzb + gc);
+            }
+        }
+        if constexpr (WIDE_PRE) {
+            if (ingest) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int64_t row = mb + i * 32 + it * (64 / LPR) + er;
+                    if (ep.residual) rf[it] = *reinterpret_cast<const float4*>(ep.residual + row * ep.ldr + gc);
+                    if constexpr (GA != ACT_NONE)
+                        if (ep.gradz) zf[it] = *reinterpret_cast<const float4*>(ep.gradz + row * ep.ldz + gc);
+                }
+            }
+        }
         acc_stage_half<NJ>(acc, i, stage, lane);
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 4 * NJ; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int lr = it * (64 / LPR) + er;
             const int64_t row = mb + i * 32 + lr;
             float4 t = *reinterpret_cast<const float4*>(stage + lr * EL + ec);
@@ -155,7 +189,9 @@ __device__ __forceinline__ void gemm_epilogue_wave_t(const AccT& acc, const Gemm
             if (ep.alpha_a) { t.x *= alpha; t.y *= alpha; t.z *= alpha; t.w *= alpha; }
             t.x += bv.x; t.y += bv.y; t.z += bv.z; t.w += bv.w;
             if (ep.residual) {
-                const float4 rv = *reinterpret_cast<const float4*>(ep.residual + row * ep.ldr + gc);
+                float4 rv;
+                if constexpr (WIDE_PRE) rv = rf[it];
+                else rv = *reinterpret_cast<const float4*>(ep.residual + row * ep.ldr + gc);
                 t.x += rv.x; t.y += rv.y; t.z += rv.z; t.w += rv.w;
             }
             if (ep.preact) *reinterpret_cast<float4*>(ep.preact + row * ep.ldp + gc) = t;
@@ -166,15 +202,19 @@ __device__ __forceinline__ void gemm_epilogue_wave_t(const AccT& acc, const Gemm
                                    act_fwd_t<A>(t.z, ep.act), act_fwd_t<A>(t.w, ep.act));
             if constexpr (GA != ACT_NONE) {   // (a gradz with gact = none multiplies by 1)
                 if (ep.gradz) {
-                    const float4 z = *reinterpret_cast<const float4*>(ep.gradz + row * ep.ldz + gc);
+                    float4 z;
+                    if constexpr (WIDE_PRE) z = zf[it];
+                    else z = *reinterpret_cast<const float4*>(ep.gradz + row * ep.ldz + gc);
                     y.x *= act_grad_t<GA>(z.x, ep.gact); y.y *= act_grad_t<GA>(z.y, ep.gact);
                     y.z *= act_grad_t<GA>(z.z, ep.gact); y.w *= act_grad_t<GA>(z.w, ep.gact);
                 } else if (ep.gradzb) {
-                    const uint2 zb = *reinterpret_cast<const uint2*>(ep.gradzb + row * ep.ldzb + gc);
-                    y.x *= act_grad_t<GA>(bf16_bits_to_f32(zb.x & 0xffffu), ep.gact);
-                    y.y *= act_grad_t<GA>(bf16_bits_to_f32(zb.x >> 16), ep.gact);
-                    y.z *= act_grad_t<GA>(bf16_bits_to_f32(zb.y & 0xffffu), ep.gact);
-                    y.w *= act_grad_t<GA>(bf16_bits_to_f32(zb.y >> 16), ep.gact);
+                    uint2 z2;
+                    if constexpr (PRE >= 1) z2 = zb[it];
+                    else z2 = *reinterpret_cast<const uint2*>(ep.gradzb + row * ep.ldzb + gc);
+                    y.x *= act_grad_t<GA>(bf16_bits_to_f32(z2.x & 0xffffu), ep.gact);
+                    y.y *= act_grad_t<GA>(bf16_bits_to_f32(z2.x >> 16), ep.gact);
+                    y.z *= act_grad_t<GA>(bf16_bits_to_f32(z2.y & 0xffffu), ep.gact);
+                    y.w *= act_grad_t<GA>(bf16_bits_to_f32(z2.y >> 16), ep.gact);
                 }
             }
             if (ep.C) *reinterpret_cast<float4*>(ep.C + row * ep.ldc + gc) = y;

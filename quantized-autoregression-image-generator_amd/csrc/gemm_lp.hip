@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_lp_kernel(const bf16_t* __re
         }
     }
     __syncthreads();                      // ring no longer in use: the epilogue stages through it
-    gemm_epilogue_wide(acc, ep, reinterpret_cast<float*>(lds), m0, n0, M, N, splitk, slabs);
+    gemm_epilogue_wide<2>(acc, ep, reinterpret_cast<float*>(lds), m0, n0, M, N, splitk, slabs);
 }
 
 // ---------------------------------------------------------------------------------
@@ -281,8 +281,8 @@ __global__ __launch_bounds__(1024, 1) void gemm_lp_big_kernel(const bf16_t* __re
         }
     }
     __syncthreads();                      // ring idle: 16 x 8 KB of epilogue staging
-    gemm_epilogue_wave(acc, ep, reinterpret_cast<float*>(ldsb) + wave * (32 * 64), m0 + wm * 64, n0 + wn * 64,
-                       M, N, splitk, slabs);
+    gemm_epilogue_wave<2, Acc, 1>(acc, ep, reinterpret_cast<float*>(ldsb) + wave * (32 * 64), m0 + wm * 64,
+                                  n0 + wn * 64, M, N, splitk, slabs);
 }
 
 // The 256 x 256 tile on v_mfma_f32_16x16x32_bf16 (QARIG_LP_MFMA16=1): same bytes, same LDS images,
@@ -371,8 +371,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_lp16_kernel(const bf16_t* __
         }
     }
     __syncthreads();
-    gemm_epilogue_wave(acc, ep, reinterpret_cast<float*>(lds) + wave * (32 * 64), m0 + wm * 64, n0 + wn * 64, M, N,
-                       splitk, slabs);
+    gemm_epilogue_wave<2, Acc16, 2>(acc, ep, reinterpret_cast<float*>(lds) + wave * (32 * 64), m0 + wm * 64,
+                                    n0 + wn * 64, M, N, splitk, slabs);
 }
 
 template <bool TNA, bool TNB>
@@ -436,8 +436,8 @@ __global__ __launch_bounds__(1024, 1) void gemm_lp_big16_kernel(const bf16_t* __
         }
     }
     __syncthreads();
-    gemm_epilogue_wave(acc, ep, reinterpret_cast<float*>(ldsm) + wave * (32 * 64), m0 + wm * 64, n0 + wn * 64,
-                       M, N, splitk, slabs);
+    gemm_epilogue_wave<2, Acc16, 1>(acc, ep, reinterpret_cast<float*>(ldsm) + wave * (32 * 64), m0 + wm * 64,
+                                    n0 + wn * 64, M, N, splitk, slabs);
 }
 
 // ---------------------------------------------------------------------------------
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f8_kernel(const unsigned cha
         }
     }
     __syncthreads();
-    gemm_epilogue_wide(acc, ep, reinterpret_cast<float*>(lds), m0, n0, M, N, 1, nullptr);
+    gemm_epilogue_wide<2>(acc, ep, reinterpret_cast<float*>(lds), m0, n0, M, N, 1, nullptr);
 }
 
 // The e4m3 product on the 256 x 256 tile of gemm_lp_big_kernel (128 bytes deep per k-tile: the

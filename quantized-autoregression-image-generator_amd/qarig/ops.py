@@ -340,7 +340,14 @@ def gemm_lp(A_bf, B_bf, layout, M, N, K, C=None, bias=None, residual=None, preac
     if GEMM_EVENTS is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        GEMM_EVENTS.append((2.0 * M * N * K, ev0, ev1))
+        outs = "+".join(n for n, t in (("C", C), ("P", preact), ("Cb", Cb), ("Pb", Pb)) if t is not None)
+        ins = "".join(n for n, t in (("b", bias), ("r", residual), ("z", gradz)) if t is not None)
+        hbm = 2.0 * (M * K + N * K) + M * N * (4.0 * (C is not None) * (2 if accumulate and splitk == 1 else 1) +
+                                               4.0 * (preact is not None) + 2.0 * (Cb is not None) +
+                                               2.0 * (Pb is not None) + 4.0 * (residual is not None) +
+                                               (0 if gradz is None else gradz.element_size()))
+        GEMM_EVENTS.append((2.0 * M * N * K, ev0, ev1, "",
+                            f"lp {('NT', 'TN', 'NN')[layout]} {M}x{N}x{K} sk{splitk} out {outs} in {ins or '-'} act{act}", hbm))
 
 
 def _gemm_lp(lib, A, B, a_kcontig, b_kcontig, C, pre, M, N, K, bias, residual, act, gradz, gact, splitk,
