@@ -30,13 +30,14 @@ def _sample(logits, temperature, end_token, mode, rows, comb):
 
 
 def _cacheable(model, hr_input, use_sliding_window):
+    if not (hr_input.shape[1] == 1 and hasattr(model, "decoder_layers")
+            and bool(model.use_pos_cond) == bool(use_sliding_window)
+            and all(l.self_attn_block.self_attn.use_masked_attn for l in model.decoder_layers)):
+        return False
     # head dims that run zero-padded (QF.attention) keep the full-window loop: the cache kernel takes the
     # instantiated head dims only
     from . import ops
-    dims_ok = all(m.head_dim in ops.ATTENTION_HEAD_DIMS for m in model.modules() if hasattr(m, "head_dim"))
-    return (dims_ok and hr_input.shape[1] == 1 and hasattr(model, "decoder_layers")
-            and bool(model.use_pos_cond) == bool(use_sliding_window)
-            and all(l.self_attn_block.self_attn.use_masked_attn for l in model.decoder_layers))
+    return all(m.head_dim in ops.ATTENTION_HEAD_DIMS for m in model.modules() if hasattr(m, "head_dim"))
 
 
 def _generate_cached(model, hr_input, enc, total_seq, temperature, use_sliding_window,
