@@ -412,7 +412,8 @@ def main():
             ach = fl / ms / 1e9
             traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-            key = args.config if precision == "f32" else f"{args.config}_{precision}"
+            default_precision = "bf16" if args.config == "c5" else "f32"      # (as profiles/summarize.py names them)
+            key = args.config if precision == default_precision else f"{args.config}_{precision}"
             tj = json.load(open(pmc)).get(key) if os.path.exists(pmc) else None
             if tj:
                 traffic = tj.get("fabric_bytes_per_launch")
