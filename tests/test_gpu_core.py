@@ -208,7 +208,10 @@ def test_bmu_vs_oracle_and_golden(case):
 
 @pytest.mark.parametrize("N,C,H,W,p,K", [(64, 4, 32, 32, 4, 512), (64, 4, 32, 32, 32, 512),
                                          (16, 4, 64, 64, 1, 8192), (64, 4, 32, 32, 2, 512),
-                                         (5, 3, 18, 30, 3, 100)])
+                                         (5, 3, 18, 30, 3, 100),
+                                         # few rows, long patches (the conditional codebook's kernel): chunk counts that
+                                         # are not whole, a patch width that is not a multiple of 4
+                                         (5, 3, 24, 24, 24, 77), (2, 1, 20, 20, 20, 30), (9, 2, 18, 18, 18, 130)])
 def test_bmu_seeded_vs_oracle(N, C, H, W, p, K):
     from qarig import ops
     from oracle import bmu as obmu

@@ -18,6 +18,7 @@ SHAPES = [  # (name, latent shape, patch, K)
     ("c5 HR shard         8192 x 8192 x 4", (2, 4, 64, 64), (1, 1), 8192),
     ("c5 LR shard         2048 x 512 x 16", (2, 4, 64, 64), (2, 2), 512),
     ("patch 4            16384 x 512 x 64", (64, 4, 64, 64), (4, 4), 512),
+    ("conditional LR        64 x 512 x 4096", (64, 4, 32, 32), (32, 32), 512),
 ]
 
 
