@@ -927,51 +927,62 @@ constexpr int FR_LD = FR_CH + 4;   // 16-B aligned rows, lanes of different code
 // of row tile blockIdx.x.  Same e-ascending fma chains: bit-identical values.  111 -> 60 us with the
 // argmin launch while a load instruction gathered 128 B of each of 8 rows, 46 us with one contiguous KB of
 // one row per instruction; the wave still waits on its loads for a good part of its life.
+// Tile: RT_T x RT_T pairs per workgroup of RT_T * RT_T / 64 waves; wave v stages tile rows RT_NQ v ... + RT_NQ - 1
+// of each operand (a row's chunk is 256 elements = one 1-KB load instruction of the wave).  16 x 16 pairs
+// read every row / code chunk once per 16 partners (half the L2 traffic of 8 x 8; the same 45 us: the bound is
+// not traffic either -- 16 waits of ~2.4 us per wave whatever the tile or the chunk).
+constexpr int RT_T = 16;
+constexpr int RT_THREADS = RT_T * RT_T;
+constexpr int RT_CH = 256;
+constexpr int RT_LD = RT_CH + 4;
+constexpr int RT_NQ = RT_T / (RT_THREADS / 64);        // tile rows staged per wave
 template <int ROLE>
 __device__ __forceinline__ void fewrows_role(const PatchGeom& g, const float* __restrict__ w, int K, int code0,
-                                             int row0, float (*xs)[FR_LD], float (*ws)[FR_LD],
+                                             int row0, float (*xs)[RT_LD], float (*ws)[RT_LD],
                                              float* __restrict__ acc_out, float* __restrict__ w2_out,
                                              float* __restrict__ x2_out) {
     constexpr bool NX = ROLE != 1, NW = ROLE != 2;
-    const int tid = threadIdx.x;
-    const int c = tid & 7, r = tid >> 3;
-    static_assert(FR_CH == 256 && FR_NQ == FR_T, "a load instruction = one tile row's 256-element chunk");
-    // load q of a chunk: tile row q (x row row0 + q / code code0 + q), elements 4 * lane ... + 3: 1 KB contiguous per
-    // instruction (patches are whole latents here: element e of a row lies at x_row + e).  Rows / codes past the
-    // end read row / code 0 instead; their results are never stored.
-    const float* wq[FR_NQ];
-    const float* xq[FR_NQ];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = tid % RT_T, r = tid / RT_T;
+    // load q of a chunk: tile row RT_NQ * wave + q (x row row0 + .. / code code0 + ..), elements 4 * lane ... + 3:
+    // 1 KB contiguous per instruction (patches are whole latents here: element e of a row lies at x_row + e).
+    // Rows / codes past the end read row / code 0 instead; their results are never stored.
+    const float* wq[RT_NQ];
+    const float* xq[RT_NQ];
 #pragma unroll
-    for (int q = 0; q < FR_NQ; ++q) {
-        wq[q] = w + (int64_t)(code0 + q < K ? code0 + q : 0) * g.D + 4 * tid;
-        xq[q] = g.x + (row0 + q < g.R ? patch_row_base(g, row0 + q) : 0) + 4 * tid;
+    for (int q = 0; q < RT_NQ; ++q) {
+        const int t = RT_NQ * wave + q;
+        wq[q] = w + (int64_t)(code0 + t < K ? code0 + t : 0) * g.D + 4 * lane;
+        xq[q] = g.x + (row0 + t < g.R ? patch_row_base(g, row0 + t) : 0) + 4 * lane;
     }
-    // (two chunks of loads in flight measured slower: 66 against 46 us)
-    float4 xr[FR_NQ], wr[FR_NQ];
+    // (two chunks of loads in flight measured slower: 66 against 46 us on the 8 x 8 tile)
+    float4 xr[RT_NQ], wr[RT_NQ];
     auto fetch = [&](int e0) {
 #pragma unroll
-        for (int q = 0; q < FR_NQ; ++q) {
+        for (int q = 0; q < RT_NQ; ++q) {
             if constexpr (NX) xr[q] = *reinterpret_cast<const float4*>(xq[q] + e0);
             if constexpr (NW) wr[q] = *reinterpret_cast<const float4*>(wq[q] + e0);
         }
     };
     float acc = 0.0f;
     fetch(0);
-    for (int e0 = 0; e0 < g.D; e0 += FR_CH) {
+    for (int e0 = 0; e0 < g.D; e0 += RT_CH) {
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < FR_NQ; ++q) {
+        for (int q = 0; q < RT_NQ; ++q) {
+            const int t = RT_NQ * wave + q;
             if constexpr (ROLE == 0)            // -2 x: (-2 w) x == w (-2 x) exactly
-                *reinterpret_cast<float4*>(&xs[q][4 * tid]) =
+                *reinterpret_cast<float4*>(&xs[t][4 * lane]) =
                     make_float4(-2.0f * xr[q].x, -2.0f * xr[q].y, -2.0f * xr[q].z, -2.0f * xr[q].w);
-            if constexpr (ROLE == 2) *reinterpret_cast<float4*>(&xs[q][4 * tid]) = xr[q];
-            if constexpr (NW) *reinterpret_cast<float4*>(&ws[q][4 * tid]) = wr[q];
+            if constexpr (ROLE == 2) *reinterpret_cast<float4*>(&xs[t][4 * lane]) = xr[q];
+            if constexpr (NW) *reinterpret_cast<float4*>(&ws[t][4 * lane]) = wr[q];
         }
         __syncthreads();
-        if (e0 + FR_CH < g.D) fetch(e0 + FR_CH);
+        if (e0 + RT_CH < g.D) fetch(e0 + RT_CH);
 #define QARIG_FR_FMAC(ACC, A, B) asm("v_fmac_f32 %0, %1, %2" : "+v"(ACC) : "v"(A), "v"(B))
 #pragma unroll 8
-        for (int e = 0; e < FR_CH; e += 4) {
+        for (int e = 0; e < RT_CH; e += 4) {
             float4 A, B;
             if constexpr (ROLE == 0) { A = *reinterpret_cast<const float4*>(&ws[c][e]); B = *reinterpret_cast<const float4*>(&xs[r][e]); }
             if constexpr (ROLE == 1) { A = *reinterpret_cast<const float4*>(&ws[c][e]); B = A; }
@@ -988,19 +999,20 @@ __device__ __forceinline__ void fewrows_role(const PatchGeom& g, const float* __
     if constexpr (ROLE == 1) { if (r == 0 && code < K) w2_out[code] = acc; }
     if constexpr (ROLE == 2) { if (c == 0 && row < g.R) x2_out[row] = acc; }
 }
-__global__ __launch_bounds__(64) void bmu_fewrows_roles_kernel(PatchGeom g, const float* __restrict__ w, int K,
-                                                               int row_tiles, float* __restrict__ acc_out,
-                                                               float* __restrict__ w2_out,
-                                                               float* __restrict__ x2_out) {
-    __shared__ __attribute__((aligned(16))) float xs[FR_T][FR_LD];
-    __shared__ __attribute__((aligned(16))) float ws[FR_T][FR_LD];
-    const int by = blockIdx.y;                  // wave-uniform
+__global__ __launch_bounds__(RT_THREADS) void bmu_fewrows_roles_kernel(PatchGeom g, const float* __restrict__ w,
+                                                                       int K, int row_tiles,
+                                                                       float* __restrict__ acc_out,
+                                                                       float* __restrict__ w2_out,
+                                                                       float* __restrict__ x2_out) {
+    __shared__ __attribute__((aligned(16))) float xs[RT_T][RT_LD];
+    __shared__ __attribute__((aligned(16))) float ws[RT_T][RT_LD];
+    const int by = blockIdx.y;                  // workgroup-uniform
     if (by < row_tiles)
-        fewrows_role<0>(g, w, K, blockIdx.x * FR_T, by * FR_T, xs, ws, acc_out, w2_out, x2_out);
+        fewrows_role<0>(g, w, K, blockIdx.x * RT_T, by * RT_T, xs, ws, acc_out, w2_out, x2_out);
     else if (by == row_tiles)
-        fewrows_role<1>(g, w, K, blockIdx.x * FR_T, 0, xs, ws, acc_out, w2_out, x2_out);
+        fewrows_role<1>(g, w, K, blockIdx.x * RT_T, 0, xs, ws, acc_out, w2_out, x2_out);
     else if ((int)blockIdx.x < row_tiles)
-        fewrows_role<2>(g, w, K, 0, blockIdx.x * FR_T, xs, ws, acc_out, w2_out, x2_out);
+        fewrows_role<2>(g, w, K, 0, blockIdx.x * RT_T, xs, ws, acc_out, w2_out, x2_out);
 }
 
 // The general form: any D, any patch shape, ragged rows / codes; every lane carries the three chains.
@@ -1637,15 +1649,15 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
         float* acc = (float*)workspace;
         float* w2 = acc + (size_t)g.R * K;
         float* x2 = w2 + K;
-        const bool fast = pW == W && pH == H && (D % FR_CH) == 0 &&
+        const bool fast = pW == W && pH == H && (D % RT_CH) == 0 &&
                           ((((uintptr_t)x) | ((uintptr_t)codebook)) & 15) == 0;
-        const int row_tiles = (g.R + 7) / 8, code_tiles = (K + 7) / 8;
-        // (the |x|^2 role takes the first row_tiles blocks of the last grid row)
-        if (fast && row_tiles <= code_tiles)
-            hipLaunchKernelGGL(bmu_fewrows_roles_kernel, dim3(code_tiles, row_tiles + 2), dim3(64), 0, st, g,
-                               codebook, K, row_tiles, acc, w2, x2);
+        const int rt = (g.R + RT_T - 1) / RT_T, ct = (K + RT_T - 1) / RT_T;
+        // (the |x|^2 role takes the first rt blocks of the last grid row)
+        if (fast && rt <= ct)
+            hipLaunchKernelGGL(bmu_fewrows_roles_kernel, dim3(ct, rt + 2), dim3(RT_THREADS), 0, st, g, codebook, K, rt,
+                               acc, w2, x2);
         else
-            hipLaunchKernelGGL(bmu_fewrows_dot_kernel, dim3(code_tiles, row_tiles), dim3(64), 0, st, g,
+            hipLaunchKernelGGL(bmu_fewrows_dot_kernel, dim3((K + 7) / 8, (g.R + 7) / 8), dim3(64), 0, st, g,
                                codebook, K, acc, w2, x2);
         QARIG_CHECK_LAUNCH("bmu fewrows dot");
         hipLaunchKernelGGL(bmu_fewrows_argmin_kernel, dim3(g.R), dim3(256), 0, st, acc, K, w2, x2, out_idx);
