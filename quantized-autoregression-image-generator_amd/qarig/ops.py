@@ -175,7 +175,13 @@ def gemm(A, B, a_kcontig=True, b_kcontig=True, bias=None, residual=None, want_pr
     if GEMM_EVENTS is not None:
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record()
-        GEMM_EVENTS.append((2.0 * M * N * K * flop_frac, ev0, ev1))
+        outs = "+".join(n for n, t in (("C", C), ("P", pre)) if t is not None)
+        ins = "".join(n for n, t in (("b", bias), ("r", residual), ("z", gradz), ("s", a_rowsum)) if t is not None)
+        hbm = 4.0 * (M * K + N * K + M * N * ((2 if accumulate and splitk == 1 else 1) + (pre is not None) +
+                                              (residual is not None) + (gradz is not None)))
+        GEMM_EVENTS.append((2.0 * M * N * K * flop_frac, ev0, ev1, "",
+                            f"f32 {'N' if a_kcontig else 'T'}{'T' if b_kcontig else 'N'} {M}x{N}x{K} sk{splitk} "
+                            f"out {outs} in {ins or '-'} act{act}{' acc' if accumulate else ''}", hbm))
     return (C, pre) if want_preact else C
 
 
