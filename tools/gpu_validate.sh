@@ -1,7 +1,7 @@
 #!/bin/bash
 # Full validation of a build: every GPU test, the entry-point smoke, the three bench configurations, the
 # generation / decode-step / BMU micro-benchmarks (everything lands in gpurun_out/<tag>_*).
-TAG=${1:-r03t}
+TAG=${1:-val}
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 step() { local t=$1 log=$2; shift 2; timeout -k 10 "$t" "$@" > "$log" 2> "${log%.*}.err"; local rc=$?; echo "[$(basename "$log")] rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi; return $rc; }
