@@ -215,8 +215,13 @@ def _lp_get(key, src):
     return hit[1]
 
 
+_LP_CACHE_MAX = 1024     # entries; a process that keeps meeting new weights / geometries starts over
+
+
 def _lp_put(key, src, value):
     import weakref
+    if len(_lp_cache) >= _LP_CACHE_MAX:
+        _lp_cache.clear()
     _lp_cache[key] = (weakref.ref(src), value)
 
 
