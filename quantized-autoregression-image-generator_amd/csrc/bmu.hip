@@ -907,30 +907,26 @@ __global__ void bmu_direct_kernel(PatchGeom g, const float* __restrict__ w, int 
 // 4096-deep reduction alone (0.59 ms).  The work is tiny (rows*K*D = 134 M fma), so it runs
 // on the vector ALU instead, one (row, code) pair per lane with the SAME k-ordered chains as
 // the MFMA form (an MFMA accumulates in k order with one rounding per fma, so
-// fmaf(-2 w_e, x_e, acc) over ascending e is bit-identical): 8 x 8 pairs per 64-lane workgroup,
-// operands through LDS in 128-element chunks, every lane carrying its own |w|^2 and |x|^2
-// chains (the first pair row / column publishes them).  acc (rows x K), w2 (K) and x2 (rows) go to the workspace; the
-// second kernel takes sqrt(max((acc + w2) + x2, 0)) and the first minimum per row.
-constexpr int FR_CH = 256;    // elements per staged chunk (128 / 256 / 512 measured the same; 1024 halves the resident workgroups)
-constexpr int FR_NQ = FR_CH / 32;   // 16-B loads per lane, operand and chunk
-constexpr int FR_T = 8;       // 8 rows x 8 codes per 64-lane workgroup: 512 workgroups at 64 x 512
-constexpr int FR_LD = FR_CH + 4;   // 16-B aligned rows, lanes of different codes on different banks
-// The aligned case (the conditional codebook itself: whole 32 x 32 x 4 latents as patches): every load is an
-// in-range 16-B load of a contiguous row (pW == W, pH == H, D % FR_CH == 0, 16-B aligned x and codebook).  Counters of the general kernel below at 64 x 512 x 4096 (111 us): its
-// per-element guards make the compiler wait for each of a lane's 256 loads before it issues the next
-// (SQ_WAIT_ANY 177 k of a wave's 315 k cycles), and a lone wave per SIMD issues the three chains' fmacs,
-// their LDS reads and the patch index arithmetic one instruction at a time (110 k cycles of issue).  Here
-// the loads are straight-line (one contiguous KB of one row per instruction), the next chunk's loads are in
-// flight under the current chunk's chain, and the three chains are split over workgroup
-// ROLES so that every wave carries one (5 k instead of 21 k vector instructions per wave):
-// blockIdx.y < row tiles: the (row, code) products; next y: |w|^2 of code tile blockIdx.x; last y: |x|^2
-// of row tile blockIdx.x.  Same e-ascending fma chains: bit-identical values.  111 -> 60 us with the
-// argmin launch while a load instruction gathered 128 B of each of 8 rows, 46 us with one contiguous KB of
-// one row per instruction; the wave still waits on its loads for a good part of its life.
-// Tile: RT_T x RT_T pairs per workgroup of RT_T * RT_T / 64 waves; wave v stages tile rows RT_NQ v ... + RT_NQ - 1
-// of each operand (a row's chunk is 256 elements = one 1-KB load instruction of the wave).  16 x 16 pairs
-// read every row / code chunk once per 16 partners (half the L2 traffic of 8 x 8; the same 45 us: the bound is
-// not traffic either -- 16 waits of ~2.4 us per wave whatever the tile or the chunk).
+// fmaf(-2 w_e, x_e, acc) over ascending e is bit-identical).  acc (rows x K), w2 (K) and x2 (rows) go to
+// the workspace; the second kernel takes sqrt(max((acc + w2) + x2, 0)) and the first minimum per row.
+//
+// Two kernels.  bmu_fewrows_dot_kernel (further down): any geometry; 8 x 8 pairs per 64-lane workgroup,
+// operands through LDS in 128-element chunks, every lane carrying the product chain and its own |w|^2 and
+// |x|^2 chains.  bmu_fewrows_roles_kernel (here): the aligned case -- the conditional codebook itself,
+// whole latents as patches (pW == W, pH == H, D % 256 == 0, 16-B aligned x and codebook).  Counters of the
+// general kernel at 64 x 512 x 4096 (111 us): its per-element guards make the compiler wait for each of a
+// lane's 256 loads before it issues the next (SQ_WAIT_ANY 177 k of a wave's 315 k cycles), and a lone wave
+// per SIMD issues the three chains' fmacs, their LDS reads and the patch index arithmetic one instruction
+// at a time (110 k cycles of issue).  Here the loads are straight-line, one contiguous KB of one row per
+// instruction (gathering 128 B of each of 8 rows per instruction: 60 us instead of 45), the next chunk's
+// loads are in flight under the current chunk's chain, and the three chains are split over workgroup ROLES
+// so that every wave carries one (5 k instead of 21 k vector instructions per wave): blockIdx.y < row
+// tiles: the (row, code) products; next y: |w|^2 of code tile blockIdx.x; last y: |x|^2 of row tile
+// blockIdx.x.  Same e-ascending fma chains: bit-identical values.
+// Tile: RT_T x RT_T pairs per workgroup of RT_T * RT_T / 64 waves; wave v stages tile rows RT_NQ v ... +
+// RT_NQ - 1 of each operand (a row's chunk is 256 elements = one 1-KB load instruction of the wave).
+// 16 x 16 pairs read every row / code chunk once per 16 partners: half the L2 traffic of 8 x 8 at the same
+// 45 us -- a wave still waits ~2.4 us per chunk whatever the tile or the chunk size.
 constexpr int RT_T = 16;
 constexpr int RT_THREADS = RT_T * RT_T;
 constexpr int RT_CH = 256;
@@ -1015,33 +1011,32 @@ __global__ __launch_bounds__(RT_THREADS) void bmu_fewrows_roles_kernel(PatchGeom
         fewrows_role<2>(g, w, K, 0, blockIdx.x * RT_T, xs, ws, acc_out, w2_out, x2_out);
 }
 
-// The general form: any D, any patch shape, ragged rows / codes; every lane carries the three chains.
+// The general form: any D, any patch shape, ragged rows / codes; every lane carries the three chains
+// (128-element chunks, each waited for between two barriers).
+constexpr int FR_CH = 128;    // elements per staged chunk
+constexpr int FR_T = 8;       // 8 rows x 8 codes per 64-lane workgroup: 512 workgroups at 64 x 512
+constexpr int FR_LD = FR_CH + 4;   // 16-B aligned rows, lanes of different codes on different banks
 __global__ __launch_bounds__(64) void bmu_fewrows_dot_kernel(PatchGeom g, const float* __restrict__ w,
                                                              int K, float* __restrict__ acc_out,
                                                              float* __restrict__ w2_out,
                                                              float* __restrict__ x2_out) {
     __shared__ __attribute__((aligned(16))) float xs[FR_T][FR_LD];
-    __shared__ __attribute__((aligned(16))) float xm[FR_T][FR_LD];     // -2 x (exact): (-2 w) x == w (-2 x)
     __shared__ __attribute__((aligned(16))) float ws[FR_T][FR_LD];
     const int tid = threadIdx.x;
     const int c = tid & 7, r = tid >> 3;
     const int code0 = blockIdx.x * FR_T, row0 = blockIdx.y * FR_T;
-    // staging: lane -> (tile row tid >> 3, elements q * 32 + (tid & 7) * 4 ... + 3): 8 lanes read 128 contiguous bytes
-    const int sr = tid >> 3, se = (tid & 7) * 4;
+    // staging: lane -> (tile row tid >> 3, 16 consecutive elements at (tid & 7) * 16)
+    const int sr = tid >> 3, se = (tid & 7) * 16;
     const int srow = row0 + sr, scode = code0 + sr;
     const int64_t rbase = srow < g.R ? patch_row_base(g, srow) : 0;
     const bool xvec = (g.pW & 3) == 0 && (g.W & 3) == 0 && (((uintptr_t)g.x) & 15) == 0;
     const bool wvec = (g.D & 3) == 0 && (((uintptr_t)w) & 15) == 0;
     float acc = 0.0f, w2 = 0.0f, x2 = 0.0f;
-    // The next chunk's 64 + 64 elements per lane are requested before the current chunk is reduced, and a chunk
-    // is long enough to cover them (a workgroup is ONE wave, two per CU: nothing else hides a load; with
-    // 128-element chunks waited for between two barriers the 64 x 512 x 4096 case spent 2 of every 2.7 us in
-    // the wait: 111 us).
-    float4 xr[FR_NQ], wr[FR_NQ];
-    auto fetch = [&](int e0) {
+    for (int e0 = 0; e0 < g.D; e0 += FR_CH) {
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < FR_NQ; ++q) {
-            const int e = e0 + se + q * 32;
+        for (int q = 0; q < 16; q += 4) {
+            const int e = e0 + se + q;
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), wv = xv;
             if (srow < g.R) {
                 if (xvec && e + 3 < g.D) {
@@ -1066,58 +1061,24 @@ __global__ __launch_bounds__(64) void bmu_fewrows_dot_kernel(PatchGeom g, const 
                     wv = make_float4(e < g.D ? wp[0] : 0.f, e + 1 < g.D ? wp[1] : 0.f,
                                      e + 2 < g.D ? wp[2] : 0.f, e + 3 < g.D ? wp[3] : 0.f);
             }
-            xr[q] = xv;
-            wr[q] = wv;
-        }
-    };
-    fetch(0);
-    for (int e0 = 0; e0 < g.D; e0 += FR_CH) {
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < FR_NQ; ++q) {
-            *reinterpret_cast<float4*>(&xs[sr][se + q * 32]) = xr[q];
-            *reinterpret_cast<float4*>(&xm[sr][se + q * 32]) =
-                make_float4(-2.0f * xr[q].x, -2.0f * xr[q].y, -2.0f * xr[q].z, -2.0f * xr[q].w);
-            *reinterpret_cast<float4*>(&ws[sr][se + q * 32]) = wr[q];
+            *reinterpret_cast<float4*>(&xs[sr][se + q]) = xv;
+            *reinterpret_cast<float4*>(&ws[sr][se + q]) = wv;
         }
         __syncthreads();
-        if (e0 + FR_CH < g.D) fetch(e0 + FR_CH);
-        // zero padding past D contributes fmaf(0, -0, acc) = acc and fmaf(0, 0, n2) = n2: exact.
-        // One v_fmac per chain and element, the three chains interleaved (each is a 4096-long dependency):
-        // written as asm because the compiler packs the two norm chains into v_pk_fma_f32 behind v_mov
-        // shuffles and rebuilds -2 w with a v_mul in front of every fma (55 cycles per element; 12 are needed).
-#define QARIG_FR_FMAC(ACC, A, B) asm("v_fmac_f32 %0, %1, %2" : "+v"(ACC) : "v"(A), "v"(B))
-        // LDS reads of the next 32 elements are issued before the fmacs of the current 32 (two register sets):
-        // one wave per SIMD, so nothing else covers the read latency
-        constexpr int U = 8;                     // float4 groups per set
-        float4 xv[2][U], mv[2][U], wv[2][U];
-        auto lds_set = [&](int set, int e) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                xv[set][u] = *reinterpret_cast<const float4*>(&xs[r][e + 4 * u]);
-                mv[set][u] = *reinterpret_cast<const float4*>(&xm[r][e + 4 * u]);
-                wv[set][u] = *reinterpret_cast<const float4*>(&ws[c][e + 4 * u]);
-            }
-        };
-        auto chains = [&](int set) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float4 X = xv[set][u], Mv = mv[set][u], W = wv[set][u];
-                QARIG_FR_FMAC(acc, W.x, Mv.x); QARIG_FR_FMAC(w2, W.x, W.x); QARIG_FR_FMAC(x2, X.x, X.x);
-                QARIG_FR_FMAC(acc, W.y, Mv.y); QARIG_FR_FMAC(w2, W.y, W.y); QARIG_FR_FMAC(x2, X.y, X.y);
-                QARIG_FR_FMAC(acc, W.z, Mv.z); QARIG_FR_FMAC(w2, W.z, W.z); QARIG_FR_FMAC(x2, X.z, X.z);
-                QARIG_FR_FMAC(acc, W.w, Mv.w); QARIG_FR_FMAC(w2, W.w, W.w); QARIG_FR_FMAC(x2, X.w, X.w);
-            }
-        };
-        lds_set(0, 0);
-#pragma unroll 1
-        for (int e = 0; e < FR_CH; e += 8 * U) {
-            lds_set(1, e + 4 * U);
-            chains(0);
-            if (e + 8 * U < FR_CH) lds_set(0, e + 8 * U);
-            chains(1);
+        // zero padding past D contributes fmaf(-0, 0, acc) = acc and fmaf(0, 0, n2) = n2: exact
+#pragma unroll 8
+        for (int e = 0; e < FR_CH; e += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(&xs[r][e]);
+            const float4 wv = *reinterpret_cast<const float4*>(&ws[c][e]);
+            acc = fmaf(-2.0f * wv.x, xv.x, acc);
+            acc = fmaf(-2.0f * wv.y, xv.y, acc);
+            acc = fmaf(-2.0f * wv.z, xv.z, acc);
+            acc = fmaf(-2.0f * wv.w, xv.w, acc);
+            w2 = fmaf(wv.x, wv.x, w2); w2 = fmaf(wv.y, wv.y, w2);
+            w2 = fmaf(wv.z, wv.z, w2); w2 = fmaf(wv.w, wv.w, w2);
+            x2 = fmaf(xv.x, xv.x, x2); x2 = fmaf(xv.y, xv.y, x2);
+            x2 = fmaf(xv.z, xv.z, x2); x2 = fmaf(xv.w, xv.w, x2);
         }
-#undef QARIG_FR_FMAC
     }
     const int row = row0 + r, code = code0 + c;
     if (row < g.R && code < K) acc_out[(int64_t)row * K + code] = acc;
