@@ -15,8 +15,8 @@ from models.FC_Encoder import FC_Encoder  # noqa: E402
 from qarig import ops  # noqa: E402
 
 
-def timeit(fn, reps=5):
-    for _ in range(2):
+def timeit(fn, reps=5, warm=6):
+    for _ in range(warm):     # the first calls of a shape load code objects and fill the inference weight-copy cache
         fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
