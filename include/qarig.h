@@ -363,7 +363,7 @@ size_t qarig_conv2d_fwd_workspace_bytes(int Cin, int Cout, int k);
  * partial sums of a launch whose reduction is split 2-8 ways because its tiles alone would leave CUs
  * idle (<= 256 workgroups): given this much scratch the call splits, given only the size above it
  * does not.  The split changes the summation order (parts added in order after the k-loop). */
-size_t qarig_conv2d_fwd_workspace_bytes_n(int N, int Cin, int H, int W, int Cout, int k);
+size_t qarig_conv2d_fwd_workspace_bytes_n(int N, int Cin, int H, int W, int Cout, int k, int stride);
 /* flags: QARIG_CONV_PACKED_VALID = the head of `workspace` still holds the re-ordered weights an earlier
  * call with the same w, geometry and workspace wrote there (inference: the weights do not change between
  * calls) -- the re-ordering launch is skipped.  0 otherwise. */
@@ -383,6 +383,8 @@ int qarig_conv_transpose2d_fwd(const float* x, int N, int Cin, int H, int W, con
 
 /* autograd of the conv layers (dT = dy * act'(preact), via qarig_act_bwd, first) */
 size_t qarig_conv2d_bwd_data_workspace_bytes(int Cin, int Cout, int k);
+/* ... plus room for the split slabs of a few-image launch (3x3 / stride 1; see qarig_conv2d_fwd_workspace_bytes_n) */
+size_t qarig_conv2d_bwd_data_workspace_bytes_n(int N, int Cin, int H, int W, int Cout, int k, int stride);
 int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, int Wo, const float* w, int Cin,
                           int k, int stride, int pad, int H, int W, float* dx, void* workspace,
                           size_t ws_bytes, void* stream);
@@ -390,6 +392,9 @@ int qarig_conv_transpose2d_bwd_data(const float* dT, int N, int Cout, int H, int
                                     int Cin, float* dx, void* stream);
 /* ... with a scratch buffer (16 * Cin * Cout floats) for tap-major weights: whole-tile layers on the strided ring
  * kernel, every other geometry as above. */
+/* scratch of the _ws form: the tap-major weights (qarig_conv_transpose2d_workspace_bytes) + the split slabs of a
+ * few-image launch */
+size_t qarig_conv_transpose2d_bwd_data_workspace_bytes_n(int N, int Cin, int H, int W, int Cout);
 int qarig_conv_transpose2d_bwd_data_ws(const float* dT, int N, int Cout, int H, int W, const float* w,
                                        int Cin, float* dx, void* workspace, size_t ws_bytes, void* stream);
 /* G (N,Cg,Gh,Gw) correlated with im2col_{k,stride,pad}(X (N,Cx,H,W)) -> dw (Cg, Cx*k*k).

@@ -1339,6 +1339,21 @@ static int conv2d_fwd_impl(const float* x, int N, int Cin, int H, int W, const f
                 QARIG_CHECK_LAUNCH("conv3x3 pack");
             }
             const int tiles_p = (int)(P / BN);
+            const size_t packed_bytes = (size_t)Cout * 9 * Cin * sizeof(float);
+            const int64_t out_elems = (int64_t)N * Cout * Ho * Wo;
+            int splits = conv_ring_splits((long)(Cout / BM) * tiles_p, 9 * Cin / BK);
+            if (splits > 1 && (ws_bytes < packed_bytes + (size_t)splits * out_elems * sizeof(float) ||
+                               (((uintptr_t)y | (uintptr_t)preact) & 15)))
+                splits = 1;
+            if (splits > 1) {
+                float* slabs = (float*)((char*)workspace + packed_bytes);
+                ConvOut raw{slabs, nullptr, nullptr, Cout, Ho, Wo, 1, 0, 0, ACT_NONE};
+                hipLaunchKernelGGL((conv3x3_ring_kernel<false, true>), dim3((Cout / BM) * tiles_p, 1, splits),
+                                   dim3(NTHREADS), 0, st, packed, g, raw, tiles_p, (unsigned)xb, (int64_t)0, 0, splits,
+                                   out_elems);
+                QARIG_CHECK_LAUNCH("conv3x3 stride-2 ring (split)");
+                return launch_conv_split_reduce(slabs, splits, o, N, st);
+            }
             hipLaunchKernelGGL((conv3x3_ring_kernel<false, true>), dim3((Cout / BM) * tiles_p), dim3(NTHREADS), 0, st,
                                packed, g, o, tiles_p, (unsigned)xb, (int64_t)0, 0, 1, (int64_t)0);
             QARIG_CHECK_LAUNCH("conv3x3 stride-2 ring");
@@ -1366,12 +1381,14 @@ static size_t conv_split_slab_bytes(long wgs, int nk, int64_t out_elems) {
     const int s = conv_ring_splits(wgs, nk);
     return s > 1 ? (size_t)s * out_elems * sizeof(float) : 0;
 }
-extern "C" size_t qarig_conv2d_fwd_workspace_bytes_n(int N, int Cin, int H, int W, int Cout, int k) {
+extern "C" size_t qarig_conv2d_fwd_workspace_bytes_n(int N, int Cin, int H, int W, int Cout, int k, int stride) {
     const size_t base = qarig_conv2d_fwd_workspace_bytes(Cin, Cout, k);
     if (!base || N < 1 || H < 1 || W < 1 || !qarig_dims_ok({N, Cout, H, W}, 1LL << 20, 1LL << 31)) return base;
-    if (k != 3 || Cin % 16 || Cout % BM || ((int64_t)N * H * W) % BN) return base;
-    return base + conv_split_slab_bytes((long)(Cout / BM) * ((int64_t)N * H * W / BN), 9 * Cin / BK,
-                                        (int64_t)N * Cout * H * W);
+    if (k != 3 || (stride != 1 && stride != 2) || H % stride || W % stride) return base;
+    const int Ho = H / stride, Wo = W / stride;          // (padding 1: the ring geometries)
+    if (Cin % 16 || Cout % BM || ((int64_t)N * Ho * Wo) % BN) return base;
+    return base + conv_split_slab_bytes((long)(Cout / BM) * ((int64_t)N * Ho * Wo / BN), 9 * Cin / BK,
+                                        (int64_t)N * Cout * Ho * Wo);
 }
 extern "C" int qarig_conv2d_fwd_ws(const float* x, int N, int Cin, int H, int W, const float* w,
                                    const float* bias, int Cout, int k, int stride, int pad, int act,
@@ -1500,6 +1517,15 @@ extern "C" size_t qarig_conv2d_bwd_data_workspace_bytes(int Cin, int Cout, int k
     return (size_t)Cin * Cout * k * k * sizeof(float);
 }
 
+// ... plus room for a few-image launch's split slabs (3x3 / stride 1: the same ring launch as the forward)
+extern "C" size_t qarig_conv2d_bwd_data_workspace_bytes_n(int N, int Cin, int H, int W, int Cout, int k, int stride) {
+    const size_t base = qarig_conv2d_bwd_data_workspace_bytes(Cin, Cout, k);
+    if (!base || N < 1 || H < 1 || W < 1 || !qarig_dims_ok({N, Cin, H, W}, 1LL << 20, 1LL << 31)) return base;
+    if (k != 3 || stride != 1 || Cout % 16 || Cin % BM || ((int64_t)N * H * W) % BN) return base;
+    return base + conv_split_slab_bytes((long)(Cin / BM) * ((int64_t)N * H * W / BN), 9 * Cout / BK,
+                                        (int64_t)N * Cin * H * W);
+}
+
 // d(input) of Conv2d: dT (N,Cout,Ho,Wo) -> dx (N,Cin,H,W).  One stride-1 implicit-GEMM
 // launch per output-parity class of dx (1 class for stride 1, 4 for stride 2), each with
 // exactly the taps that hit it.
@@ -1524,7 +1550,9 @@ extern "C" int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, i
         // dx[ci] = sum_{co, tap} dT[co] at offset (1 - tap) * w[co][ci][tap]: a 3x3 conv over dT with M = Cin,
         // C = Cout and the taps flipped
         ConvOut o{dx, nullptr, nullptr, Cin, H, W, 1, 0, 0, ACT_NONE};
-        return launch_conv3x3_ring(w, 9, (int64_t)Cin * 9, 1, dT, N, Cout, H, W, Cin, o, packed, st);
+        const size_t packed_bytes = qarig_conv2d_bwd_data_workspace_bytes(Cin, Cout, k);
+        return launch_conv3x3_ring(w, 9, (int64_t)Cin * 9, 1, dT, N, Cout, H, W, Cin, o, packed, st,
+                                   (float*)((char*)workspace + packed_bytes), ws_bytes - packed_bytes);
     }
     if (k == 3 && s == 2 && pad == 1 && H == 2 * Ho && W == 2 * Wo && conv3x3_ring_ok(N, Cout, Ho, Wo, Cin, dT, packed) &&
         ((uintptr_t)dx & 7) == 0) {
@@ -1566,6 +1594,14 @@ extern "C" int qarig_conv2d_bwd_data(const float* dT, int N, int Cout, int Ho, i
     return QARIG_OK;
 }
 
+// scratch of qarig_conv_transpose2d_bwd_data_ws: the tap-major weights + a few-image launch's split slabs
+extern "C" size_t qarig_conv_transpose2d_bwd_data_workspace_bytes_n(int N, int Cin, int H, int W, int Cout) {
+    const size_t base = qarig_conv_transpose2d_workspace_bytes(Cin, Cout);
+    if (!base || N < 1 || H < 1 || W < 1 || !qarig_dims_ok({N, Cin, H, W}, 1LL << 20, 1LL << 31)) return base;
+    if (Cout % 16 || Cin % BM || ((int64_t)N * H * W) % BN) return base;
+    return base + conv_split_slab_bytes((long)(Cin / BM) * ((int64_t)N * H * W / BN), Cout, (int64_t)N * Cin * H * W);
+}
+
 // d(input) of ConvTranspose2d(4,2,1): dT (N,Cout,2H,2W) -> dx (N,Cin,H,W) is a
 // Conv2d(k=4, stride 2, pad 1) over dT whose weight matrix [Cin][Cout*16] is the
 // ConvTranspose weight exactly as stored.
@@ -1605,6 +1641,21 @@ static int convt_bwd_data_impl(const float* dT, int N, int Cout, int H, int W, c
                                (int64_t)16, 0, packed, 16);
             QARIG_CHECK_LAUNCH("conv_transpose2d_bwd_data pack");
             const int tiles_p = (int)(P / BN);
+            const size_t packed_bytes = (size_t)16 * Cin * Cout * sizeof(float);
+            const int64_t out_elems = (int64_t)N * Cin * H * W;
+            int splits = conv_ring_splits((long)(Cin / BM) * tiles_p, Cout);         // 16 * Cout / 16 k-tiles
+            if (splits > 1 && (ws_bytes < packed_bytes + (size_t)splits * out_elems * sizeof(float) ||
+                               ((uintptr_t)dx & 15)))
+                splits = 1;
+            if (splits > 1) {
+                float* slabs = (float*)((char*)workspace + packed_bytes);
+                ConvOut raw{slabs, nullptr, nullptr, Cin, H, W, 1, 0, 0, ACT_NONE};
+                hipLaunchKernelGGL((conv3x3_ring_kernel<false, true, false>), dim3((Cin / BM) * tiles_p, 1, splits),
+                                   dim3(NTHREADS), 0, st, packed, g, raw, tiles_p, (unsigned)xb, (int64_t)0, 0, splits,
+                                   out_elems);
+                QARIG_CHECK_LAUNCH("conv_transpose2d_bwd_data ring (split)");
+                return launch_conv_split_reduce(slabs, splits, o, N, st);
+            }
             hipLaunchKernelGGL((conv3x3_ring_kernel<false, true, false>), dim3((Cin / BM) * tiles_p), dim3(NTHREADS), 0,
                                st, packed, g, o, tiles_p, (unsigned)xb, (int64_t)0, 0, 1, (int64_t)0);
             QARIG_CHECK_LAUNCH("conv_transpose2d_bwd_data ring");

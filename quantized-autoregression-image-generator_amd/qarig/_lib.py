@@ -86,12 +86,14 @@ SIGNATURES = {
     "qarig_scale_by": (I, [P, P, P, L, P]),
     "qarig_conv2d_fwd": (I, [P, I, I, I, I, P, P, I, I, I, I, I, P, P, P]),
     "qarig_conv2d_fwd_workspace_bytes": (Z, [I, I, I]),
-    "qarig_conv2d_fwd_workspace_bytes_n": (Z, [I, I, I, I, I, I]),
+    "qarig_conv2d_fwd_workspace_bytes_n": (Z, [I, I, I, I, I, I, I]),
     "qarig_conv2d_fwd_ws": (I, [P, I, I, I, I, P, P, I, I, I, I, I, P, P, P, Z, I, P]),
     "qarig_conv_transpose2d_workspace_bytes": (Z, [I, I]),
     "qarig_conv_transpose2d_workspace_bytes_n": (Z, [I, I, I, I, I]),
     "qarig_conv_transpose2d_fwd": (I, [P, I, I, I, I, P, P, I, I, P, P, P, Z, I, P]),
     "qarig_conv2d_bwd_data_workspace_bytes": (Z, [I, I, I]),
+    "qarig_conv2d_bwd_data_workspace_bytes_n": (Z, [I, I, I, I, I, I, I]),
+    "qarig_conv_transpose2d_bwd_data_workspace_bytes_n": (Z, [I, I, I, I, I]),
     "qarig_conv2d_bwd_data": (I, [P, I, I, I, I, P, I, I, I, I, I, I, P, P, Z, P]),
     "qarig_conv_transpose2d_bwd_data": (I, [P, I, I, I, I, P, I, P, P]),
     "qarig_conv_transpose2d_bwd_data_ws": (I, [P, I, I, I, I, P, I, P, P, Z, P]),

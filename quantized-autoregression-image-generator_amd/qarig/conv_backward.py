@@ -43,7 +43,7 @@ def conv2d_bwd(ctx, dy, x, weight, pre, stride, pad, act, has_bias):
     lib = _lib.load()
     if ctx.needs_input_grad[0]:
         dx = torch.empty_like(x)
-        ws = workspace(lib.qarig_conv2d_bwd_data_workspace_bytes(Cin, Cout, k), x.device, "convbwd")
+        ws = workspace(lib.qarig_conv2d_bwd_data_workspace_bytes_n(N, Cin, H, W, Cout, k, stride), x.device, "convbwd")
         check(lib.qarig_conv2d_bwd_data(ptr(dT), N, Cout, Ho, Wo, ptr(weight), Cin, k, stride, pad, H,
                                         W, ptr(dx), ptr(ws), ws.numel(), stream()),
               "qarig_conv2d_bwd_data")
@@ -64,7 +64,7 @@ def conv_transpose2d_bwd(ctx, dy, x, weight, pre, act, has_bias):
     if ctx.needs_input_grad[0]:
         dx = torch.empty_like(x)
         lib = _lib.load()
-        ws = workspace(lib.qarig_conv_transpose2d_workspace_bytes(Cin, Cout), x.device, "convbwd")
+        ws = workspace(lib.qarig_conv_transpose2d_bwd_data_workspace_bytes_n(N, Cin, H, W, Cout), x.device, "convbwd")
         check(lib.qarig_conv_transpose2d_bwd_data_ws(ptr(dT), N, Cout, H, W, ptr(weight), Cin, ptr(dx), ptr(ws),
                                                      ws.numel(), stream()),
               "qarig_conv_transpose2d_bwd_data_ws")

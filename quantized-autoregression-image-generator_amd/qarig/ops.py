@@ -993,7 +993,7 @@ def conv2d_fwd(x, weight, bias, stride, pad, act, want_preact=False):
     y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if want_preact else None
     lib = _lib.load()
-    ws, flags = _conv_workspace(weight, lib.qarig_conv2d_fwd_workspace_bytes_n(N, Cin, H, W, Cout, k),
+    ws, flags = _conv_workspace(weight, lib.qarig_conv2d_fwd_workspace_bytes_n(N, Cin, H, W, Cout, k, stride),
                                 (N, H, W, stride, pad), "convfwd")
     check(lib.qarig_conv2d_fwd_ws(ptr(x), N, Cin, H, W, ptr(weight), ptr(bias), Cout, k, stride,
                                   pad, act, ptr(y), ptr(pre), ptr(ws), ws.numel(), flags, stream()),

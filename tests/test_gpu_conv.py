@@ -397,7 +397,7 @@ def test_few_image_launches_split_the_reduction(kind, N, Cin, H, W, Cout):
         ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
         y, pre = ops.conv2d_fwd(x.cuda(), w.cuda(), b.cuda(), 1, 1, 1, want_preact=True)
         small, big = (lib.qarig_conv2d_fwd_workspace_bytes(Cin, Cout, 3),
-                      lib.qarig_conv2d_fwd_workspace_bytes_n(N, Cin, H, W, Cout, 3))
+                      lib.qarig_conv2d_fwd_workspace_bytes_n(N, Cin, H, W, Cout, 3, 1))
     assert rel_err(pre, ref) < 2e-6
     assert rel_err(y, torch.nn.functional.silu(ref)) < 4e-6
     if kind == "direct":
@@ -458,3 +458,50 @@ def test_inference_weight_copies_are_cached_and_follow_the_weights():
     n = len(ops._lp_cache)
     dec(z).sum().backward()
     assert len(ops._lp_cache) == n
+
+
+@pytest.mark.parametrize("kind,N,Cin,H,W,Cout", [
+    ("s1", 1, 128, 16, 16, 128),        # input gradient of a 3x3 / stride 1 layer: 2 tiles, split
+    ("s1", 2, 512, 16, 16, 256),
+    ("s2", 2, 128, 32, 32, 256),        # stride-2 forward: 4 tiles of 72 k-tiles
+    ("s2", 1, 256, 32, 32, 128),
+    ("convt", 2, 128, 16, 16, 128),     # ConvTranspose input gradient: 16-tap strided product over dT
+    ("convt", 1, 256, 16, 16, 64)])
+def test_few_image_backward_and_strided_launches_split_the_reduction(kind, N, Cin, H, W, Cout):
+    """The input gradient of the 3x3 / stride 1 layers, the stride-2 forward and the ConvTranspose input gradient
+    take the same k-tile windows on blockIdx.z as the stride-1 forward when their tiles alone leave CUs idle
+    (config 1 trains at batch 4): forward and gradients against fp64 at the tolerances of the unsplit tests, and
+    the scratch-size functions say that a split is planned."""
+    from conftest import grad_err
+    from qarig import functional as QF, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(N * 5 + Cin + Cout)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    if kind == "convt":
+        w = torch.randn((Cin, Cout, 4, 4), generator=g) / (4 * Cin ** 0.5)
+        f64 = lambda a, b, c: torch.nn.functional.conv_transpose2d(a, b, c, stride=2, padding=1)
+        hip = lambda a, b, c: QF.conv_transpose2d_act(a, b, c, 0)
+        assert lib.qarig_conv_transpose2d_bwd_data_workspace_bytes_n(N, Cin, H, W, Cout) > \
+            lib.qarig_conv_transpose2d_workspace_bytes(Cin, Cout)
+    else:
+        st = 2 if kind == "s2" else 1
+        w = torch.randn((Cout, Cin, 3, 3), generator=g) / (3 * Cin ** 0.5)
+        f64 = lambda a, b, c: torch.nn.functional.conv2d(a, b, c, stride=st, padding=1)
+        hip = lambda a, b, c: QF.conv2d_act(a, b, c, st, 1, 0)
+        if kind == "s2":
+            assert lib.qarig_conv2d_fwd_workspace_bytes_n(N, Cin, H, W, Cout, 3, 2) > \
+                lib.qarig_conv2d_fwd_workspace_bytes(Cin, Cout, 3)
+        else:
+            assert lib.qarig_conv2d_bwd_data_workspace_bytes_n(N, Cin, H, W, Cout, 3, 1) > \
+                lib.qarig_conv2d_bwd_data_workspace_bytes(Cin, Cout, 3)
+    b = torch.randn(Cout, generator=g)
+    a = [t.double().requires_grad_(True) for t in (x, w, b)]
+    ya = f64(*a)
+    dy = torch.randn(ya.shape, generator=g)
+    (ya * dy.double()).sum().backward()
+    c = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    yc = hip(*c)
+    assert rel_err(yc, ya) < 4e-6
+    (yc * dy.cuda()).sum().backward()
+    for p_, q_ in zip(c, a):
+        assert grad_err(p_.grad, q_.grad) < 1e-5

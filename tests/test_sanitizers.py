@@ -106,9 +106,16 @@ call("qarig_conv_transpose2d_fwd", X, 16, 256, 64, 64, X, X, 256, 1, X, X, X, 1 
 # few images: split reductions (slabs behind the packed weights), the re-ordering launch skipped
 call("qarig_conv2d_fwd_ws", X, 4, 512, 32, 32, X, X, 512, 3, 1, 1, 1, X, X, X, 1 << 40, 1, None)
 call("qarig_conv2d_fwd_ws", X, 4, 256, 128, 128, X, X, 3, 3, 1, 1, 2, X, None, X, 1 << 40, 0, None)
-assert lib.qarig_conv2d_fwd_workspace_bytes_n(4, 512, 32, 32, 512, 3) == 512 * 512 * 9 * 4 + 4 * 4 * 512 * 1024 * 4
-assert lib.qarig_conv2d_fwd_workspace_bytes_n(16, 512, 32, 32, 512, 3) == 512 * 512 * 9 * 4
+assert lib.qarig_conv2d_fwd_workspace_bytes_n(4, 512, 32, 32, 512, 3, 1) == 512 * 512 * 9 * 4 + 4 * 4 * 512 * 1024 * 4
+assert lib.qarig_conv2d_fwd_workspace_bytes_n(16, 512, 32, 32, 512, 3, 1) == 512 * 512 * 9 * 4
 assert lib.qarig_conv_transpose2d_workspace_bytes_n(4, 512, 32, 32, 256) == 16 * 512 * 256 * 4 + 4 * 4 * 256 * 4096 * 4
+assert lib.qarig_conv2d_bwd_data_workspace_bytes_n(4, 512, 16, 16, 512, 3, 1) > 512 * 512 * 9 * 4
+assert lib.qarig_conv2d_bwd_data_workspace_bytes_n(4, 512, 32, 32, 512, 3, 2) == 512 * 512 * 9 * 4
+assert lib.qarig_conv2d_fwd_workspace_bytes_n(4, 256, 64, 64, 512, 3, 2) > 256 * 512 * 9 * 4
+assert lib.qarig_conv_transpose2d_bwd_data_workspace_bytes_n(4, 512, 16, 16, 256) > 16 * 512 * 256 * 4
+call("qarig_conv2d_bwd_data", X, 4, 512, 16, 16, X, 512, 3, 1, 1, 16, 16, X, X, 1 << 40, None)
+call("qarig_conv2d_fwd_ws", X, 4, 256, 64, 64, X, X, 512, 3, 2, 1, 1, X, None, X, 1 << 40, 0, None)
+call("qarig_conv_transpose2d_bwd_data_ws", X, 4, 256, 16, 16, X, 512, X, X, 1 << 40, None)
 # the decode step's fused Linear launches: AdaLN form on 3 stacked weights, affine form, gate multiply
 call("qarig_gemm_skinny_ln_f32", X, 512, 1e-5, None, None, X, X, 512, X, 512, 2048 * 512, X, 2048, 4 * 2048, X, 2048,
      None, 0, 3, 4, 2048, 512, 1, None)
