@@ -994,7 +994,7 @@ def conv2d_fwd(x, weight, bias, stride, pad, act, want_preact=False):
     pre = torch.empty_like(y) if want_preact else None
     lib = _lib.load()
     ws, flags = _conv_workspace(weight, lib.qarig_conv2d_fwd_workspace_bytes_n(N, Cin, H, W, Cout, k, stride),
-                                (N, H, W, stride, pad), "convfwd")
+                                (N, H, W, stride, pad, x.data_ptr() % 16), "convfwd")   # (alignment picks the kernel family)
     check(lib.qarig_conv2d_fwd_ws(ptr(x), N, Cin, H, W, ptr(weight), ptr(bias), Cout, k, stride,
                                   pad, act, ptr(y), ptr(pre), ptr(ws), ws.numel(), flags, stream()),
           "qarig_conv2d_fwd_ws")
@@ -1012,7 +1012,7 @@ def conv_transpose2d_fwd(x, weight, bias, act, want_preact=False):
     pre = torch.empty_like(y) if want_preact else None
     lib = _lib.load()
     ws, flags = _conv_workspace(weight, lib.qarig_conv_transpose2d_workspace_bytes_n(N, Cin, H, W, Cout),
-                                (N, H, W, bool(want_preact)), "convt")
+                                (N, H, W, bool(want_preact), x.data_ptr() % 16), "convt")
     check(lib.qarig_conv_transpose2d_fwd(ptr(x), N, Cin, H, W, ptr(weight), ptr(bias), Cout, act,
                                          ptr(y), ptr(pre), ptr(ws), ws.numel(), flags, stream()),
           "qarig_conv_transpose2d_fwd")
