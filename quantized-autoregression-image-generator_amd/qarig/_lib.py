@@ -132,8 +132,13 @@ OPTIONS = ("gemm_dma", "gemm_pair", "bmu_cs", "bmu_groups", "bmu_coarse", "attn_
            "lp_mfma16", "convt_pair", "conv_ring", "gemm_xcd_splits")
 
 
+OPTION_EPOCH = 0     # bumped by set_option: cached artefacts whose layout depends on the kernel family carry it in their key
+
+
 def set_option(name, value):
     """Kernel-selection option (include/qarig.h qarig_set_option); returns the previous value."""
+    global OPTION_EPOCH
+    OPTION_EPOCH += 1
     old = load().qarig_set_option(name.encode(), int(value))
     if old == -2 ** 31:
         raise KeyError(f"{name}: {last_error()}")

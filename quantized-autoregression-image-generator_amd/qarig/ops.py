@@ -971,7 +971,7 @@ def _conv_workspace(weight, nbytes, geom, tag):
     shadows), so the re-ordering launch runs once (QARIG_CONV_PACKED_VALID)."""
     if torch.is_grad_enabled():
         return workspace(nbytes, weight.device, tag), 0
-    key = (tag, weight.data_ptr(), tuple(weight.shape), weight._version, LP_EPOCH, geom)
+    key = (tag, weight.data_ptr(), tuple(weight.shape), weight._version, LP_EPOCH, _lib.OPTION_EPOCH, geom)
     hit = _lp_get(key, weight)
     if hit is not None:
         return hit, 1

@@ -454,6 +454,16 @@ def test_inference_weight_copies_are_cached_and_follow_the_weights():
     fresh.load_state_dict(dec.state_dict())
     with torch.no_grad():
         assert torch.equal(fresh(z), y2) and not torch.equal(y2, y0)
+    # a kernel-family switch changes the copies' layout: entries made before it are not served after it
+    from qarig import _lib
+    with torch.no_grad():
+        ya = dec(z)
+        old = _lib.set_option("conv_ring", 0)
+        try:
+            yb = dec(z)                  # gather kernels, their own weight layout
+        finally:
+            _lib.set_option("conv_ring", old)
+        assert rel_err(yb, ya) < 1e-5 and torch.equal(dec(z), ya)
     # training mode (grad enabled) never uses the cache
     n = len(ops._lp_cache)
     dec(z).sum().backward()
