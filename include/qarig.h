@@ -332,10 +332,11 @@ int qarig_mse_fwd(const float* pred, const float* target, int64_t n, float* loss
 
 /* torch.optim.Adam step on a flat buffer -- train_quantized_transformer.py:317-320.
  * dev_step (optional device float[2] = {lr / (1 - beta1^t), sqrt(1 - beta2^t)}) overrides the two
- * per-step scalars (graph replay). */
+ * per-step scalars (graph replay).  shadow_bf16 (optional, n x 2 bytes): the updated parameters rounded to
+ * bf16 from the same pass (the reduced-precision GEMMs' weight operands). */
 int qarig_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
                     float beta2, float eps, float step_size, float bc2_sqrt, float grad_scale,
-                    const float* dev_step, void* stream);
+                    const float* dev_step, void* shadow_bf16, void* stream);
 
 /* elementwise helpers (ResidualLinearLayer gate, models/layers.py:293-295) */
 int qarig_mul_fwd(const float* a, const float* b, float* y, int64_t n, void* stream);

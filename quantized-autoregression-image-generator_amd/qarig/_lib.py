@@ -78,7 +78,7 @@ SIGNATURES = {
     "qarig_cross_entropy_fwd": (I, [P, P, I, I, P, P, P, P, P]),
     "qarig_mse_workspace_bytes": (Z, []),
     "qarig_mse_fwd": (I, [P, P, L, P, P, P, P]),
-    "qarig_adam_step": (I, [P, P, P, P, L, F, F, F, F, F, F, P, P]),
+    "qarig_adam_step": (I, [P, P, P, P, L, F, F, F, F, F, F, P, P, P]),
     "qarig_mul_fwd": (I, [P, P, P, L, P]),
     "qarig_mul_bwd": (I, [P, P, P, P, P, L, P]),
     "qarig_act_fwd": (I, [P, P, L, I, P]),

@@ -11,8 +11,9 @@ up to bf16 rounding of the GEMM operands):
  * the narrow (512-wide) GEMM inputs that other kernels produce in fp32 (LayerNorm output,
    attention output, incoming gradients) are cast once per node; the cast of an incoming gradient
    also yields the bias gradient (column sums ride on the same pass: qarig_cast_colsum);
- * weights keep fp32 masters (Adam is unchanged); ONE bf16 shadow per weight, as stored (N,K), is
-   refreshed once per optimiser step (qarig.ops cache): the forward reads it reduction-contiguous,
+ * weights keep fp32 masters; ONE bf16 shadow per weight, as stored (N,K): a view of the flat bf16 image the
+   Adam kernel writes beside the fp32 update (optim.FlatAdam.flat_shadow; before the first step, and for weights
+   no FlatAdam owns, a cast cached until the next optimiser step): the forward reads it reduction-contiguous,
    the input gradient reduction-major (transposed on the LDS read), so no W^T copy exists;
  * weight gradients are TN products of the row-major bf16 activations as they lie (transposed on
    the LDS read), accumulated in fp32 straight into the parameter's .grad.
@@ -42,6 +43,12 @@ def _shadow(w, transpose=False, pad_rows=0):
         if not torch.cuda.is_current_stream_capturing():
             ops._lp_put(key, w, out)
         return out
+    if not transpose:
+        owner = getattr(w, "_qarig_owner", None)
+        if owner is not None and hasattr(owner, "shadow_of"):
+            v = owner.shadow_of(w)           # written by the optimiser's own pass (optim.FlatAdam)
+            if v is not None:
+                return v
     wd = w.detach()
     wd._qarig_weight = True
     wd._qarig_src = w            # the cache entry is tied to the parameter, not to this temporary

@@ -924,9 +924,11 @@ def cross_entropy_fwd(logits2d, target, want_grad=True):
     return loss, dl
 
 
-def adam_step(p, g, m, v, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale=1.0, dev_step=None):
+def adam_step(p, g, m, v, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale=1.0, dev_step=None, shadow=None):
+    """shadow: optional bf16 tensor of p's numel that receives the updated parameters (reduced precision)."""
+    assert shadow is None or (shadow.dtype == torch.bfloat16 and shadow.numel() == p.numel())
     check(_lib.load().qarig_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), beta1, beta2, eps,
-                                      step_size, bc2_sqrt, grad_scale, ptr(dev_step), stream()),
+                                      step_size, bc2_sqrt, grad_scale, ptr(dev_step), ptr(shadow), stream()),
           "qarig_adam_step")
 
 

@@ -31,11 +31,12 @@ class FlatAdam:
         self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False)
         self.param_groups = [dict(self.defaults, params=list(range(len(self.params))))]
         sizes = [p.numel() for p in self.params]
-        # 16-B aligned slices so every view can be read with float4 loads
+        # 32-B aligned slices: every fp32 view can be read with float4 loads, and the same offsets are 16-B
+        # aligned in the bf16 image of the buffer (flat_shadow: LDS-DMA rows of the reduced-precision GEMMs)
         offs, total = [], 0
         for s in sizes:
             offs.append(total)
-            total += (s + 3) // 4 * 4
+            total += (s + 7) // 8 * 8
         self.offsets, self.total = offs, total
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -147,14 +148,52 @@ class FlatAdam:
         b1, b2 = g["betas"]
         return g["lr"] / (1 - b1 ** step), math.sqrt(1 - b2 ** step)
 
+    # -- reduced precision: the bf16 copies of the weights come out of the Adam pass --------------------
+    def _shadow_buffer(self):
+        """Flat bf16 image of flat_param, written by the Adam kernel of every step while a reduced-precision
+        mode is on (173 per-weight cast launches per step of the config-5 model otherwise)."""
+        if not ops.lp_mode():
+            return None
+        if getattr(self, "flat_shadow", None) is None:
+            self.flat_shadow = torch.empty(self.total, dtype=torch.bfloat16, device=self.flat_param.device)
+            self._shadow_views = {}
+        return self.flat_shadow
+
+    def _shadow_written(self):
+        # the kernel writes through raw pointers: torch's version counters stay where they are, so a later
+        # in-place change of a parameter by anyone else (load_state_dict, a test) shows as a version mismatch
+        self._shadow_versions = [p._version for p in self.params]
+
+    def shadow_of(self, p):
+        """bf16 view of parameter p out of the last Adam pass, or None (no pass yet in this mode, or p was
+        modified since)."""
+        if getattr(self, "_shadow_versions", None) is None or not ops.lp_mode():
+            return None
+        i = self._index.get(id(p)) if hasattr(self, "_index") else None
+        if i is None:
+            self._index = {id(q): k for k, q in enumerate(self.params)}
+            i = self._index.get(id(p))
+        if i is None or self._shadow_versions[i] != p._version:
+            return None
+        v = self._shadow_views.get(i)
+        if v is None:
+            o = self.offsets[i]
+            v = self._shadow_views[i] = self.flat_shadow[o:o + p.numel()].view(p.shape)
+        return v
+
     def step(self, grad_scale=1.0):
         self.step_count += 1
         g = self.param_groups[0]
         b1, b2 = g["betas"]
         step_size, bc2_sqrt = self._step_scalars(self.step_count)
+        shadow = self._shadow_buffer()
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, b1, b2,
-                      g["eps"], step_size, bc2_sqrt, grad_scale)
-        ops.lp_invalidate()      # bf16 weight shadows of the reduced-precision mode are stale now
+                      g["eps"], step_size, bc2_sqrt, grad_scale, shadow=shadow)
+        ops.lp_invalidate()      # cached bf16 / e4m3 copies made from the old weights are stale now
+        if shadow is not None:
+            self._shadow_written()
+        else:
+            self._shadow_versions = None     # (a step outside the mode leaves the bf16 image behind)
 
     # -- graph replay (qarig.pipeline.GraphedTrainStep) -----------------------------------
     def _dev_step_buffer(self):
@@ -168,9 +207,14 @@ class FlatAdam:
         host before every replay (learning-rate changes included)."""
         g = self.param_groups[0]
         b1, b2 = g["betas"]
+        shadow = self._shadow_buffer()
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, b1, b2,
-                      g["eps"], 0.0, 1.0, grad_scale, dev_step=self._dev_step_buffer())
+                      g["eps"], 0.0, 1.0, grad_scale, dev_step=self._dev_step_buffer(), shadow=shadow)
         ops.lp_invalidate()
+        if shadow is not None:
+            self._shadow_written()
+        else:
+            self._shadow_versions = None
 
     def advance_captured(self):
         """Called before every replay of a captured step: the replayed Adam kernel rewrites the

@@ -391,3 +391,43 @@ def test_weight_shadows_follow_captured_graph_replays(bf16_mode):
         outs.append(got)
     assert step.graph is not None
     assert not torch.equal(outs[-1], outs[-2])      # the replays did move the weights
+
+
+def test_adam_pass_writes_the_bf16_weight_image(bf16_mode):
+    """In a reduced-precision mode the Adam kernel leaves the updated parameters rounded to bf16 in one flat image
+    (FlatAdam.flat_shadow); the Linear nodes read their weights from it instead of casting every weight after
+    every step.  The image equals round-to-nearest-even of the fp32 masters bit for bit; a parameter somebody
+    else modifies in place, and a step taken outside the mode, fall back to the cast of the current weights."""
+    from qarig import ops, functional_lp, _lib
+    from qarig.optim import FlatAdam
+    torch.manual_seed(2)
+    lin = [torch.nn.Linear(256, 512), torch.nn.Linear(512, 129), torch.nn.Linear(129, 256)]    # a ragged bias in the middle
+    m = torch.nn.Sequential(*lin).cuda()
+    opt = FlatAdam(m.parameters(), lr=1e-2, betas=(0.5, 0.999))
+    ps = list(m.parameters())
+    assert all(o % 8 == 0 for o in opt.offsets)
+    assert opt.shadow_of(ps[0]) is None                              # no pass yet
+    for p in ps:
+        p.grad.copy_(torch.randn_like(p))
+    opt.step()
+    for p in ps:
+        v = opt.shadow_of(p)
+        assert v is not None and v.dtype == torch.bfloat16 and v.shape == p.shape and v.data_ptr() % 16 == 0
+        assert torch.equal(v, p.detach().to(torch.bfloat16))
+    w = ps[0]
+    n0 = _lib.N_CALLS
+    sh = functional_lp._shadow(w)
+    assert sh.data_ptr() == opt.shadow_of(w).data_ptr() and _lib.N_CALLS == n0        # no cast launch
+    with torch.no_grad():
+        w.mul_(2.0)                                                  # somebody else's in-place change
+    assert opt.shadow_of(w) is None
+    assert torch.equal(functional_lp._shadow(w), w.detach().to(torch.bfloat16))
+    opt.step()                                                       # the next pass serves it again
+    assert torch.equal(opt.shadow_of(w), w.detach().to(torch.bfloat16))
+    ops.set_precision("f32")
+    try:
+        opt.step()
+    finally:
+        ops.set_precision("bf16")
+    assert opt.shadow_of(w) is None                                  # image left behind by an fp32 step
+    assert torch.equal(functional_lp._shadow(w), w.detach().to(torch.bfloat16))
