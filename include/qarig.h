@@ -191,6 +191,25 @@ int qarig_gemm_skinny_ln_f32(const float* X, int64_t ldx, float eps, const float
                              const float* mul, int64_t ldmul, int groups, int M, int N, int K,
                              int act, void* stream);
 
+/* The Linear of a single-token decode step (generate_images.py:283-286 evaluates the decoder per
+ * sampled token; with a key/value cache only the new row of each sequence is computed):
+ *   C_g = act(LN(X_g) W_g^T + bias_g + residual) * mul        M <= 16 rows, `groups` products.
+ * A weight-streaming kernel whose loads are all issued before its first wait (the step is a chain
+ * of ~80 dependent launches, each bound by its memory round trips, not by bytes).  LN over K:
+ * nn.LayerNorm's affine form (gamma, beta: K) or AdaLN's scale(cond) * LN(x) + shift(cond)
+ * (scale, shift rows at ldmod, models/layers.py:130-153; ldmod == 0: ONE row for every activation
+ * row -- the rows of a decode step share their window position); residual (M, N): the skip input
+ * of ResidualLinearLayer (models/layers.py:291-304); mul (M, N) at ldmul (0: one row): its
+ * x * scale(cond) gate applied by the producer.  X_g = X + g * x_gs (0 shares X).
+ * qarig_decode_linear_supported: M <= 16 and K in {256, 512, 1024} (2048, 4096 when ln == 0). */
+int qarig_decode_linear_supported(int M, int N, int K, int ln);
+int qarig_decode_linear_f32(const float* X, int64_t ldx, int64_t x_gs, float eps,
+                            const float* gamma, const float* beta, const float* scale,
+                            const float* shift, int64_t ldmod, const float* W, int64_t ldw,
+                            int64_t w_gs, const float* bias, int64_t bias_gs, const float* residual,
+                            int64_t ldr, const float* mul, int64_t ldmul, float* C, int64_t ldc,
+                            int64_t c_gs, int groups, int M, int N, int K, int act, void* stream);
+
 /* out[N] = column sums of X[M][N] in a fixed order (bias / LayerNorm-affine grads). */
 size_t qarig_colsum_workspace_bytes(int M, int N);
 int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,

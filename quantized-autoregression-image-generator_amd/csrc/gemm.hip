@@ -767,6 +767,10 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     if (M <= SKINNY_MAX_ROWS && a_kcontig && b_kcontig && K % 256 == 0 && !accumulate && !a_rowsum &&
         al16(A) && al16(B) && lda % 4 == 0 && ldb % 4 == 0) {
+        if (g_qarig_opt.decode_stream && !preact && !gradz && qarig_decode_linear_supported(M, N, K, 0) && lda >= K &&
+            ldb >= K && ldc >= N && (!residual || ldr >= N))
+            return qarig_decode_linear_f32(A, lda, 0, 0.0f, nullptr, nullptr, nullptr, nullptr, 0, B, ldb, 0, bias, 0,
+                                           residual, ldr, nullptr, 0, C, ldc, 0, 1, M, N, K, act, stream);
         GemmEpilogue eps{C, ldc, bias, residual, ldr, preact, ldp, act, gradz, ldz, gact, nullptr};
         launch_skinny(A, lda, B, ldb, eps, M, N, K, 0, 0, 0, 0, 1, st);
         QARIG_CHECK_LAUNCH("gemm skinny");
@@ -1055,6 +1059,9 @@ extern "C" int qarig_gemm_grouped_skinny_f32(const float* A, int64_t lda, int64_
     QARIG_CHECK_ARG((((uintptr_t)A | (uintptr_t)W) & 15) == 0 && lda % 4 == 0 && ldw % 4 == 0 &&
                         a_gs % 4 == 0 && w_gs % 4 == 0,
                     "gemm_grouped_skinny: operands must be 16-B aligned");
+    if (g_qarig_opt.decode_stream && qarig_decode_linear_supported(M, N, K, 0) && lda >= K && ldw >= K && ldc >= N)
+        return qarig_decode_linear_f32(A, lda, a_gs, 0.0f, nullptr, nullptr, nullptr, nullptr, 0, W, ldw, w_gs, bias,
+                                       bias_gs, nullptr, 0, nullptr, 0, C, ldc, c_gs, groups, M, N, K, act, stream);
     GemmEpilogue eps{C, ldc, bias, nullptr, 0, nullptr, 0, act, nullptr, 0, 0, nullptr};
     launch_skinny(A, lda, W, ldw, eps, M, N, K, a_gs, w_gs, c_gs, bias_gs, groups, (hipStream_t)stream);
     QARIG_CHECK_LAUNCH("gemm_grouped_skinny");
@@ -1085,6 +1092,10 @@ extern "C" int qarig_gemm_skinny_ln_f32(const float* X, int64_t ldx, float eps, 
                         (!scale || ldmod % 4 == 0),
                     "gemm_skinny_ln: operands must be 16-B aligned");
     QARIG_CHECK_ARG(!(gamma || scale) || eps > 0.0f, "gemm_skinny_ln: eps must be positive");
+    if (g_qarig_opt.decode_stream && qarig_decode_linear_supported(M, N, K, (gamma || scale) ? 1 : 0) && ldx >= K &&
+        ldw >= K && ldc >= N && (!mul || ldmul == 0 || ldmul >= N) && (!scale || ldmod == 0 || ldmod >= K))
+        return qarig_decode_linear_f32(X, ldx, 0, eps, gamma, beta, scale, shift, ldmod, W, ldw, w_gs, bias, bias_gs,
+                                       nullptr, 0, mul, ldmul, C, ldc, c_gs, groups, M, N, K, act, stream);
     GemmEpilogue eps_{C, ldc, bias, nullptr, 0, nullptr, 0, act, nullptr, 0, 0, nullptr};
     SkinnyFuse fz{gamma, beta, scale, shift, ldmod, eps, mul, ldmul};
     launch_skinny(X, ldx, W, ldw, eps_, M, N, K, 0, w_gs, c_gs, bias_gs, groups, (hipStream_t)stream, fz);

@@ -17,6 +17,16 @@
 
 extern "C" void qarig_set_error(const char* fmt, ...);
 
+// csrc/decode.hip (include/qarig.h): the weight-streaming Linear of a single-token decode step; the
+// skinny entry points of gemm.hip hand their <= 16-row calls to it.
+extern "C" int qarig_decode_linear_supported(int M, int N, int K, int ln);
+extern "C" int qarig_decode_linear_f32(const float* X, int64_t ldx, int64_t x_gs, float eps, const float* gamma,
+                                       const float* beta, const float* scale, const float* shift, int64_t ldmod,
+                                       const float* W, int64_t ldw, int64_t w_gs, const float* bias, int64_t bias_gs,
+                                       const float* residual, int64_t ldr, const float* mul, int64_t ldmul, float* C,
+                                       int64_t ldc, int64_t c_gs, int groups, int M, int N, int K, int act,
+                                       void* stream);
+
 // Kernel-selection options (qarig_set_option): every one only chooses between kernels that must give
 // the same results; -1 / 0 = the library's own choice where stated.  Defined in capi.hip.
 struct QarigOptions {
@@ -31,6 +41,7 @@ struct QarigOptions {
     int lp_big = -1;       // reduced precision, 256 x 256 tiles: -1 auto (>= 224 tiles), 0 / 1
     int lp_mfma16 = 1;     // reduced precision, v_mfma_f32_16x16x32_bf16 (1) or 32x32x16 (0)
     int convt_pair = 1;    // ConvTranspose parity classes paired per workgroup where a class is < 512 workgroups
+    int decode_stream = 1; // decode-step Linear layers of <= 16 rows on decode_linear_kernel (1) or gemm_skinny_kernel (0)
     int conv_ring = 1;     // 0: every convolution on the gather (im2col-in-registers) kernels, none on the LDS-DMA ring
 };
 extern QarigOptions g_qarig_opt;

@@ -74,6 +74,9 @@ SIGNATURES = {
     "qarig_attention_decode": (I, [P, P, P, P, P, I, I, I, I, P, I, L, F, P, P, P]),
     "qarig_gemm_grouped_skinny_f32": (I, [P, L, L, P, L, L, P, L, L, P, L, I, I, I, I, I, P]),
     "qarig_gemm_skinny_ln_f32": (I, [P, L, F, P, P, P, P, L, P, L, L, P, L, L, P, L, P, L, I, I, I, I, I, P]),
+    "qarig_decode_linear_supported": (I, [I, I, I, I]),
+    "qarig_decode_linear_f32": (I, [P, L, L, F, P, P, P, P, L, P, L, L, P, L, P, L, P, L, P, L, L, I, I, I, I, I,
+                                    P]),
     "qarig_attention_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P, P, P, P, P]),
     "qarig_cross_entropy_fwd": (I, [P, P, I, I, P, P, P, P, P]),
     "qarig_mse_workspace_bytes": (Z, []),

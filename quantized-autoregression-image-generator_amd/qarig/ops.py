@@ -455,6 +455,50 @@ def gemm_skinny_ln(x, W, bias=None, act=0, gamma=None, beta=None, scale=None, sh
     return C[0] if single else C
 
 
+def decode_linear_supported(M, N, K, ln=False):
+    return bool(_lib.load().qarig_decode_linear_supported(int(M), int(N), int(K), int(bool(ln))))
+
+
+def decode_linear(x, W, bias=None, act=0, gamma=None, beta=None, scale=None, shift=None, eps=1e-5,
+                  residual=None, mul=None, out=None):
+    """out[g] = act(LN(x[g]) @ W[g].T + bias[g] + residual) * mul -- the Linear of a single-token decode
+    step on the weight-streaming kernel (csrc/decode.hip; M <= 16 rows).  x: (M, K) shared by the
+    groups, or (G, M, K); W: (G, N, K) or (N, K); bias like W without K.  LN: gamma/beta (K,), or
+    scale/shift (M, K) rows or ONE (K,) row for every activation row.  residual (M, N) (one group);
+    mul (M, N) or (N,).  Returns (G, M, N), or (M, N) for a 2-D W."""
+    require_cuda(x, W, bias, gamma, beta, scale, shift, residual, mul)
+    single = W.dim() == 2
+    G, (N, K) = (1 if single else W.shape[0]), W.shape[-2:]
+    if x.dim() == 3:
+        assert x.shape[0] == G
+        M, x_gs = x.shape[1], x.shape[1] * K
+    else:
+        M, x_gs = x.shape[0], 0
+    assert x.shape[-1] == K and x.is_contiguous() and W.is_contiguous() and x.dtype == W.dtype == torch.float32
+    if bias is not None:
+        assert bias.numel() == G * N and bias.is_contiguous()
+    for t in (gamma, beta):
+        assert t is None or (t.shape == (K,) and t.is_contiguous())
+    ldmod = 0
+    for t in (scale, shift):
+        assert t is None or (t.shape in ((M, K), (K,)) and t.is_contiguous())
+    if scale is not None:
+        assert scale.shape == shift.shape
+        ldmod = K if scale.dim() == 2 else 0
+    assert residual is None or (residual.shape == (M, N) and residual.is_contiguous() and G == 1)
+    ldmul = 0
+    if mul is not None:
+        assert mul.shape in ((M, N), (N,)) and mul.is_contiguous()
+        ldmul = N if mul.dim() == 2 else 0
+    C = out if out is not None else torch.empty((G, M, N), dtype=torch.float32, device=x.device)
+    assert C.numel() == G * M * N and C.is_contiguous() and C.dtype == torch.float32
+    check(_lib.load().qarig_decode_linear_f32(
+        ptr(x), K, x_gs, float(eps), ptr(gamma), ptr(beta), ptr(scale), ptr(shift), ldmod, ptr(W), K, N * K,
+        ptr(bias), N, ptr(residual), N, ptr(mul), ldmul, ptr(C), N, M * N, G, M, N, K, act, stream()),
+        "qarig_decode_linear_f32")
+    return C.view(M, N) if single else C.view(G, M, N)
+
+
 GEMM_MAX_GROUPS = 16          # csrc/gemm.hip GEMM_MAX_GROUPS
 
 

@@ -22,12 +22,16 @@ def main():
     ap.add_argument("--rows", type=int, default=4)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--base", action="store_true", help="decoder-only base stage")
+    ap.add_argument("--opt", action="append", default=[], help="name=value kernel-selection option (qarig_set_option)")
     args = ap.parse_args()
+    for o in args.opt:
+        k, v = o.split("=")
+        _lib.load().qarig_set_option(k.encode(), int(v))
     dev = torch.device("cuda", 0)
     torch.manual_seed(1)
     K, B, S = 512, args.rows, 256
     model = build_stage_model(0 if args.base else 2, K, dev)
-    out = {"rows": B, "window": S, "stage": "base" if args.base else "encoder-decoder", "steps": args.steps}
+    out = {"rows": B, "window": S, "options": args.opt, "stage": "base" if args.base else "encoder-decoder", "steps": args.steps}
     with torch.no_grad():
         enc = None if args.base else model.encode(torch.randint(0, K, (B, 64), device=dev))
         ids = torch.randint(0, K, (B,), device=dev)
