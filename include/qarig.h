@@ -210,6 +210,69 @@ int qarig_decode_linear_f32(const float* X, int64_t ldx, int64_t x_gs, float eps
                             int64_t ldr, const float* mul, int64_t ldmul, float* C, int64_t ldc,
                             int64_t c_gs, int groups, int M, int N, int K, int act, void* stream);
 
+/* ---- Device-resident sampling loop (generate_images.py:256-345) ------------------------------
+ * The reference samples a token, appends it on the host and re-runs the decoder.  Here the loop's
+ * state stays on the device and the host only enqueues launches, never reading a token back: `ctl` is an int32 array
+ * of QARIG_DECODE_CTL_WORDS words -- [0] window index of the token the next step evaluates,
+ * [1] window index at which the current chunk of beam_width tokens starts, [2] draws made so far
+ * (row of the uniform / forced / log buffers), [3] candidate chunks evaluated at this position,
+ * [4] decoder steps since the candidate began (the chunk slot the next draw fills). */
+#define QARIG_DECODE_CTL_WORDS 8
+
+/* First launch of a step: x[b] = table[ids[b]] + pe[len] (models/Transformer.py:154-167; pe may be
+ * NULL), len = ctl[0] (ctl NULL: the `len` argument), and the copy of row `len` of proj_table
+ * (max_len rows of proj_row_floats floats: every ScaleLayer / ShiftLayer projection of `cond` --
+ * models/layers.py:100-153, 258-304 -- evaluated once per window position of the stage) into
+ * proj_row.  With ctl it also counts the step: ctl[4] += 1.  An id outside [0, V) sets *bad_flag and
+ * yields a zero row. */
+int qarig_decode_embed(const int64_t* ids, int B, int D, int V, const float* table, const float* pe,
+                       int* ctl, int len, int max_len, const float* proj_table,
+                       int64_t proj_row_floats, float* x, float* proj_row, int* bad_flag, void* stream);
+
+/* qarig_attention_decode with the cache layout given by strides -- row j of head h of sequence n at
+ * n * batch_stride + h * head_stride + j * row_stride: row-major (head_stride = d, row_stride = H * d) or
+ * head-major (row_stride = d, head_stride >= max_len * d: a head's keys contiguous, what the kernel's
+ * lane-per-key loads coalesce on) -- and the o_mul factor at row stride ldmul (0: one row for every
+ * sequence). */
+int qarig_decode_attention(const float* q, const float* k_new, const float* v_new, float* kcache,
+                           float* vcache, int B, int H, int d, int len, const int* len_dev,
+                           int max_len, int64_t batch_stride, int64_t head_stride, int64_t row_stride,
+                           float sqrt_d, const float* o_mul, int64_t ldmul, float* o, void* stream);
+
+/* One sampling draw per row as generate_images.py:289-304 makes it (train_quantized_transformer.py:
+ * 626-636 with generate_mode == 0): probs = softmax(logits / temperature), generate mode zeroes
+ * probs[end_token], a token is drawn in proportion to probs by inverse CDF from uniforms[draw][b]
+ * (draw = ctl[2] + slot; slot == -1: the slot the device counts, ctl[4]; the reference's
+ * torch.multinomial consumes its generator differently: same distribution, not the same stream), comb[b] *= probs[token], train mode maps <end> to 0,
+ * token + shift goes to ids[b] and chunk[b][slot]; inc_len != 0 advances ctl[0].  forced (optional):
+ * entries >= 0 are taken instead of drawing; probs_log (optional, (max_draws, B, V)): the rows
+ * sampled from. */
+int qarig_decode_sample(const float* logits, int64_t ldl, int B, int V, float temperature,
+                        int end_token, int generate_mode, int64_t shift, const float* uniforms,
+                        const int64_t* forced, int* ctl, int slot, int beam_width, int max_draws,
+                        int inc_len, int64_t* ids, int64_t* chunk, float* comb, float* probs_log,
+                        void* stream);
+
+/* After a candidate chunk: per image the beam with the largest product (first on ties) replaces the
+ * kept chunk unless the kept product is >= (generate_images.py:325-337); take[n] = 1 + that beam or
+ * 0; comb is reset to 1, ctl: candidate + 1, draws + beam_width, len back to the chunk start. */
+int qarig_decode_decide(int* ctl, int N, int NB, int beam_width, float* comb, const int64_t* chunk,
+                        float* best_p, int64_t* best_chunk, int* take, void* stream);
+
+/* Cache rows [ctl[1], ctl[1] + R) of the head-major kv (layers2 = layers * 2, N * NB, H, max_len, d):
+ * restore == 0 copies the winning beam's rows of the images with take[n] > 0 into staged
+ * (layers2, N, H, R, d); restore == 1 writes the staged rows into every beam of every image. */
+int qarig_decode_rows(const int* ctl, float* kv, float* staged, const int* take, int layers2, int N,
+                      int NB, int H, int R, int d, int max_len, int restore, void* stream);
+
+/* tokens[n][ctl[1] + j] = best_chunk[n][j]; ids of every beam = the chunk's last token;
+ * ctl[0] = ctl[1] + beam_width - 1 (the step that follows produces the next chunk's first logits). */
+int qarig_decode_commit(int* ctl, int N, int NB, int beam_width, const int64_t* best_chunk,
+                        int64_t* tokens, int64_t ldt, int64_t* ids, void* stream);
+
+/* ctl[1] += beam_width; ctl[0] = ctl[1]; ctl[3] = 0. */
+int qarig_decode_advance(int* ctl, int beam_width, void* stream);
+
 /* out[N] = column sums of X[M][N] in a fixed order (bias / LayerNorm-affine grads). */
 size_t qarig_colsum_workspace_bytes(int M, int N);
 int qarig_colsum_f32(const float* X, int64_t ldx, int M, int N, float* out, int accumulate,

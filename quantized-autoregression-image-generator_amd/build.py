@@ -16,6 +16,12 @@ LIB = os.path.join(HERE, "lib", "libqarig_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
+# per-file additions.  decode.hip: the decode step's launches are bound by dependent memory round trips;
+# with the first 16 dwords of the kernel arguments preloaded into SGPRs by the command processor their first
+# loads do not wait for a scalar-cache miss on the argument segment (the kernels list what they need first).
+FILE_FLAGS = {"decode.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
+if os.environ.get("QARIG_NO_KERNARG_PRELOAD") == "1":       # ablation builds (tools/)
+    FILE_FLAGS = {}
 
 
 def _newer(a, b):
@@ -34,7 +40,7 @@ def build_lib(verbose=True, force=False):
         obj = os.path.join(OBJ, s[:-4] + ".o")
         objs.append(obj)
         if force or _newer(src, obj) or (os.path.exists(obj) and hdr_time > os.path.getmtime(obj)):
-            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([HIPCC, *FLAGS, *FILE_FLAGS.get(s, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -611,86 +611,6 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_kernel(
 }
 
 
-// Single-query decode step against a key/value cache (generation with a KV cache: one new
-// token per sequence).  One wave per (sequence, head): lanes own keys j = lane, lane+64, ...
-// with a private online softmax, merged across the wave at the end.  When k_new/v_new are
-// given they are appended to the cache at row `len` and attended as the last key, so the
-// caller needs no separate cache-append launch.  `len` may come from device memory
-// (len_dev) so that a captured hipGraph of the whole decode step can be replayed as the
-// sequence grows.
-template <int HD>
-__global__ __launch_bounds__(64) void attn_decode_kernel(
-    const float* __restrict__ q, const float* __restrict__ k_new, const float* __restrict__ v_new,
-    float* __restrict__ kc, float* __restrict__ vc, int64_t bstride, int H, int len_arg,
-    const int* __restrict__ len_dev, int max_len, float c2, const float* __restrict__ o_mul,
-    float* __restrict__ o) {
-    const int h = blockIdx.x % H, n = blockIdx.x / H;
-    const int D = H * HD;
-    const int lane = threadIdx.x;
-    int L = len_dev ? *len_dev : len_arg;
-    const bool app = k_new != nullptr;
-    L = min(max(L, 0), app ? max_len - 1 : max_len);
-    const int Sk = L + (app ? 1 : 0);
-    const int64_t row = (int64_t)n * D + h * HD;
-    float* kb = kc + (int64_t)n * bstride + h * HD;
-    float* vb = vc + (int64_t)n * bstride + h * HD;
-    if (app && lane < HD) {
-        kb[(int64_t)L * D + lane] = k_new[row + lane];
-        vb[(int64_t)L * D + lane] = v_new[row + lane];
-    }
-    float qv[HD], ov[HD];
-#pragma unroll
-    for (int c = 0; c < HD; ++c) {
-        qv[c] = q[row + c];
-        ov[c] = 0.0f;
-    }
-    float m = -INFINITY, l = 0.0f;
-    // U rows per lane are fetched back to back (the step is latency bound), then folded
-    // into the running softmax in key order
-    constexpr int U = HD <= 16 ? 4 : 2;
-    for (int j0 = lane; j0 < Sk; j0 += 64 * U) {
-        float kk[U][HD], vv[U][HD];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + 64 * u;
-            const bool in = j < Sk;
-            const bool fresh = app && j == L;   // the new row comes from its source, not the cache
-            const float* kr = fresh ? k_new + row : kb + (int64_t)(in ? j : 0) * D;
-            const float* vr = fresh ? v_new + row : vb + (int64_t)(in ? j : 0) * D;
-#pragma unroll
-            for (int c = 0; c < HD; c += 4) {
-                const float4 a = *reinterpret_cast<const float4*>(kr + c);
-                const float4 b = *reinterpret_cast<const float4*>(vr + c);
-                kk[u][c] = a.x; kk[u][c + 1] = a.y; kk[u][c + 2] = a.z; kk[u][c + 3] = a.w;
-                vv[u][c] = b.x; vv[u][c + 1] = b.y; vv[u][c + 2] = b.z; vv[u][c + 3] = b.w;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (j0 + 64 * u >= Sk) break;
-            float dot = 0.0f;
-#pragma unroll
-            for (int c = 0; c < HD; ++c) dot = fmaf(qv[c], kk[u][c], dot);
-            const float t = dot * c2;
-            const float mn = fmaxf(m, t);
-            const float alpha = exp2_fast(m - mn);
-            const float p = exp2_fast(t - mn);
-            l = l * alpha + p;
-#pragma unroll
-            for (int c = 0; c < HD; ++c) ov[c] = fmaf(p, vv[u][c], ov[c] * alpha);
-            m = mn;
-        }
-    }
-    const float M = wave_max(m);
-    const float sc = m == -INFINITY ? 0.0f : exp2_fast(m - M);
-    l = wave_sum(l * sc);
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int c = 0; c < HD; ++c) {
-        const float t = wave_sum(ov[c] * sc);
-        if (lane == 0) o[row + c] = o_mul ? (t * inv) * o_mul[row + c] : t * inv;
-    }
-}
 }  // namespace qarig
 
 using namespace qarig;
@@ -864,22 +784,7 @@ extern "C" int qarig_attention_decode(const float* q, const float* k_new, const 
                                       float* kcache, float* vcache, int B, int H, int d, int len,
                                       const int* len_dev, int max_len, int64_t batch_stride,
                                       float sqrt_d, const float* o_mul, float* o, void* stream) {
-    QARIG_CHECK_ARG(q && kcache && vcache && o, "attention_decode: null pointer");
-    QARIG_CHECK_ARG((k_new == nullptr) == (v_new == nullptr),
-                    "attention_decode: k_new and v_new go together");
-    QARIG_CHECK_ARG(B > 0 && H > 0 && d > 0 && max_len > 0, "attention_decode: bad extents");
-    QARIG_CHECK_DIMS("attention_decode", B, H, max_len);
-    QARIG_CHECK_ARG(d <= 64 && (long long)B * H < (1LL << 31), "attention_decode: bad extents");
-    QARIG_CHECK_ARG(batch_stride >= (int64_t)max_len * H * d,
-                    "attention_decode: batch_stride smaller than max_len rows");
-    if (!len_dev) {
-        QARIG_CHECK_ARG(len >= 0 && (k_new ? len < max_len : (len > 0 && len <= max_len)),
-                        "attention_decode: len out of range for the cache");
-    }
-    const float c2 = 1.4426950408889634f / sqrt_d;
-    QARIG_HD_DISPATCH(d, hipLaunchKernelGGL((attn_decode_kernel<HD>), dim3(B * H), dim3(64), 0,
-                                            (hipStream_t)stream, q, k_new, v_new, kcache, vcache,
-                                            batch_stride, H, len, len_dev, max_len, c2, o_mul, o));
-    QARIG_CHECK_LAUNCH("attention_decode");
-    return QARIG_OK;
+    // the decode step's kernels live in decode.hip; this entry keeps o_mul as one row per sequence
+    return qarig_decode_attention(q, k_new, v_new, kcache, vcache, B, H, d, len, len_dev, max_len, batch_stride, d,
+                                  (int64_t)H * d, sqrt_d, o_mul, (int64_t)H * d, o, stream);
 }

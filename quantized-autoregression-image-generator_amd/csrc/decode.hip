@@ -16,25 +16,30 @@
 
 namespace qarig {
 
+// The operands a launch needs to issue its loads come first, as individual kernel arguments: the first 16
+// dwords of the kernel-argument segment are preloaded into SGPRs by the command processor
+// (-mllvm -amdgpu-kernarg-preload-count=16 in build.py for this file), so the first loads do not wait for a
+// scalar-cache miss on the argument segment the host has just written.  The rest travels as a struct.
 struct DecLin {
-    const float* X; int64_t ldx, x_gs;       // activations (M, K); group stride (0: shared by the groups)
-    const float* W; int64_t ldw, w_gs;       // weights (N, K) per group, reduction-contiguous
     const float* bias; int64_t bias_gs;      // (N) per group, or null
     float* C; int64_t ldc, c_gs;             // out (M, N) per group
     const float* residual; int64_t ldr;      // (M, N) added before the activation, or null
     const float* mul; int64_t ldmul;         // (M, N) elementwise factor on the output, or null; ldmul 0: one row
     const float* gamma; const float* beta;   // LN = 1: nn.LayerNorm affine form (K)
-    const float* scale; const float* shift;  // LN = 2: AdaLN rows (M, K) at ldmod; ldmod 0: one row for all
+    const float* scale; const float* shift;  // LN = 2: AdaLN rows (M, K) at ldmod; LN = 3: one row for all
     int64_t ldmod;
     float eps;
-    int M, N, K, act;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 ld4_nt(const float* p) {
+#ifdef QARIG_DECODE_NO_NT       // ablation build (tools/): weights through the default cache policy
+    return ld4(p);
+#else
     typedef float v4 __attribute__((ext_vector_type(4)));
     const v4 r = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
     return make_float4(r.x, r.y, r.z, r.w);
+#endif
 }
 
 template <int CTRL>
@@ -100,7 +105,9 @@ __device__ __forceinline__ int wave_sum_multi(float (&v)[V], int lane, bool& own
 //            thread t sits in row group t / kq at float4 t % kq; a column is summed over kq/64 waves;
 //   KS  > 1: kq = 256 KS; passes j = c KS + s cover chunk s of row c; a column is summed over all 4 waves.
 template <int MR, int LN, int J, int KS>
-__global__ __launch_bounds__(256) void decode_linear_kernel(DecLin p) {
+__global__ __launch_bounds__(256) void decode_linear_kernel(const float* __restrict__ Xb, const float* __restrict__ Wb,
+                                                            int64_t ldx, int64_t ldw, int M, int N, int K, int act,
+                                                            int64_t x_gs, int64_t w_gs, DecLin p) {
     static_assert(J % KS == 0 && (LN == 0 || KS == 1) && LN >= 0 && LN <= 3, "");
     constexpr int NC = J / KS;          // distinct columns per thread
     constexpr int V = NC * MR;          // partial sums per thread
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256) void decode_linear_kernel(DecLin p) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int g = blockIdx.y;
     // kq = K/4 is a power of two (host-checked): shifts instead of integer divisions
-    const int kqs = KS == 1 ? 31 - __builtin_clz(p.K >> 2) : 8;     // log2 kq (KS > 1: of the 256-float4 chunk)
+    const int kqs = KS == 1 ? 31 - __builtin_clz(K >> 2) : 8;     // log2 kq (KS > 1: of the 256-float4 chunk)
     const int cgs = KS == 1 ? 8 - kqs : 0;                          // log2 CG, CG = 256 / kq row groups per pass
     const int WS = 4 >> cgs;                                        // waves that share a column
     const int cg = KS == 1 ? t >> kqs : 0;                          // wave-uniform
@@ -117,20 +124,20 @@ __global__ __launch_bounds__(256) void decode_linear_kernel(DecLin p) {
     constexpr int ncs = NC == 1 ? 0 : (NC == 2 ? 1 : 2);
     const int cws = ncs + cgs;                                      // log2 CW, CW = NC * CG columns of this workgroup
     const int n0 = blockIdx.x << cws;
-    const float* X = p.X + (int64_t)g * p.x_gs;
-    const float* W = p.W + (int64_t)g * p.w_gs;
+    const float* X = Xb + (int64_t)g * x_gs;
+    const float* W = Wb + (int64_t)g * w_gs;
 
     // ---- every load of the launch, oldest first in the order they are needed.  No load sits behind a
     //      branch (the compiler waits for a conditional load where its value meets the alternative):
     //      rows / columns past the end re-read the last one, absent operands read X; what they produce
     //      is never stored.
-    const int Ml = p.M - 1, Nl = p.N - 1;
+    const int Ml = M - 1, Nl = N - 1;
     float4 xv[KS][MR];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int m = 0; m < MR; ++m)
-            xv[s][m] = ld4(X + (int64_t)min(m, Ml) * p.ldx + 4 * (kc + 256 * s));
+            xv[s][m] = ld4(X + (int64_t)min(m, Ml) * ldx + 4 * (kc + 256 * s));
     float4 lg, lb, ls[LN == 2 ? MR : 1], lh[LN == 2 ? MR : 1];
     if (LN == 1 || LN == 3) {
         lg = ld4((LN == 1 ? p.gamma : p.scale) + 4 * kc);
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256) void decode_linear_kernel(DecLin p) {
     // the output this thread will finish: row t / CW, column t % CW
     const int om = t >> cws, ocl = t & ((1 << cws) - 1);
     const int on = n0 + ocl;
-    const bool oval = om < p.M && on < p.N;
+    const bool oval = om < M && on < N;
     const int omc = min(om, Ml), onc = min(on, Nl);
     const float eb = *(p.bias ? p.bias + (int64_t)g * p.bias_gs + onc : X);
     const float er = *(p.residual ? p.residual + (int64_t)omc * p.ldr + onc : X);
@@ -156,14 +163,14 @@ __global__ __launch_bounds__(256) void decode_linear_kernel(DecLin p) {
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int c = j / KS, s = j % KS;
-        wv[j] = ld4_nt(W + (int64_t)min(n0 + (c << cgs) + cg, Nl) * p.ldw + 4 * (kc + 256 * s));
+        wv[j] = ld4_nt(W + (int64_t)min(n0 + (c << cgs) + cg, Nl) * ldw + 4 * (kc + 256 * s));
     }
     __builtin_amdgcn_sched_barrier(0);      // nothing that waits for a load moves in front of the last issue
 
     // ---- LayerNorm of the rows on the way in (two passes: mean, then centred squares --
     //      layernorm_fwd_kernel's form); the weights are still in flight
     if (LN) {
-        const float invK = 1.0f / (float)p.K;       // K is a power of two here: exact
+        const float invK = 1.0f / (float)K;       // K is a power of two here: exact
         float s1[MR];
 #pragma unroll
         for (int m = 0; m < MR; ++m) s1[m] = (xv[0][m].x + xv[0][m].y) + (xv[0][m].z + xv[0][m].w);
@@ -235,12 +242,379 @@ __global__ __launch_bounds__(256) void decode_linear_kernel(DecLin p) {
         for (int i = 1; i < WS; ++i) v += red[ocg * WS + i][c * MR + om];
         if (p.bias) v += eb;
         if (p.residual) v += er;
-        v = p.act == ACT_SILU ? v * sigmoid_f(v) : act_fwd(v, p.act);
+        v = act == ACT_SILU ? v * sigmoid_f(v) : act_fwd(v, act);
         if (p.mul) v *= em;
         p.C[(int64_t)g * p.c_gs + (int64_t)om * p.ldc + on] = v;
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident state of the sampling loop (generate_images.py:256-345): the host replays captured
+// graphs and never reads a token back between them.  int32 control words:
+enum DecCtl : int {
+    CTL_LEN = 0,     // window index of the token the next decoder step evaluates
+    CTL_CUR = 1,     // window index at which the current chunk of beam_width tokens starts
+    CTL_DRAW = 2,    // sampling draws made so far (row of the uniform / forced-token / probability-log buffers)
+    CTL_CAND = 3,    // candidate chunks of the current chunk position evaluated so far
+    CTL_TOK = 4,     // decoder steps since the candidate began = the chunk slot the next draw fills
+    CTL_WORDS = 8
+};
+
+// First launch of a step: x[b] = table[ids[b]] + pe[len] (Transformer.py:154-167: embedding + the
+// sinusoid of the window index) and, when the stage keeps a per-position table of every projection of
+// `cond` (ScaleLayer / ShiftLayer of all layers, models/layers.py:100-153, 258-304: cond depends on
+// the token's position alone and the positions of a stage are known before its loop), the copy of
+// this position's row of it into the buffer the step's launches read.
+__global__ __launch_bounds__(256) void decode_embed_kernel(const int64_t* __restrict__ ids, int B, int D, int V,
+                                                           const float* __restrict__ table,
+                                                           const float* __restrict__ pe, int* __restrict__ ctl,
+                                                           int len_arg, int max_len,
+                                                           const float* __restrict__ proj_table, int64_t PD,
+                                                           float* __restrict__ x, float* __restrict__ proj_row,
+                                                           int* __restrict__ bad) {
+    int L = ctl ? ctl[CTL_LEN] : len_arg;
+    L = min(max(L, 0), max_len - 1);
+    const int64_t nx = (int64_t)B * D / 4, total = nx + PD / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        if (i < nx) {
+            const int b = (int)(i / (D / 4)), c = (int)(i - (int64_t)b * (D / 4)) * 4;
+            const int64_t id = ids[b];
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (id < 0 || id >= V) {
+                if (c == 0) atomicExch(bad, 1);
+            } else {
+                t = ld4(table + id * D + c);
+                if (pe) {
+                    const float4 q = ld4(pe + (int64_t)L * D + c);
+                    t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+                }
+            }
+            *reinterpret_cast<float4*>(x + (int64_t)b * D + c) = t;
+        } else {
+            const int64_t j = (i - nx) * 4;
+            *reinterpret_cast<float4*>(proj_row + j) = ld4(proj_table + (int64_t)L * PD + j);
+        }
+    }
+    // a step has begun: the draw behind it fills the next slot of the chunk (no workgroup of this launch reads it)
+    if (ctl && blockIdx.x == 0 && threadIdx.x == 0) ctl[CTL_TOK] += 1;
+}
+
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+template <int CTRL> __device__ __forceinline__ float dpp_max_step(float x) { return fmaxf(x, dpp_lane<CTRL>(x)); }
+__device__ __forceinline__ float wave_max_dpp(float x) {
+    x = dpp_max_step<0x140>(x); x = dpp_max_step<0x141>(x); x = dpp_max_step<0x4E>(x); x = dpp_max_step<0xB1>(x);
+    x = fmaxf(x, __shfl_xor(x, 16, 64));
+    return fmaxf(x, __shfl_xor(x, 32, 64));
+}
+
+// One query row per sequence against its cached keys / values: a wave per (sequence, head), the four
+// waves of a workgroup on four adjacent heads (they read the same 128-B lines at head dim 8), a lane
+// per key.  Rows are loaded without waiting for the length word (rows past it hold finite data -- the
+// cache is zero-initialised -- and are masked afterwards); the running softmax of a lane's keys is
+// combined over the wave with one DPP maximum and one multi-value sum.
+template <int HD>
+__global__ __launch_bounds__(256) void decode_attention_kernel(
+    const float* __restrict__ q, const float* __restrict__ k_new, const float* __restrict__ v_new,
+    float* __restrict__ kc, float* __restrict__ vc, int64_t bstride, int64_t hstride, int64_t rstride, int H,
+    int len_arg, const int* __restrict__ ctl, int max_len, float c2, const float* __restrict__ o_mul,
+    int64_t ldmul, float* __restrict__ o) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int hq = (H + 3) >> 2;
+    const int n = blockIdx.x / hq, h = (blockIdx.x - n * hq) * 4 + w;
+    if (h >= H) return;                      // whole wave; no workgroup barrier below
+    const int D = H * HD;
+    const bool app = k_new != nullptr;
+    const int64_t row = (int64_t)n * D + h * HD;
+    // cache row j of head h: n * bstride + h * hstride + j * rstride (row-major rows of H * d floats, or
+    // head-major -- DecodeCache's layout: a head's keys contiguous, a wave-level load is one 2-KB run at d = 8)
+    float* kb = kc + (int64_t)n * bstride + (int64_t)h * hstride;
+    float* vb = vc + (int64_t)n * bstride + (int64_t)h * hstride;
+    constexpr int U = HD <= 16 ? 4 : (HD <= 32 ? 2 : 1);     // keys per lane and pass (128 registers of rows)
+    float qv[HD], kn[HD], vn[HD];
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+        const float4 a = ld4(q + row + c);
+        qv[c] = a.x; qv[c + 1] = a.y; qv[c + 2] = a.z; qv[c + 3] = a.w;
+        const float4 b = ld4((app ? k_new : q) + row + c), d = ld4((app ? v_new : q) + row + c);
+        kn[c] = b.x; kn[c + 1] = b.y; kn[c + 2] = b.z; kn[c + 3] = b.w;
+        vn[c] = d.x; vn[c + 1] = d.y; vn[c + 2] = d.z; vn[c + 3] = d.w;
+    }
+    float4 kk[U][HD / 4], vv[U][HD / 4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = min(lane + 64 * u, max_len - 1);
+#pragma unroll
+        for (int c = 0; c < HD / 4; ++c) {
+            kk[u][c] = ld4(kb + (int64_t)j * rstride + 4 * c);
+            vv[u][c] = ld4(vb + (int64_t)j * rstride + 4 * c);
+        }
+    }
+    const float mq = *(o_mul ? o_mul + (int64_t)n * ldmul + h * HD + min(lane, HD - 1) : q + row);
+    int L = ctl ? ctl[CTL_LEN] : len_arg;
+    L = min(max(L, 0), app ? max_len - 1 : max_len);
+    const int Sk = L + (app ? 1 : 0);
+    if (app && lane < HD) {                  // the new row joins the cache (off the critical path)
+        kb[(int64_t)L * rstride + lane] = k_new[row + lane];
+        vb[(int64_t)L * rstride + lane] = v_new[row + lane];
+    }
+    float m = -INFINITY, l = 0.0f, ov[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) ov[c] = 0.0f;
+    for (int j0 = 0; j0 < Sk; j0 += 64 * U) {
+        if (j0 > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = min(j0 + lane + 64 * u, max_len - 1);
+#pragma unroll
+                for (int c = 0; c < HD / 4; ++c) {
+                    kk[u][c] = ld4(kb + (int64_t)j * rstride + 4 * c);
+                    vv[u][c] = ld4(vb + (int64_t)j * rstride + 4 * c);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + lane + 64 * u;
+            const bool fresh = app && j == L;      // the new row comes from its source, not from the cache
+            float dot = 0.0f;
+#pragma unroll
+            for (int c = 0; c < HD / 4; ++c) {
+                dot = fmaf(qv[4 * c], fresh ? kn[4 * c] : kk[u][c].x, dot);
+                dot = fmaf(qv[4 * c + 1], fresh ? kn[4 * c + 1] : kk[u][c].y, dot);
+                dot = fmaf(qv[4 * c + 2], fresh ? kn[4 * c + 2] : kk[u][c].z, dot);
+                dot = fmaf(qv[4 * c + 3], fresh ? kn[4 * c + 3] : kk[u][c].w, dot);
+            }
+            if (j < Sk) {
+                const float t = dot * c2;
+                const float mn = fmaxf(m, t);
+                const float alpha = exp2_fast(m - mn);
+                const float pr = exp2_fast(t - mn);
+                l = l * alpha + pr;
+#pragma unroll
+                for (int c = 0; c < HD / 4; ++c) {
+                    ov[4 * c] = fmaf(pr, fresh ? vn[4 * c] : vv[u][c].x, ov[4 * c] * alpha);
+                    ov[4 * c + 1] = fmaf(pr, fresh ? vn[4 * c + 1] : vv[u][c].y, ov[4 * c + 1] * alpha);
+                    ov[4 * c + 2] = fmaf(pr, fresh ? vn[4 * c + 2] : vv[u][c].z, ov[4 * c + 2] * alpha);
+                    ov[4 * c + 3] = fmaf(pr, fresh ? vn[4 * c + 3] : vv[u][c].w, ov[4 * c + 3] * alpha);
+                }
+                m = mn;
+            }
+        }
+    }
+    const float Mx = wave_max_dpp(m);
+    const float sc = m == -INFINITY ? 0.0f : exp2_fast(m - Mx);
+    // {l, o[0..HD)} summed over the wave together: value number 0 is l, 1 + c is o[c]
+    constexpr int NV = HD < 8 ? 8 : (HD < 16 ? 16 : (HD < 32 ? 32 : 64));
+    static_assert(HD + 1 <= NV || HD == 64, "");
+    if constexpr (HD < 64) {
+        float r[NV];
+        r[0] = l * sc;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) r[1 + c] = ov[c] * sc;
+#pragma unroll
+        for (int c = HD + 1; c < NV; ++c) r[c] = 0.0f;
+        bool own;
+        const int idx = wave_sum_multi<NV>(r, lane, own);
+        // value 0 (l) ends on lane 0 (no bit of its number set); lane c < HD holds o_mul[c]
+        const float lt = __shfl(r[0], 0, 64);
+        const float mv = __shfl(mq, min(max(idx - 1, 0), HD - 1), 64);
+        if (own && idx >= 1 && idx <= HD) {
+            const float t = r[0] / lt;
+            o[row + idx - 1] = o_mul ? t * mv : t;
+        }
+    } else {
+        float lsum[1] = {l * sc};
+        bool own;
+        wave_sum_multi<1>(lsum, lane, own);
+        float r[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) r[c] = ov[c] * sc;
+        const int idx = wave_sum_multi<64>(r, lane, own);
+        const float mv = __shfl(mq, idx, 64);
+        const float t = r[0] / lsum[0];
+        o[row + idx] = o_mul ? t * mv : t;
+    }
+}
+
+__device__ __forceinline__ int wave_min_int(int x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = min(x, __shfl_xor(x, o, 64));
+    return x;
+}
+__device__ __forceinline__ int wave_max_int(int x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = max(x, __shfl_xor(x, o, 64));
+    return x;
+}
+
+// One sampling draw per row, as generate_images.py:289-304 makes it (train_quantized_transformer.py:
+// 626-636 in "train" mode): probs = softmax(logits / T); generate mode zeroes the <end> probability;
+// a token is drawn in proportion to probs -- by inverse CDF from ONE uniform of the caller's generator
+// (torch.multinomial consumes its generator differently: the same distribution, not the same stream) --
+// the running product of the chosen probabilities is updated, train mode maps a drawn <end> to 0, and the
+// token (+ shift: the base stage's vocabulary offset) is appended: to ids (the next step's input) and to
+// slot `slot` of the row's chunk.  forced (optional, >= 0 entries): tokens to take instead of drawing
+// (tests replay the reference's recorded draws); probs_log (optional): receives the row it sampled from.
+// A wave per row; every sum runs in a fixed order.
+__global__ __launch_bounds__(64) void decode_sample_kernel(
+    const float* __restrict__ logits, int64_t ldl, int B, int V, float temperature, int end_token,
+    int generate_mode, int64_t shift, const float* __restrict__ uniforms, const int64_t* __restrict__ forced,
+    int* __restrict__ ctl, int slot, int bw, int max_draws, int inc_len, int64_t* __restrict__ ids,
+    int64_t* __restrict__ chunk, float* __restrict__ comb, float* __restrict__ probs_log) {
+    __shared__ float part[64];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (slot < 0) slot = min(max(ctl[CTL_TOK], 0), bw - 1);     // the slot the device counts
+    const int d = min(max(ctl[CTL_DRAW] + slot, 0), max_draws - 1);
+    const float* z = logits + (int64_t)b * ldl;
+    const int per = (V + 63) / 64, i0 = min(V, lane * per), i1 = min(V, i0 + per);
+    float mx = -INFINITY;
+    for (int i = i0; i < i1; ++i) mx = fmaxf(mx, z[i] / temperature);
+    mx = wave_max_dpp(mx);
+    float s[1] = {0.0f};
+    for (int i = i0; i < i1; ++i) s[0] += expf(z[i] / temperature - mx);
+    bool own;
+    wave_sum_multi<1>(s, lane, own);
+    const float S = s[0];
+    auto prob = [&](int i) {
+        const float pr = expf(z[i] / temperature - mx) / S;
+        return (generate_mode && i == end_token) ? 0.0f : pr;
+    };
+    float ps = 0.0f;
+    int last_nz = -1;
+    float* lg = probs_log ? probs_log + ((int64_t)d * B + b) * V : nullptr;
+    for (int i = i0; i < i1; ++i) {
+        const float pr = prob(i);
+        ps += pr;
+        if (pr > 0.0f) last_nz = i;
+        if (lg) lg[i] = pr;
+    }
+    part[lane] = ps;
+    __syncthreads();
+    float base = 0.0f, total = 0.0f;
+    for (int k = 0; k < 64; ++k) {
+        if (k == lane) base = total;
+        total += part[k];
+    }
+    const float target = uniforms[(int64_t)d * B + b] * total;
+    int cand = 0x7fffffff;
+    float run = base;
+    for (int i = i0; i < i1; ++i) {
+        const float pr = prob(i);
+        run += pr;
+        if (pr > 0.0f && run > target && cand == 0x7fffffff) cand = i;
+    }
+    cand = wave_min_int(cand);
+    const int fallback = wave_max_int(last_nz);       // rounding left the target at or past the total
+    int64_t nxt = cand == 0x7fffffff ? max(fallback, 0) : cand;
+    if (forced) {
+        const int64_t f = forced[(int64_t)d * B + b];
+        if (f >= 0 && f < V) nxt = f;
+    }
+    if (lane == 0) {
+        comb[b] *= prob((int)nxt);
+        if (!generate_mode && nxt == end_token) nxt = 0;      // reference HACK: <end> -> index 0
+        ids[b] = nxt + shift;
+        chunk[(int64_t)b * bw + slot] = nxt + shift;
+        if (b == 0 && inc_len) ctl[CTL_LEN] += 1;             // no other workgroup of this launch reads it
+    }
+}
+
+// After a candidate chunk (all rows have drawn beam_width tokens): per image, the beam with the largest
+// probability product (first one on ties: torch.argmax) competes with the best chunk kept so far --
+// generate_images.py:325-337 keeps the earlier candidate unless the new product is larger -- and the
+// counters move on: next candidate, the draws it consumed, the cache position back at the chunk start.
+// take[n] = 1 + winning beam when the new chunk replaces the kept one, else 0.
+__global__ __launch_bounds__(64) void decode_decide_kernel(int* __restrict__ ctl, int N, int NB, int bw,
+                                                           float* __restrict__ comb,
+                                                           const int64_t* __restrict__ chunk,
+                                                           float* __restrict__ best_p,
+                                                           int64_t* __restrict__ best_chunk,
+                                                           int* __restrict__ take) {
+    const int cand = ctl[CTL_CAND];
+    for (int n = threadIdx.x; n < N; n += 64) {
+        int pb = 0;
+        float c = comb[(int64_t)n * NB];
+        for (int k = 1; k < NB; ++k)
+            if (comb[(int64_t)n * NB + k] > c) { c = comb[(int64_t)n * NB + k]; pb = k; }
+        const bool tk = cand == 0 || !(best_p[n] >= c);
+        take[n] = tk ? pb + 1 : 0;
+        if (tk) {
+            best_p[n] = c;
+            for (int j = 0; j < bw; ++j) best_chunk[(int64_t)n * bw + j] = chunk[((int64_t)n * NB + pb) * bw + j];
+        }
+        for (int k = 0; k < NB; ++k) comb[(int64_t)n * NB + k] = 1.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctl[CTL_CAND] = cand + 1;
+        ctl[CTL_DRAW] += bw;
+        ctl[CTL_LEN] = ctl[CTL_CUR];
+        ctl[CTL_TOK] = 0;
+    }
+}
+
+// Cache rows [cur, cur + R) of every layer, keys and values: restore == 0 saves the winning beam's rows
+// of the images whose chunk was just kept (take[n] > 0) into the staging copy; restore == 1 writes the
+// staged rows into EVERY beam of every image (the kept chunk becomes the common prefix).
+// kv (layers * 2, N * NB, H, max_len, d) head-major; staged (layers * 2, N, H, R, d).
+__global__ __launch_bounds__(256) void decode_rows_kernel(const int* __restrict__ ctl, float* __restrict__ kv,
+                                                          float* __restrict__ staged,
+                                                          const int* __restrict__ take, int layers2, int N,
+                                                          int NB, int H, int R, int d, int max_len, int restore) {
+    const int cur = ctl[CTL_CUR];
+    const int64_t dq = d / 4;
+    const int64_t per = (restore ? (int64_t)NB : 1) * H * R * dq;
+    const int64_t total = (int64_t)layers2 * N * per;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t r_ = i;
+        const int c = (int)(r_ % dq); r_ /= dq;
+        const int r = (int)(r_ % R); r_ /= R;
+        const int h = (int)(r_ % H); r_ /= H;
+        int bm = 0;
+        if (restore) { bm = (int)(r_ % NB); r_ /= NB; }
+        const int n = (int)(r_ % N);
+        const int l2 = (int)(r_ / N);
+        const int row = cur + r;
+        if (row < 0 || row >= max_len) continue;
+        float* st = staged + ((((int64_t)l2 * N + n) * H + h) * R + r) * d + 4 * c;
+        if (restore) {
+            float* dst = kv + ((((int64_t)l2 * N * NB + (int64_t)n * NB + bm) * H + h) * max_len + row) * d + 4 * c;
+            *reinterpret_cast<float4*>(dst) = ld4(st);
+        } else {
+            const int tk = take[n];
+            if (tk <= 0) continue;
+            const float* src = kv + ((((int64_t)l2 * N * NB + (int64_t)n * NB + (tk - 1)) * H + h) * max_len + row) * d + 4 * c;
+            *reinterpret_cast<float4*>(st) = ld4(src);
+        }
+    }
+}
+
+// The kept chunk becomes part of the sequence: tokens[n][cur + j] = best_chunk[n][j]; its last token is
+// the input of the step that produces the next chunk's first logits, at window index cur + bw - 1.
+__global__ __launch_bounds__(64) void decode_commit_kernel(int* __restrict__ ctl, int N, int NB, int bw,
+                                                           const int64_t* __restrict__ best_chunk,
+                                                           int64_t* __restrict__ tokens, int64_t ldt,
+                                                           int64_t* __restrict__ ids) {
+    const int cur = ctl[CTL_CUR];
+    for (int n = threadIdx.x; n < N; n += 64) {
+        for (int j = 0; j < bw; ++j)
+            if (cur + j >= 0 && cur + j < ldt) tokens[(int64_t)n * ldt + cur + j] = best_chunk[(int64_t)n * bw + j];
+        for (int k = 0; k < NB; ++k) ids[(int64_t)n * NB + k] = best_chunk[(int64_t)n * bw + bw - 1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ctl[CTL_LEN] = cur + bw - 1;
+}
+
+// Behind that step: the next chunk starts.
+__global__ void decode_advance_kernel(int* __restrict__ ctl, int bw) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ctl[CTL_CUR] += bw;
+        ctl[CTL_LEN] = ctl[CTL_CUR];
+        ctl[CTL_CAND] = 0;
+        ctl[CTL_TOK] = 0;
+    }
+}
 }  // namespace qarig
 
 using namespace qarig;
@@ -253,12 +627,16 @@ extern "C" int qarig_decode_linear_supported(int M, int N, int K, int ln) {
     return (K == 2048 || K == 4096) && !ln;
 }
 
+struct DecLinHead { const float* X; const float* W; int64_t ldx, ldw; int M, N, K, act; int64_t x_gs, w_gs; };
+
 template <int MR, int LN>
-static void launch_decode_linear(const DecLin& p, int groups, hipStream_t st) {
-    const int kq = p.K / 4;
-    auto grid = [&](int cw) { return dim3((p.N + cw - 1) / cw, groups); };
-    auto wgs = [&](int cw) { return (int64_t)((p.N + cw - 1) / cw) * groups; };
-#define QARIG_DL(J, KS, CW) hipLaunchKernelGGL((decode_linear_kernel<MR, LN, J, KS>), grid(CW), dim3(256), 0, st, p)
+static void launch_decode_linear(const DecLinHead& h, const DecLin& p, int groups, hipStream_t st) {
+    const int kq = h.K / 4;
+    auto grid = [&](int cw) { return dim3((h.N + cw - 1) / cw, groups); };
+    auto wgs = [&](int cw) { return (int64_t)((h.N + cw - 1) / cw) * groups; };
+#define QARIG_DL(J, KS, CW)                                                                                     \
+    hipLaunchKernelGGL((decode_linear_kernel<MR, LN, J, KS>), grid(CW), dim3(256), 0, st, h.X, h.W, h.ldx, h.ldw, \
+                       h.M, h.N, h.K, h.act, h.x_gs, h.w_gs, p)
     if (kq <= 256) {
         const int CG = 256 / kq;
         // 16 KB of weights per workgroup while that leaves >= 256 workgroups, else fewer bytes each
@@ -306,18 +684,157 @@ extern "C" int qarig_decode_linear_f32(const float* X, int64_t ldx, int64_t x_gs
     QARIG_CHECK_ARG(ldx >= K && ldw >= K && ldc >= N && (!residual || ldr >= N) && (!mul || ldmul == 0 || ldmul >= N) &&
                         (!scale || ldmod == 0 || ldmod >= K),
                     "decode_linear: a row stride is shorter than its row");
-    const DecLin p{X, ldx, x_gs, W, ldw, w_gs, bias, bias_gs, C, ldc, c_gs, residual, ldr, mul, ldmul,
-                   gamma, beta, scale, shift, ldmod, eps, M, N, K, act};
+    const DecLinHead h{X, W, ldx, ldw, M, N, K, act, x_gs, w_gs};
+    const DecLin p{bias, bias_gs, C, ldc, c_gs, residual, ldr, mul, ldmul, gamma, beta, scale, shift, ldmod, eps};
     hipStream_t st = (hipStream_t)stream;
 #define QARIG_DL_LN(MR)                                                     \
     switch (ln) {                                                           \
-        case 0: launch_decode_linear<MR, 0>(p, groups, st); break;          \
-        case 1: launch_decode_linear<MR, 1>(p, groups, st); break;          \
-        case 2: launch_decode_linear<MR, 2>(p, groups, st); break;          \
-        default: launch_decode_linear<MR, 3>(p, groups, st); break;         \
+        case 0: launch_decode_linear<MR, 0>(h, p, groups, st); break;          \
+        case 1: launch_decode_linear<MR, 1>(h, p, groups, st); break;          \
+        case 2: launch_decode_linear<MR, 2>(h, p, groups, st); break;          \
+        default: launch_decode_linear<MR, 3>(h, p, groups, st); break;         \
     }
     if (M <= 4) { QARIG_DL_LN(4) } else { QARIG_DL_LN(16) }
 #undef QARIG_DL_LN
     QARIG_CHECK_LAUNCH("decode_linear");
+    return QARIG_OK;
+}
+
+
+extern "C" int qarig_decode_embed(const int64_t* ids, int B, int D, int V, const float* table,
+                                  const float* pe, int* ctl, int len, int max_len,
+                                  const float* proj_table, int64_t proj_row_floats, float* x,
+                                  float* proj_row, int* bad_flag, void* stream) {
+    QARIG_CHECK_ARG(ids && table && x && bad_flag, "decode_embed: null pointer");
+    QARIG_CHECK_ARG(B > 0 && D > 0 && V > 0 && max_len > 0 && D % 4 == 0, "decode_embed: bad extents (D %% 4 == 0)");
+    QARIG_CHECK_DIMS("decode_embed", B, D);
+    QARIG_CHECK_DIMS("decode_embed", V, D);
+    QARIG_CHECK_DIMS("decode_embed", max_len, D);
+    QARIG_CHECK_ARG(ctl || (len >= 0 && len < max_len), "decode_embed: len out of range");
+    QARIG_CHECK_ARG(proj_row_floats >= 0 && proj_row_floats % 4 == 0 && proj_row_floats <= (1LL << 30) &&
+                        (proj_row_floats == 0 || (proj_table && proj_row)),
+                    "decode_embed: projection row must be a multiple of 4 floats with both pointers given");
+    QARIG_CHECK_ARG(proj_row_floats == 0 || qarig_dims_ok({max_len, proj_row_floats}), "decode_embed: table too large");
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    QARIG_CHECK_ARG(al16(table) && al16(pe) && al16(x) && al16(proj_table) && al16(proj_row),
+                    "decode_embed: operands must be 16-B aligned");
+    const int64_t items = (int64_t)B * D / 4 + proj_row_floats / 4;
+    const int blocks = (int)((items + 255) / 256 < 1024 ? (items + 255) / 256 : 1024);
+    hipLaunchKernelGGL(decode_embed_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, B, D, V, table, pe,
+                       ctl, len, max_len, proj_table, proj_row_floats, x, proj_row, bad_flag);
+    QARIG_CHECK_LAUNCH("decode_embed");
+    return QARIG_OK;
+}
+
+extern "C" int qarig_decode_attention(const float* q, const float* k_new, const float* v_new, float* kcache,
+                                      float* vcache, int B, int H, int d, int len, const int* len_dev,
+                                      int max_len, int64_t batch_stride, int64_t head_stride, int64_t row_stride,
+                                      float sqrt_d, const float* o_mul, int64_t ldmul, float* o, void* stream) {
+    QARIG_CHECK_ARG(q && kcache && vcache && o, "decode_attention: null pointer");
+    QARIG_CHECK_ARG((k_new == nullptr) == (v_new == nullptr), "decode_attention: k_new and v_new go together");
+    QARIG_CHECK_ARG(B > 0 && H > 0 && d > 0 && max_len > 0 && sqrt_d > 0.0f, "decode_attention: bad extents");
+    QARIG_CHECK_DIMS("decode_attention", B, H, max_len);
+    QARIG_CHECK_ARG(d == 4 || d == 8 || d == 16 || d == 32 || d == 64,
+                    "decode_attention: head dim %d unsupported (4,8,16,32,64)", d);
+    QARIG_CHECK_ARG((long long)B * H < (1LL << 31), "decode_attention: bad extents");
+    const bool row_major = head_stride == d && row_stride == (int64_t)H * d && batch_stride >= (int64_t)max_len * H * d;
+    const bool head_major = row_stride == d && head_stride >= (int64_t)max_len * d && head_stride <= (1LL << 40) &&
+                            batch_stride >= (int64_t)H * head_stride;
+    QARIG_CHECK_ARG((row_major || head_major) && batch_stride % 4 == 0 && head_stride % 4 == 0,
+                    "decode_attention: cache strides are neither row-major (rows of H * d) nor head-major "
+                    "(a head's max_len rows of d), or shorter than max_len rows");
+    QARIG_CHECK_ARG(!o_mul || ldmul == 0 || ldmul >= (int64_t)H * d, "decode_attention: ldmul shorter than a row");
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    QARIG_CHECK_ARG(al16(q) && al16(k_new) && al16(v_new) && al16(kcache) && al16(vcache),
+                    "decode_attention: operands must be 16-B aligned");
+    if (!len_dev) {
+        QARIG_CHECK_ARG(len >= 0 && (k_new ? len < max_len : (len > 0 && len <= max_len)),
+                        "decode_attention: len out of range for the cache");
+    }
+    const float c2 = 1.4426950408889634f / sqrt_d;
+    const dim3 grid(B * ((H + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define QARIG_DA(HD)                                                                                          \
+    hipLaunchKernelGGL((decode_attention_kernel<HD>), grid, block, 0, st, q, k_new, v_new, kcache, vcache,    \
+                       batch_stride, head_stride, row_stride, H, len, len_dev, max_len, c2, o_mul, ldmul, o)
+    switch (d) {
+        case 4: QARIG_DA(4); break;
+        case 8: QARIG_DA(8); break;
+        case 16: QARIG_DA(16); break;
+        case 32: QARIG_DA(32); break;
+        default: QARIG_DA(64); break;
+    }
+#undef QARIG_DA
+    QARIG_CHECK_LAUNCH("decode_attention");
+    return QARIG_OK;
+}
+
+extern "C" int qarig_decode_sample(const float* logits, int64_t ldl, int B, int V, float temperature,
+                                   int end_token, int generate_mode, int64_t shift, const float* uniforms,
+                                   const int64_t* forced, int* ctl, int slot, int beam_width, int max_draws,
+                                   int inc_len, int64_t* ids, int64_t* chunk, float* comb, float* probs_log,
+                                   void* stream) {
+    QARIG_CHECK_ARG(logits && uniforms && ctl && ids && chunk && comb, "decode_sample: null pointer");
+    QARIG_CHECK_ARG(B > 0 && V > 0 && beam_width > 0 && max_draws > 0 && slot >= -1 && slot < beam_width,
+                    "decode_sample: bad extents");
+    QARIG_CHECK_DIMS("decode_sample", B, V);
+    QARIG_CHECK_DIMS("decode_sample", max_draws, B);
+    QARIG_CHECK_DIMS("decode_sample", B, beam_width);
+    QARIG_CHECK_ARG(ldl >= V && temperature > 0.0f, "decode_sample: ldl < V or temperature <= 0");
+    QARIG_CHECK_ARG(!probs_log || qarig_dims_ok({max_draws, B, V}), "decode_sample: probability log too large");
+    hipLaunchKernelGGL(decode_sample_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, ldl, B, V,
+                       temperature, end_token, generate_mode, shift, uniforms, forced, ctl, slot, beam_width,
+                       max_draws, inc_len, ids, chunk, comb, probs_log);
+    QARIG_CHECK_LAUNCH("decode_sample");
+    return QARIG_OK;
+}
+
+extern "C" int qarig_decode_decide(int* ctl, int N, int NB, int beam_width, float* comb, const int64_t* chunk,
+                                   float* best_p, int64_t* best_chunk, int* take, void* stream) {
+    QARIG_CHECK_ARG(ctl && comb && chunk && best_p && best_chunk && take, "decode_decide: null pointer");
+    QARIG_CHECK_ARG(N > 0 && NB > 0 && beam_width > 0, "decode_decide: bad extents");
+    QARIG_CHECK_DIMS("decode_decide", N, NB, beam_width);
+    hipLaunchKernelGGL(decode_decide_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, N, NB, beam_width, comb,
+                       chunk, best_p, best_chunk, take);
+    QARIG_CHECK_LAUNCH("decode_decide");
+    return QARIG_OK;
+}
+
+extern "C" int qarig_decode_rows(const int* ctl, float* kv, float* staged, const int* take, int layers2, int N,
+                                 int NB, int H, int R, int d, int max_len, int restore, void* stream) {
+    QARIG_CHECK_ARG(ctl && kv && staged && (restore || take), "decode_rows: null pointer");
+    QARIG_CHECK_ARG(layers2 > 0 && N > 0 && NB > 0 && H > 0 && R > 0 && d > 0 && d % 4 == 0 && max_len > 0,
+                    "decode_rows: bad extents (d %% 4 == 0)");
+    QARIG_CHECK_DIMS("decode_rows", layers2, N, NB, max_len);
+    QARIG_CHECK_DIMS("decode_rows", layers2, N, NB, R);
+    QARIG_CHECK_DIMS("decode_rows", max_len, H, d);
+    QARIG_CHECK_DIMS("decode_rows", R, H, d);
+    QARIG_CHECK_ARG(qarig_dims_ok({layers2, (long long)N * NB, (long long)max_len * H * d}, 1LL << 40, 1LL << 44),
+                    "decode_rows: cache too large");
+    QARIG_CHECK_ARG((((uintptr_t)kv | (uintptr_t)staged) & 15) == 0, "decode_rows: operands must be 16-B aligned");
+    const int64_t total = (int64_t)layers2 * N * (restore ? NB : 1) * H * R * (d / 4);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(decode_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ctl, kv, staged, take,
+                       layers2, N, NB, H, R, d, max_len, restore);
+    QARIG_CHECK_LAUNCH("decode_rows");
+    return QARIG_OK;
+}
+
+extern "C" int qarig_decode_commit(int* ctl, int N, int NB, int beam_width, const int64_t* best_chunk,
+                                   int64_t* tokens, int64_t ldt, int64_t* ids, void* stream) {
+    QARIG_CHECK_ARG(ctl && best_chunk && tokens && ids, "decode_commit: null pointer");
+    QARIG_CHECK_ARG(N > 0 && NB > 0 && beam_width > 0 && ldt > 0, "decode_commit: bad extents");
+    QARIG_CHECK_DIMS("decode_commit", N, NB, beam_width);
+    QARIG_CHECK_ARG(qarig_dims_ok({N, ldt}, 1LL << 40), "decode_commit: token buffer too large");
+    hipLaunchKernelGGL(decode_commit_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, N, NB, beam_width,
+                       best_chunk, tokens, ldt, ids);
+    QARIG_CHECK_LAUNCH("decode_commit");
+    return QARIG_OK;
+}
+
+extern "C" int qarig_decode_advance(int* ctl, int beam_width, void* stream) {
+    QARIG_CHECK_ARG(ctl && beam_width > 0, "decode_advance: bad arguments");
+    hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, beam_width);
+    QARIG_CHECK_LAUNCH("decode_advance");
     return QARIG_OK;
 }

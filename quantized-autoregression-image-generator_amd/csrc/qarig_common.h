@@ -26,6 +26,10 @@ extern "C" int qarig_decode_linear_f32(const float* X, int64_t ldx, int64_t x_gs
                                        const float* residual, int64_t ldr, const float* mul, int64_t ldmul, float* C,
                                        int64_t ldc, int64_t c_gs, int groups, int M, int N, int K, int act,
                                        void* stream);
+extern "C" int qarig_decode_attention(const float* q, const float* k_new, const float* v_new, float* kcache,
+                                      float* vcache, int B, int H, int d, int len, const int* len_dev, int max_len,
+                                      int64_t batch_stride, int64_t head_stride, int64_t row_stride, float sqrt_d,
+                                      const float* o_mul, int64_t ldmul, float* o, void* stream);
 
 // Kernel-selection options (qarig_set_option): every one only chooses between kernels that must give
 // the same results; -1 / 0 = the library's own choice where stated.  Defined in capi.hip.

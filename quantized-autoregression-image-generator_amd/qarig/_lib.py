@@ -77,6 +77,13 @@ SIGNATURES = {
     "qarig_decode_linear_supported": (I, [I, I, I, I]),
     "qarig_decode_linear_f32": (I, [P, L, L, F, P, P, P, P, L, P, L, L, P, L, P, L, P, L, P, L, L, I, I, I, I, I,
                                     P]),
+    "qarig_decode_embed": (I, [P, I, I, I, P, P, P, I, I, P, L, P, P, P, P]),
+    "qarig_decode_attention": (I, [P, P, P, P, P, I, I, I, I, P, I, L, L, L, F, P, L, P, P]),
+    "qarig_decode_sample": (I, [P, L, I, I, F, I, I, L, P, P, P, I, I, I, I, P, P, P, P, P]),
+    "qarig_decode_decide": (I, [P, I, I, I, P, P, P, P, P, P]),
+    "qarig_decode_rows": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "qarig_decode_commit": (I, [P, I, I, I, P, P, L, P, P]),
+    "qarig_decode_advance": (I, [P, I, P]),
     "qarig_attention_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, F, P, P, P, P, P]),
     "qarig_cross_entropy_fwd": (I, [P, P, I, I, P, P, P, P, P]),
     "qarig_mse_workspace_bytes": (Z, []),

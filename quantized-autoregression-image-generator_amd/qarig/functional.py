@@ -676,7 +676,7 @@ class _Conv2dAct(torch.autograd.Function):
         if need and act:
             y, pre = ops.conv2d_fwd(x, weight, bias, stride, pad, act, want_preact=True)
         else:
-            y, pre = ops.conv2d_fwd(x, weight, bias, stride, pad, act), None
+            y, pre = ops.conv2d_fwd(x, weight, bias, stride, pad, act, inference=not need), None
         ctx.save_for_backward(x, weight, pre)
         ctx.cfg = (stride, pad, act, bias is not None)
         return y
@@ -706,7 +706,7 @@ class _ConvT2dAct(torch.autograd.Function):
         if need and act:
             y, pre = ops.conv_transpose2d_fwd(x, weight, bias, act, want_preact=True)
         else:
-            y, pre = ops.conv_transpose2d_fwd(x, weight, bias, act), None
+            y, pre = ops.conv_transpose2d_fwd(x, weight, bias, act, inference=not need), None
         ctx.save_for_backward(x, weight, pre)
         ctx.cfg = (act, bias is not None)
         return y

@@ -926,20 +926,104 @@ def attention_fwd(q, k, v, heads, causal, scale_dim=None):
 
 def attention_decode(q, k_new, v_new, kcache, vcache, length, heads, len_dev=None, o_mul=None):
     """One decode step: q (B,D) against cache rows [0,length) (+ the appended new row).
-    kcache/vcache: (B, max_len, D) views with unit row stride D (batch stride free)."""
+    kcache/vcache: row-major (B, max_len, D) views with unit row stride D (batch stride free), or
+    head-major (B, H, max_len, d) -- DecodeCache's layout.  o_mul: (B, D), or one (D,) row for every sequence."""
     B, D = q.shape
     d = D // heads
-    assert kcache.shape == vcache.shape and kcache.shape[0] == B and kcache.shape[2] == D
-    assert kcache.stride(2) == 1 and kcache.stride(1) == D and vcache.stride() == kcache.stride()
+    assert kcache.shape == vcache.shape and kcache.shape[0] == B and vcache.stride() == kcache.stride()
+    if kcache.dim() == 4:
+        assert kcache.shape[1] == heads and kcache.shape[3] == d and kcache.stride(3) == 1 and kcache.stride(2) == d
+        max_len, hstride, rstride = kcache.shape[2], kcache.stride(1), d
+    else:
+        assert kcache.shape[2] == D and kcache.stride(2) == 1 and kcache.stride(1) == D
+        max_len, hstride, rstride = kcache.shape[1], d, D
+    assert q.is_contiguous()
     o = torch.empty_like(q)
+    ldmul = 0
     if o_mul is not None:
-        assert o_mul.shape == q.shape and o_mul.is_contiguous() and q.is_contiguous()
-    check(_lib.load().qarig_attention_decode(
+        assert o_mul.shape in (q.shape, (D,)) and o_mul.is_contiguous()
+        ldmul = D if o_mul.dim() == 2 else 0
+    check(_lib.load().qarig_decode_attention(
         ptr(q), ptr(k_new) if k_new is not None else None,
         ptr(v_new) if v_new is not None else None, ptr(kcache), ptr(vcache), B, heads, d,
-        int(length), ptr(len_dev) if len_dev is not None else None, kcache.shape[1],
-        kcache.stride(0), float(d ** 0.5), ptr(o_mul), ptr(o), stream()), "qarig_attention_decode")
+        int(length), ptr(len_dev) if len_dev is not None else None, max_len,
+        kcache.stride(0), hstride, rstride, float(d ** 0.5), ptr(o_mul), ldmul, ptr(o), stream()),
+        "qarig_decode_attention")
     return o
+
+
+DECODE_CTL_WORDS = 8          # include/qarig.h QARIG_DECODE_CTL_WORDS: [0] len, [1] chunk start, [2] draws, [3] candidate
+
+
+def decode_embed(ids, table, pe, ctl=None, length=0, proj_table=None, proj_row=None):
+    """x[b] = table[ids[b]] + pe[len] (len = ctl[0], or `length` without ctl) and proj_row <- row len of
+    proj_table (max_len, PD), the stage's per-position projections of `cond`.  Returns x (B, D)."""
+    require_cuda(ids, table, pe, ctl, proj_table, proj_row)
+    ids = _i64c(ids).reshape(-1)
+    B, (V, D) = ids.numel(), table.shape
+    assert table.is_contiguous() and table.dtype == torch.float32
+    max_len = pe.shape[0] if pe is not None else (proj_table.shape[0] if proj_table is not None else int(length) + 1)
+    assert pe is None or (pe.shape == (max_len, D) and pe.is_contiguous())
+    pd = 0
+    if proj_table is not None:
+        assert proj_table.dim() == 2 and proj_table.shape[0] == max_len and proj_table.is_contiguous()
+        pd = proj_table.shape[1]
+        assert proj_row is not None and proj_row.numel() == pd and proj_row.is_contiguous()
+    assert ctl is None or (ctl.dtype == torch.int32 and ctl.numel() >= DECODE_CTL_WORDS)
+    x = torch.empty((B, D), dtype=torch.float32, device=table.device)
+    check(_lib.load().qarig_decode_embed(ptr(ids), B, D, V, ptr(table), ptr(pe), ptr(ctl), int(length), max_len,
+                                         ptr(proj_table), pd, ptr(x), ptr(proj_row), ptr(_bad_flag(table.device)),
+                                         stream()), "qarig_decode_embed")
+    return x
+
+
+def decode_sample(logits, temperature, end_token, generate_mode, shift, uniforms, ctl, slot, beam_width, ids,
+                  chunk, comb, forced=None, probs_log=None, inc_len=False):
+    """One draw per row of logits (B, V): see include/qarig.h qarig_decode_sample."""
+    require_cuda(logits, uniforms, ctl, ids, chunk, comb, forced, probs_log)
+    B, V = logits.shape
+    max_draws = uniforms.shape[0]
+    assert logits.stride(1) == 1 and uniforms.shape == (max_draws, B) and uniforms.is_contiguous()
+    assert ids.dtype == chunk.dtype == torch.int64 and ids.numel() == B and chunk.shape == (B, beam_width)
+    assert comb.shape == (B,) and comb.dtype == torch.float32 and ctl.dtype == torch.int32
+    assert forced is None or (forced.shape == (max_draws, B) and forced.dtype == torch.int64 and forced.is_contiguous())
+    assert probs_log is None or (probs_log.shape == (max_draws, B, V) and probs_log.is_contiguous())
+    check(_lib.load().qarig_decode_sample(ptr(logits), logits.stride(0), B, V, float(temperature), int(end_token),
+                                          int(bool(generate_mode)), int(shift), ptr(uniforms), ptr(forced), ptr(ctl),
+                                          int(slot), int(beam_width), max_draws, int(bool(inc_len)), ptr(ids),
+                                          ptr(chunk), ptr(comb), ptr(probs_log), stream()), "qarig_decode_sample")
+
+
+def decode_decide(ctl, N, NB, beam_width, comb, chunk, best_p, best_chunk, take):
+    require_cuda(ctl, comb, chunk, best_p, best_chunk, take)
+    assert comb.numel() == N * NB and chunk.shape == (N * NB, beam_width) and best_chunk.shape == (N, beam_width)
+    assert best_p.numel() == N and take.numel() == N and take.dtype == torch.int32
+    check(_lib.load().qarig_decode_decide(ptr(ctl), N, NB, beam_width, ptr(comb), ptr(chunk), ptr(best_p),
+                                          ptr(best_chunk), ptr(take), stream()), "qarig_decode_decide")
+
+
+def decode_rows(ctl, kv, staged, take, N, NB, restore):
+    """kv (layers, 2, N * NB, H, max_len, d) <-> staged (layers, 2, N, H, R, d) at rows [ctl[1], ctl[1] + R)."""
+    require_cuda(ctl, kv, staged, take)
+    layers, two, B, H, max_len, d = kv.shape
+    R = staged.shape[4]
+    assert two == 2 and B == N * NB and staged.shape == (layers, 2, N, H, R, d)
+    assert kv.is_contiguous() and staged.is_contiguous()
+    check(_lib.load().qarig_decode_rows(ptr(ctl), ptr(kv), ptr(staged), ptr(take), layers * 2, N, NB, H, R, d,
+                                        max_len, int(bool(restore)), stream()), "qarig_decode_rows")
+
+
+def decode_commit(ctl, N, NB, beam_width, best_chunk, tokens, ids):
+    require_cuda(ctl, best_chunk, tokens, ids)
+    assert tokens.dtype == torch.int64 and tokens.dim() == 2 and tokens.shape[0] == N and tokens.stride(1) == 1
+    assert ids.numel() == N * NB and best_chunk.shape == (N, beam_width)
+    check(_lib.load().qarig_decode_commit(ptr(ctl), N, NB, beam_width, ptr(best_chunk), ptr(tokens),
+                                          tokens.stride(0), ptr(ids), stream()), "qarig_decode_commit")
+
+
+def decode_advance(ctl, beam_width):
+    require_cuda(ctl)
+    check(_lib.load().qarig_decode_advance(ptr(ctl), int(beam_width), stream()), "qarig_decode_advance")
 
 
 def attention_bwd(q, k, v, o, dO, lse, heads, causal, scale_dim=None):
@@ -1010,26 +1094,28 @@ def scale_by(x, s):
 
 
 # -------------------------------------------------------------------------- conv
-def _conv_workspace(weight, nbytes, geom, tag):
-    """(scratch tensor, flags) of a conv forward.  Training: the shared scratch, weights re-ordered in
-    every call.  Inference (no grad: the weights are constants between optimiser steps): one scratch per
-    weight and geometry, kept while the weight is unchanged (address / version / LP_EPOCH, as the bf16
-    shadows), so the re-ordering launch runs once (QARIG_CONV_PACKED_VALID)."""
-    if torch.is_grad_enabled():
+def _conv_workspace(weight, nbytes, geom, tag, inference):
+    """(scratch tensor, flags) of a conv forward.  Training (`inference` False: some input of the autograd
+    node requires a gradient -- the caller decides, torch.is_grad_enabled() is always False inside an
+    autograd.Function.forward): the shared scratch, weights re-ordered in every call.  Inference (the
+    weights are constants between optimiser steps): one scratch per weight and geometry, kept while the
+    weight is unchanged (address / version / LP_EPOCH, as the bf16 shadows), so the re-ordering launch runs
+    once (QARIG_CONV_PACKED_VALID).  Inside a stream capture always the shared scratch: a captured launch
+    must not hold the address of a cache entry that an invalidation can free."""
+    if not inference or torch.cuda.is_current_stream_capturing():
         return workspace(nbytes, weight.device, tag), 0
     key = (tag, weight.data_ptr(), tuple(weight.shape), weight._version, LP_EPOCH, _lib.OPTION_EPOCH, geom)
     hit = _lp_get(key, weight)
     if hit is not None:
         return hit, 1
-    if torch.cuda.is_current_stream_capturing():      # no allocation inside a capture
-        return workspace(nbytes, weight.device, tag), 0
     ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=weight.device)
     _lp_put(key, weight, ws)
     return ws, 0
 
 
-def conv2d_fwd(x, weight, bias, stride, pad, act, want_preact=False):
-    """nn.Conv2d + bias + activation (reference models/layers.py:157-184, 211-230)."""
+def conv2d_fwd(x, weight, bias, stride, pad, act, want_preact=False, inference=False):
+    """nn.Conv2d + bias + activation (reference models/layers.py:157-184, 211-230).
+    inference: no gradient will be asked of this call (cached re-ordered weights, _conv_workspace)."""
     require_cuda(x, weight, bias)
     x = f32c(x)
     N, Cin, H, W = x.shape
@@ -1040,14 +1126,14 @@ def conv2d_fwd(x, weight, bias, stride, pad, act, want_preact=False):
     pre = torch.empty_like(y) if want_preact else None
     lib = _lib.load()
     ws, flags = _conv_workspace(weight, lib.qarig_conv2d_fwd_workspace_bytes_n(N, Cin, H, W, Cout, k, stride),
-                                (N, H, W, stride, pad, x.data_ptr() % 16), "convfwd")   # (alignment picks the kernel family)
+                                (N, H, W, stride, pad, x.data_ptr() % 16), "convfwd", inference)   # (alignment picks the kernel family)
     check(lib.qarig_conv2d_fwd_ws(ptr(x), N, Cin, H, W, ptr(weight), ptr(bias), Cout, k, stride,
                                   pad, act, ptr(y), ptr(pre), ptr(ws), ws.numel(), flags, stream()),
           "qarig_conv2d_fwd_ws")
     return (y, pre) if want_preact else y
 
 
-def conv_transpose2d_fwd(x, weight, bias, act, want_preact=False):
+def conv_transpose2d_fwd(x, weight, bias, act, want_preact=False, inference=False):
     """nn.ConvTranspose2d(4, 2, 1) + bias + activation (reference layers.py:188-207)."""
     require_cuda(x, weight, bias)
     x = f32c(x)
@@ -1058,7 +1144,7 @@ def conv_transpose2d_fwd(x, weight, bias, act, want_preact=False):
     pre = torch.empty_like(y) if want_preact else None
     lib = _lib.load()
     ws, flags = _conv_workspace(weight, lib.qarig_conv_transpose2d_workspace_bytes_n(N, Cin, H, W, Cout),
-                                (N, H, W, bool(want_preact), x.data_ptr() % 16), "convt")
+                                (N, H, W, bool(want_preact), x.data_ptr() % 16), "convt", inference)
     check(lib.qarig_conv_transpose2d_fwd(ptr(x), N, Cin, H, W, ptr(weight), ptr(bias), Cout, act,
                                          ptr(y), ptr(pre), ptr(ws), ws.numel(), flags, stream()),
           "qarig_conv_transpose2d_fwd")

@@ -71,9 +71,18 @@ def shard(t, dim=0):
     return t.narrow(dim, r * per, per)
 
 
-def broadcast_params(flat_param, src=0):
+def broadcast_params(optim, src=0):
+    """Rank `src`'s parameters to every rank.  optim: the FlatAdam that owns them (or its flat parameter
+    buffer).  The broadcast writes the flat buffer behind torch's per-parameter version counters, so every
+    copy derived from the old values -- the bf16 image of the reduced-precision mode, cached bf16 / e4m3 /
+    re-ordered conv weights -- is declared stale here rather than left to a key that did not change."""
+    flat = getattr(optim, "flat_param", optim)
     if world_size() > 1:
-        dist.broadcast(flat_param, src=src)
+        dist.broadcast(flat, src=src)
+    from . import ops
+    ops.lp_invalidate()
+    if hasattr(optim, "_shadow_versions"):
+        optim._shadow_versions = None
 
 
 def broadcast_host_tensor(t, src=0):

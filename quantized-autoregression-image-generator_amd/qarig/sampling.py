@@ -12,6 +12,8 @@ Reference quirks kept on purpose (drop-in behaviour):
  - "generate" numbers the appended window positions cur_len + tok + 1 (position 1 is
    never used: 0, 2, 3, ...), "train" numbers them 0, 1, 2, ...;
  - "generate" loops while len < total_seq, so beam_width must divide total_seq."""
+import os
+
 import torch
 
 from .kvcache import DecodeCache
@@ -38,6 +40,88 @@ def _cacheable(model, hr_input, use_sliding_window):
     # instantiated head dims only
     from . import ops
     return all(m.head_dim in ops.ATTENTION_HEAD_DIMS for m in model.modules() if hasattr(m, "head_dim"))
+
+
+# Which sampler the cached loop uses: "fused" (default) draws inside the captured graphs
+# (csrc/decode.hip qarig_decode_sample: inverse CDF from uniforms of the device generator, ONE generator call
+# per stage; the whole chunk search stays on the device), "torch" makes one torch.multinomial call per token as
+# the reference does on --device cuda (same generator stream as the reference for a given seed, ~8 extra
+# launches and a graph boundary per token).  QARIG_SAMPLER overrides the default.
+DEFAULT_SAMPLER = "fused"
+
+# Test hook of the fused sampler: {"forced": (draws, rows) int64 tensor or None, "log": bool}; after a stage
+# "probs" holds the (draws, rows, V) probability rows it sampled from and "draws" their number.
+FUSED_DEBUG = None
+
+
+class _Timer:
+    """QARIG_GEN_TIMING=1: wall time of the phases of a stage on stderr (synchronises; diagnosis only)."""
+
+    def __init__(self):
+        self.on = os.environ.get("QARIG_GEN_TIMING") == "1"
+        self.marks = []
+        if self.on:
+            import time
+            torch.cuda.synchronize()
+            self.clock, self.t = time.perf_counter, time.perf_counter()
+
+    def mark(self, name):
+        if self.on:
+            torch.cuda.synchronize()
+            t = self.clock()
+            self.marks.append(f"{name} {(t - self.t) * 1e3:.2f} ms")
+            self.t = t
+
+    def report(self):
+        if self.on:
+            import sys
+            print("[qarig generate] " + ", ".join(self.marks), file=sys.stderr)
+
+
+def _generate_fused(model, hr_input, enc, total_seq, temperature, use_sliding_window,
+                    sliding_window, end_token, shift, num_beam, beam_width, mode, progress,
+                    stop_len, pos_off, batch_beams):
+    """The cached search with sampling, candidate bookkeeping and the decoder steps replayed from
+    captured graphs (kvcache.DecodeCache.begin_search); nothing is read back before the stage ends.
+    Returns (hr_input, pos, cache), or None when the model does not fit the fused kernels; the cache (rows of
+    the kept tokens but the last) serves the evaluations of the next chunk that come before the window slides."""
+    device = hr_input.device
+    N = hr_input.shape[0]
+    B = num_beam if batch_beams and num_beam > 1 else 1
+    cap = stop_len + beam_width
+    limit = min(cap, sliding_window) if use_sliding_window else cap
+    pos = torch.zeros((N, 1), device=device) if use_sliding_window else None
+    cur = hr_input.shape[1]
+    chunks = 0
+    while cur + chunks * beam_width < stop_len and cur + (chunks + 1) * beam_width <= limit:
+        chunks += 1
+    if chunks == 0:
+        return hr_input, pos, None
+    positions = [0.0] + [float(L + pos_off) for L in range(1, limit)] if use_sliding_window else None
+    enc_b = enc.repeat_interleave(B, dim=0) if (enc is not None and B > 1) else enc
+    tm = _Timer()
+    cache = DecodeCache(model, enc_b, N * B, limit, graph=False, positions=positions)
+    if cache.dim % 4 or (model.use_pos_cond and cache._table is None):
+        return None
+    tm.mark("cache")
+    dbg = FUSED_DEBUG or {}
+    cache.begin_search(hr_input[:, 0], N, B, beam_width, temperature, end_token, shift, mode == "generate",
+                       chunks, 1 if B > 1 else num_beam, forced=dbg.get("forced"), log_probs=bool(dbg.get("log")))
+    tm.mark("capture")
+    for c in range(chunks):
+        cache.run_chunk(last=c == chunks - 1)
+        if progress is not None:
+            progress(cur + (c + 1) * beam_width - 1, total_seq)
+    hr_input = cache.finish_search()
+    tm.mark(f"{chunks} chunks")
+    tm.report()
+    if FUSED_DEBUG is not None:
+        FUSED_DEBUG["probs"] = cache._search.probs
+        FUSED_DEBUG["draws"] = cache._search.used
+    if use_sliding_window:
+        new = torch.tensor([float(L + pos_off) for L in range(cur, hr_input.shape[1])], device=device)
+        pos = torch.cat((pos, new[None].expand(N, -1)), dim=1)
+    return hr_input, pos, cache
 
 
 def _generate_cached(model, hr_input, enc, total_seq, temperature, use_sliding_window,
@@ -91,7 +175,7 @@ def _generate_cached(model, hr_input, enc, total_seq, temperature, use_sliding_w
                 best_p = torch.where(keep, best_p, comb)
                 best_chunk = torch.where(keep[:, None], best_chunk, chunk)
                 if saved is not None:
-                    best_rows = torch.where(keep[None, None, :, None, None], best_rows, saved)
+                    best_rows = torch.where(keep[None, None, :, None, None, None], best_rows, saved)
         if B > 1:       # first beam with the maximal product wins, as in _generate_batched
             pick = torch.arange(N, device=device) * B + best_p.view(N, B).argmax(dim=1)
             best_chunk = best_chunk[pick]
@@ -116,11 +200,12 @@ def _generate_cached(model, hr_input, enc, total_seq, temperature, use_sliding_w
 @torch.no_grad()
 def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_sliding_window,
                     sliding_window, end_token, shift=0, num_beam=1, beam_width=1, mode="generate",
-                    progress=None, batch_beams=False, use_kv_cache=True):
+                    progress=None, batch_beams=False, use_kv_cache=True, sampler=None):
     """hr_input: (N, S0) int64 conditioning/start tokens.  Returns the extended (N, S) tensor
     (first tokens included; callers strip them and undo `shift`).  use_kv_cache: evaluate one
     token per step from a key/value cache until the window starts to slide (same logits up
-    to fp32 summation order); False re-runs the window for every token like the reference."""
+    to fp32 summation order); False re-runs the window for every token like the reference.
+    sampler: "fused" / "torch" for the cached loop (DEFAULT_SAMPLER)."""
     assert mode in ("generate", "train")
     device = hr_input.device
     N = hr_input.shape[0]
@@ -130,15 +215,39 @@ def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_slidi
     rows = torch.arange(N, device=device)
     stop_len = total_seq if mode == "generate" else hr_input.shape[1] + total_seq
     pos_off = 1 if mode == "generate" else 0
+    cache = None
     if use_kv_cache and _cacheable(model, hr_input, use_sliding_window):
-        hr_input, pos = _generate_cached(model, hr_input, enc, total_seq, temperature,
-                                         use_sliding_window, sliding_window, end_token, shift,
-                                         num_beam, beam_width, mode, progress, stop_len, pos_off,
-                                         batch_beams)
+        args = (model, hr_input, enc, total_seq, temperature, use_sliding_window, sliding_window, end_token,
+                shift, num_beam, beam_width, mode, progress, stop_len, pos_off, batch_beams)
+        done = None
+        if (sampler or os.environ.get("QARIG_SAMPLER", DEFAULT_SAMPLER)) == "fused":
+            done = _generate_fused(*args)
+        if done is not None:
+            hr_input, pos, cache = done
+        else:
+            hr_input, pos = _generate_cached(*args)
+
+    def last_logits(t_in, t_start, t_pos):
+        """Logits of the window's last token.  While no token has left the window the key/value cache of the
+        fused phase is still the window's: the last chunk of a stage that ends where the window starts to slide
+        (256 tokens in a 256-token window) evaluates all but its final token from it instead of re-running the
+        window (each candidate rewrites the rows it reads; nothing reads the cache after this chunk)."""
+        n = t_in.shape[1]
+        if cache is not None and n - 1 < cache.max_len and t_in.shape[0] == cache.batch and \
+                (not use_sliding_window or n < sliding_window):
+            return cache.step(t_in[:, -1], None, n - 1)
+        return model.decode(t_in[:, t_start:].contiguous(), enc_eval, t_pos)[:, -1, :]
+
+    tail = _Timer()
+    enc_eval = enc
     if batch_beams and num_beam > 1:
-        return _generate_batched(model, hr_input, enc, total_seq, temperature, use_sliding_window,
-                                 sliding_window, end_token, shift, num_beam, beam_width, mode,
-                                 progress, stop_len, pos_off, pos)
+        enc_eval = enc.repeat_interleave(num_beam, dim=0) if enc is not None else None
+        out = _generate_batched(model, hr_input, last_logits, total_seq, temperature, use_sliding_window,
+                                sliding_window, end_token, shift, num_beam, beam_width, mode,
+                                progress, stop_len, pos_off, pos)
+        tail.mark("windowed tail (batched beams)")
+        tail.report()
+        return out
     while hr_input.shape[1] < stop_len:
         cur = hr_input.shape[1]
         best_in = best_p = None
@@ -149,7 +258,7 @@ def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_slidi
                 if use_sliding_window and t_in.shape[1] >= sliding_window:
                     t_start += 1
                     t_pos = t_pos[:, 1:]
-                logits = model.decode(t_in[:, t_start:].contiguous(), enc, t_pos)[:, -1, :]
+                logits = last_logits(t_in, t_start, t_pos)
                 probs = torch.softmax(logits / temperature, dim=1)
                 if mode == "generate":
                     probs[:, end_token] = 0.0          # <end> removed from consideration
@@ -173,10 +282,12 @@ def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_slidi
             pos = t_pos
         if progress is not None:
             progress(hr_input.shape[1] - 1, total_seq)
+    tail.mark("windowed tail")
+    tail.report()
     return hr_input
 
 
-def _generate_batched(model, hr_input, enc, total_seq, temperature, use_sliding_window,
+def _generate_batched(model, hr_input, last_logits, total_seq, temperature, use_sliding_window,
                       sliding_window, end_token, shift, num_beam, beam_width, mode, progress,
                       stop_len, pos_off, pos):
     """Same search, with the `num_beam` independent candidate chunks evaluated as ONE batch
@@ -185,7 +296,6 @@ def _generate_batched(model, hr_input, enc, total_seq, temperature, use_sliding_
     different order, so samples differ from the sequential loop for a given seed."""
     device = hr_input.device
     N, B = hr_input.shape[0], num_beam
-    enc_b = enc.repeat_interleave(B, dim=0) if enc is not None else None
     start = 0
     rows = torch.arange(N * B, device=device)
     while hr_input.shape[1] < stop_len:
@@ -198,7 +308,7 @@ def _generate_batched(model, hr_input, enc, total_seq, temperature, use_sliding_
             if use_sliding_window and t_in.shape[1] >= sliding_window:
                 t_start += 1
                 t_pos = t_pos[:, 1:]
-            logits = model.decode(t_in[:, t_start:].contiguous(), enc_b, t_pos)[:, -1, :]
+            logits = last_logits(t_in, t_start, t_pos)
             probs = torch.softmax(logits / temperature, dim=1)
             if mode == "generate":
                 probs[:, end_token] = 0.0

@@ -64,7 +64,7 @@ def main():
         else:
             for g in optim.param_groups:
                 g["lr"] = model_lr
-    parallel.broadcast_params(optim.flat_param)
+    parallel.broadcast_params(optim)
     dataset = ImageDataset(dataset_path=args["dataset_path"])
     loader = cc.ShardedLoader(dataset, args["batch_size"], num_workers=4, shuffle=True)
     info(f"{project_name}")

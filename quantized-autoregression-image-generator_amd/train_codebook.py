@@ -64,7 +64,7 @@ def main():
                             init_neighbour_range=cfg["num_embeddings"] // 2)
     codebook = codebook.to(device)
     optim = FlatAdam(codebook.parameters(), lr=model_lr, betas=(0.5, 0.999))
-    parallel.broadcast_params(optim.flat_param)
+    parallel.broadcast_params(optim)
     dataset = FeatureMapDataset(dataset_path=args["dataset_path"], load_image=False,
                                 return_filepaths=False)
     loader = cc.ShardedLoader(dataset, args["batch_size"], num_workers=4, shuffle=True)

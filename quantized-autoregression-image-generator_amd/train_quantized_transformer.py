@@ -125,7 +125,7 @@ def main():
         else:
             for g in optim.param_groups:
                 g["lr"] = model_lr
-    parallel.broadcast_params(optim.flat_param)
+    parallel.broadcast_params(optim)
     optim.enable_allreduce_overlap()     # no-op at world 1
 
     dataset = FeatureMapDataset(dataset_path=args["dataset_path"], load_image=False,

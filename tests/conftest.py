@@ -62,3 +62,71 @@ def grad_err(a, b, floor=1e-6):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(floor))
+
+
+class DrawTape:
+    """Sampling draws of one generation run replayed into another.  `record(fn)` runs fn with
+    torch.multinomial wrapped and keeps every probability matrix it sampled from and the tokens it drew (one
+    segment per call); `replay(i, fn, sampler)` runs fn with segment i's tokens injected -- the fused sampler's
+    draws through qarig.sampling.FUSED_DEBUG (forced tokens, probability log), every torch.multinomial call of the
+    run through the patched function -- and requires the probabilities at EVERY draw to equal the recorded ones
+    within `tol`, and the run to make exactly the recorded number of draws."""
+
+    def __init__(self, monkeypatch, tol=1e-5):
+        self.mp, self.tol, self.segments = monkeypatch, tol, []
+        self.real = torch.multinomial
+        self.worst = 0.0
+        self.fused_draws = 0
+
+    def add_segment(self, probs, tokens):
+        self.segments.append([(p, t.reshape(-1)) for p, t in zip(probs, tokens)])
+
+    def record(self, fn):
+        seg = []
+
+        def rec(probs, num_samples, *a, **k):
+            out = self.real(probs, num_samples, *a, **k)
+            seg.append((probs.detach().clone(), out.detach().clone().reshape(-1)))
+            return out
+
+        self.mp.setattr(torch, "multinomial", rec)
+        try:
+            r = fn()
+        finally:
+            self.mp.setattr(torch, "multinomial", self.real)
+        self.segments.append(seg)
+        return r
+
+    def replay(self, i, fn, sampler="fused"):
+        from qarig import sampling
+        seg = self.segments[i]
+        state = {"d": 0}
+        if sampler == "fused":
+            sampling.FUSED_DEBUG = {"forced": torch.stack([t.cpu() for _, t in seg]), "log": True}
+
+        def inj(probs, num_samples, *a, **k):
+            d = (sampling.FUSED_DEBUG or {}).get("draws", 0) + state["d"]
+            assert num_samples == 1 and d < len(seg), "more draws than were recorded"
+            want, tok = seg[d]
+            err = float((probs.detach().cpu() - want.cpu()).abs().max())
+            self.worst = max(self.worst, err)
+            assert err < self.tol, f"draw {d}: probabilities differ from the recorded ones by {err}"
+            state["d"] += 1
+            return tok.to(probs.device)[:, None]
+
+        self.mp.setattr(torch, "multinomial", inj)
+        try:
+            r = fn()
+        finally:
+            dbg, sampling.FUSED_DEBUG = sampling.FUSED_DEBUG, None
+            self.mp.setattr(torch, "multinomial", self.real)
+        fused = int((dbg or {}).get("draws", 0))
+        if fused:
+            got = dbg["probs"][:fused].cpu()
+            want = torch.stack([p.cpu() for p, _ in seg[:fused]])
+            err = float((got - want).abs().max())
+            self.worst = max(self.worst, err)
+            assert err < self.tol, f"fused sampler: probabilities differ from the recorded ones by {err}"
+        assert fused + state["d"] == len(seg), f"{fused} + {state['d']} draws made, {len(seg)} recorded"
+        self.fused_draws = fused
+        return r

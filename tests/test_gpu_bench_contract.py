@@ -12,7 +12,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-        "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+        "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "configs"}
 
 
 def test_bench_line_contract():
@@ -37,6 +37,22 @@ def test_bench_line_contract():
     cb = out["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] in ("port", "reference")
     assert cb["value"] > 0 and cb["cores"] >= 1
+    # the other BASELINE configurations on the same line: cascade generation (config 3), the per-GPU shards of
+    # configs 4 and 5 -- a few steps each, measured by child runs of this script
+    side = out["configs"]
+    assert set(side) == {"c3", "c4_shard", "c5_shard"}
+    for name, o in side.items():
+        assert "error" not in o, (name, o)
+        assert {"workload", "value", "unit", "ms_per_step", "dtype", "roofline"} <= set(o), name
+        assert o["value"] > 0 and o["ms_per_step"] > 0
+        assert {"bound", "achieved", "peak", "unit", "frac"} <= set(o["roofline"]), name
+    c3 = side["c3"]
+    assert {"sequential", "batched_beams", "decode_step_ms_rows4", "decode_step_ms_rows16",
+            "decoder_images_per_s"} <= set(c3)
+    assert c3["sequential"]["accepted_tokens_per_s"] == c3["value"] and c3["roofline"]["bound"] == "hbm"
+    assert c3["batched_beams"]["accepted_tokens_per_s"] > c3["value"]
+    assert side["c4_shard"]["dtype"] == "f32" and side["c5_shard"]["dtype"].startswith("bf16")
+    assert side["c4_shard"]["roofline"]["bound"] == side["c5_shard"]["roofline"]["bound"] == "mfma"
 
 
 def test_graft_entry_smoke():

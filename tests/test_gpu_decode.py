@@ -115,3 +115,163 @@ def test_skinny_entry_points_route_small_batches_to_the_streaming_kernel():
     for a, c in zip(outs[1], outs[0]):
         assert rel_err(a, c) < 2e-6
     assert torch.equal(outs[1][0], ops.decode_linear(x, W, b, act=1))
+
+
+def test_decode_embed_row_and_position_table():
+    from qarig import ops
+    g = torch.Generator().manual_seed(2)
+    B, D, V, L, PD = 5, 64, 33, 12, 7 * 64
+    table = torch.randn((V, D), generator=g).cuda()
+    pe = torch.randn((L, D), generator=g).cuda()
+    proj = torch.randn((L, PD), generator=g).cuda()
+    ids = torch.randint(0, V, (B,), generator=g).cuda()
+    row = torch.zeros(PD, device="cuda")
+    ctl = torch.zeros(ops.DECODE_CTL_WORDS, dtype=torch.int32, device="cuda")
+    for length in (0, 5, L - 1):
+        x = ops.decode_embed(ids, table, pe, length=length, proj_table=proj, proj_row=row)
+        assert torch.equal(x, table[ids] + pe[length]) and torch.equal(row, proj[length])
+        ctl[0] = length
+        steps = int(ctl[4])
+        x2 = ops.decode_embed(ids, table, pe, ctl=ctl, length=99, proj_table=proj, proj_row=row)   # ctl wins
+        assert torch.equal(x2, x) and int(ctl[4]) == steps + 1                                       # and counts the step
+    assert torch.equal(ops.decode_embed(ids, table, None, length=0), table[ids])
+    ops.check_index_flag(torch.device("cuda"), "valid ids")
+    bad = ids.clone()
+    bad[2] = V
+    x = ops.decode_embed(bad, table, pe, length=1)
+    assert not x[2].any() and torch.equal(x[0], table[ids[0]] + pe[1])
+    with pytest.raises(IndexError):
+        ops.check_index_flag(torch.device("cuda"), "decode_embed")
+
+
+def _sample_once(logits, T, end, gen, shift, uniforms, ctl, slot, bw, forced=None, log=True, inc=False):
+    from qarig import ops
+    B, V = logits.shape
+    ids = torch.zeros(B, dtype=torch.int64, device="cuda")
+    chunk = torch.full((B, bw), -7, dtype=torch.int64, device="cuda")
+    comb = torch.full((B,), 0.5, device="cuda")
+    probs = torch.zeros((uniforms.shape[0], B, V), device="cuda") if log else None
+    ops.decode_sample(logits, T, end, gen, shift, uniforms, ctl, slot, bw, ids, chunk, comb, forced=forced,
+                      probs_log=probs, inc_len=inc)
+    return ids, chunk, comb, probs
+
+
+@pytest.mark.parametrize("V", [513, 8193, 41, 3])
+def test_decode_sample_is_the_references_draw(V):
+    """softmax(logits / T), <end> zeroed (generate mode), a token by inverse CDF of the row's uniform, the running
+    product, the train-mode <end> -> 0 hack, forced tokens, the counters (generate_images.py:289-304)."""
+    from qarig import ops
+    g = torch.Generator().manual_seed(V)
+    B, bw, draws, end, T = 6, 4, 5, V - 1, 0.7
+    logits = (torch.randn((B, V), generator=g) * 3).cuda()
+    uniforms = torch.rand((draws, B), generator=g).cuda()
+    uniforms[3, 0], uniforms[3, 1] = 0.0, 0.99999994      # the ends of the interval
+    ctl = torch.zeros(ops.DECODE_CTL_WORDS, dtype=torch.int32, device="cuda")
+    for d, slot in ((0, 0), (1, 1), (3, 3)):
+        ctl[2] = d - slot
+        ctl[0] = 10
+        ids, chunk, comb, probs = _sample_once(logits, T, end, True, 100, uniforms, ctl, slot, bw, inc=slot > 0)
+        assert int(ctl[0]) == (11 if slot > 0 else 10) and int(ctl[2]) == d - slot
+        want = torch.softmax(logits.double() / T, dim=1)
+        want[:, end] = 0
+        assert float((probs[d].double() - want).abs().max()) < 1e-6 and not probs[[i for i in range(draws) if i != d]].any()
+        tok = ids - 100
+        assert int(tok.min()) >= 0 and int(tok.max()) < V and not (tok == end).any()
+        assert torch.equal(chunk[:, slot], ids) and (chunk[:, [s for s in range(bw) if s != slot]] == -7).all()
+        cdf = torch.cumsum(want, dim=1)
+        target = uniforms[d].double() * cdf[:, -1]
+        rows = torch.arange(B, device="cuda")
+        hi = cdf[rows, tok]
+        lo = hi - want[rows, tok]
+        assert ((lo - 1e-6 <= target) & (target < hi + 1e-6)).all(), "token outside its CDF interval"
+        assert (want[rows, tok] > 0).all()
+        assert float((comb.double() - 0.5 * want[rows, tok]).abs().max()) < 1e-6
+    # slot -1: the slot is the device's step counter
+    ctl[2], ctl[4] = 1, 2
+    ids, chunk, comb, probs = _sample_once(logits, T, end, True, 0, uniforms, ctl, -1, bw)
+    assert probs[3].any() and not probs[[0, 1, 2, 4]].any() and torch.equal(chunk[:, 2], ids) and (chunk[:, 3] == -7).all()
+    ctl[4] = 0
+    # forced tokens replace the draw (entries < 0 do not); train mode keeps <end> in play and maps it to 0
+    forced = torch.full((draws, B), -1, dtype=torch.int64, device="cuda")
+    forced[2] = torch.tensor([0, 1 % V, end, -1, 2 % V, end], device="cuda")
+    ctl[2] = 2
+    ids, chunk, comb, probs = _sample_once(logits, T, end, False, 0, uniforms, ctl, 0, bw, forced=forced)
+    want = torch.softmax(logits.double() / T, dim=1)
+    assert float((probs[2].double() - want).abs().max()) < 1e-6
+    assert ids[0] == 0 and ids[1] == 1 % V and ids[2] == 0 and ids[5] == 0      # <end> -> 0
+    assert ids[4] == (0 if 2 % V == end else 2 % V)
+    assert float((comb[2].double() - 0.5 * want[2, end])).__abs__() < 1e-6           # the product saw p[<end>]
+
+
+def test_decode_sample_frequencies_follow_the_distribution():
+    from qarig import ops
+    g = torch.Generator().manual_seed(0)
+    B, V, bw = 4096, 9, 1
+    logits = torch.tensor([0.3, -1.0, 2.0, 0.0, 1.0, -3.0, 0.5, 0.1, 5.0]).repeat(B, 1).cuda()
+    uniforms = torch.rand((1, B), generator=g).cuda()
+    ctl = torch.zeros(ops.DECODE_CTL_WORDS, dtype=torch.int32, device="cuda")
+    ids, _, _, probs = _sample_once(logits, 1.0, V - 1, True, 0, uniforms, ctl, 0, bw)
+    p = probs[0, 0].double().cpu()
+    p = p / p.sum()
+    freq = torch.bincount(ids.cpu(), minlength=V).double() / B
+    sigma = torch.sqrt(p * (1 - p) / B)
+    assert freq[V - 1] == 0 and ((freq - p).abs() <= 4.5 * sigma + 1e-12).all(), (freq, p)
+
+
+@pytest.mark.parametrize("N,NB,bw", [(4, 1, 4), (3, 4, 4), (5, 2, 1), (2, 3, 2)])
+def test_chunk_bookkeeping_kernels_follow_the_reference_rule(N, NB, bw):
+    """decide / rows / commit / advance against generate_images.py:325-345 restated in torch: per image keep the
+    earlier candidate unless the new product is larger; the kept chunk's cache rows become every beam's rows;
+    its tokens join the sequence; the counters move to the next chunk."""
+    from qarig import ops
+    g = torch.Generator().manual_seed(N * 10 + NB)
+    B, layers, max_len, H, d, cur = N * NB, 3, 12, 2, 8, 5
+    R = max(bw - 1, 1)
+    kv = torch.randn((layers, 2, B, H, max_len, d), generator=g).cuda()
+    staged = torch.zeros((layers, 2, N, H, R, d), device="cuda")
+    tokens = torch.zeros((N, max_len + bw), dtype=torch.int64, device="cuda")
+    ids = torch.zeros(B, dtype=torch.int64, device="cuda")
+    best_p = torch.zeros(N, device="cuda")
+    best_chunk = torch.zeros((N, bw), dtype=torch.int64, device="cuda")
+    take = torch.zeros(N, dtype=torch.int32, device="cuda")
+    ctl = torch.zeros(ops.DECODE_CTL_WORDS, dtype=torch.int32, device="cuda")
+    ctl[0], ctl[1], ctl[2] = cur + bw - 1, cur, 40
+    ref_p, ref_chunk, ref_rows = None, None, None
+    cands = 3 if NB == 1 else 1
+    for c in range(cands):
+        comb = torch.rand(B, generator=g).cuda()
+        if c == 1:
+            comb[0] = ref_p[0]            # a tie keeps the earlier candidate
+        chunk = torch.randint(0, 50, (B, bw), generator=g).cuda()
+        kv[:, :, :, :, cur:cur + bw - 1] = torch.randn((layers, 2, B, H, bw - 1, d), generator=g).cuda()
+        cv = comb.view(N, NB)
+        pb = cv.argmax(dim=1)
+        cbest = cv.max(dim=1).values
+        pick = torch.arange(N, device="cuda") * NB + pb
+        if ref_p is None:
+            tk = torch.ones(N, dtype=torch.bool, device="cuda")
+        else:
+            tk = ~(ref_p >= cbest)
+        new_rows = kv[:, :, pick, :, cur:cur + bw - 1].clone()
+        ref_p = cbest.clone() if ref_p is None else torch.where(tk, cbest, ref_p)
+        ref_chunk = chunk[pick].clone() if ref_chunk is None else torch.where(tk[:, None], chunk[pick], ref_chunk)
+        ref_rows = new_rows if ref_rows is None else torch.where(tk[None, None, :, None, None, None], new_rows, ref_rows)
+        ops.decode_decide(ctl, N, NB, bw, comb, chunk, best_p, best_chunk, take)
+        assert torch.equal(take.bool(), tk) and torch.equal(take[tk].long() - 1, pb[tk])
+        assert (comb == 1).all() and int(ctl[3]) == c + 1 and int(ctl[2]) == 40 + (c + 1) * bw and int(ctl[0]) == cur
+        if bw > 1:
+            ops.decode_rows(ctl, kv, staged, take, N, NB, restore=False)
+        assert torch.equal(best_p, ref_p) and torch.equal(best_chunk, ref_chunk)
+        if bw > 1:
+            assert torch.equal(staged, ref_rows)
+    before = kv.clone()
+    if bw > 1:
+        ops.decode_rows(ctl, kv, staged, take, N, NB, restore=True)
+        want = before.clone()
+        want[:, :, :, :, cur:cur + bw - 1] = ref_rows.repeat_interleave(NB, dim=2)
+        assert torch.equal(kv, want)
+    ops.decode_commit(ctl, N, NB, bw, best_chunk, tokens, ids)
+    assert torch.equal(tokens[:, cur:cur + bw], ref_chunk) and not tokens[:, :cur].any() and not tokens[:, cur + bw:].any()
+    assert torch.equal(ids, ref_chunk[:, -1].repeat_interleave(NB)) and int(ctl[0]) == cur + bw - 1
+    ops.decode_advance(ctl, bw)
+    assert ctl[:4].tolist() == [cur + bw, cur + bw, 40 + cands * bw, 0]

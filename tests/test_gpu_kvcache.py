@@ -28,8 +28,8 @@ def _model(use_encoder, adaln0=False, heads=8, dim=64, hidden=128, layers=2, voc
 def test_attention_decode_matches_full_attention():
     from qarig import ops
     torch.manual_seed(0)
-    for heads, d in ((8, 8), (4, 16), (2, 64), (16, 4)):
-        B, L, D, Lmax = 5, 150, heads * d, 160
+    for heads, d, L in ((8, 8, 150), (4, 16, 150), (2, 64, 150), (16, 4, 150), (3, 32, 150), (64, 8, 700), (6, 16, 300)):
+        B, D, Lmax = 5, heads * d, L + 10
         q = torch.randn(B, 1, D, device="cuda")
         k = torch.randn(B, L + 1, D, device="cuda")
         v = torch.randn(B, L + 1, D, device="cuda")
@@ -53,6 +53,18 @@ def test_attention_decode_matches_full_attention():
         mul = torch.randn(B, D, device="cuda")
         got4 = ops.attention_decode(q[:, 0].contiguous(), None, None, kc, vc, L + 1, heads, o_mul=mul)
         assert rel_err(got4, want * mul) < 1e-5
+        got5 = ops.attention_decode(q[:, 0].contiguous(), None, None, kc, vc, L + 1, heads, o_mul=mul[0].contiguous())
+        assert rel_err(got5, want * mul[0]) < 1e-5          # one gate row for every sequence
+        # head-major cache (B, H, max_len, d) -- DecodeCache's layout: append + attend, then read-only
+        hm = lambda t: t.reshape(B, Lmax, heads, d).permute(0, 2, 1, 3).contiguous()
+        kh, vh = hm(kc), hm(vc)
+        kh[:, :, L], vh[:, :, L] = 0.0, 0.0
+        got6 = ops.attention_decode(q[:, 0].contiguous(), k[:, L].contiguous(), v[:, L].contiguous(), kh, vh, L, heads,
+                                    o_mul=mul)
+        assert rel_err(got6, want * mul) < 1e-5
+        assert torch.equal(kh, hm(kc)) and torch.equal(vh, hm(vc))      # the new row landed in every head's run
+        got7 = ops.attention_decode(q[:, 0].contiguous(), None, None, kh, vh, 0, heads, len_dev=ln)
+        assert rel_err(got7, want) < 1e-5
 
 
 def test_grouped_skinny_gemm():
@@ -187,13 +199,18 @@ def test_decode_cache_step_matches_full_window(use_encoder, graph, wide):
             cache.step(ids[:, 0], pos[:, 0], S)
 
 
+@pytest.mark.parametrize("sampler", ["torch", "fused"])
 @pytest.mark.parametrize("use_encoder,num_beam,bw,batch_beams,wide", [
     (False, 1, 1, False, False), (False, 3, 4, False, False), (True, 2, 4, False, False),
     (True, 3, 2, True, False), (False, 2, 4, True, False), (True, 2, 4, False, True),
     (True, 3, 2, True, True)])
-def test_cached_generation_matches_full_window_loop(use_encoder, num_beam, bw, batch_beams, wide):
-    """Same seed, same draw order: the cached loop (then its windowed continuation once the
-    window slides) must emit the tokens of the reference-style full-window loop."""
+def test_cached_generation_matches_full_window_loop(use_encoder, num_beam, bw, batch_beams, wide, sampler,
+                                                    monkeypatch):
+    """The cached loop (then its windowed continuation once the window slides) must emit the tokens of the
+    reference-style full-window loop.  sampler "torch": same seed, same torch.multinomial call order;
+    "fused": the full-window run's draws are recorded and forced into the in-graph sampler, whose probability
+    row must equal the recorded one at every draw."""
+    from conftest import DrawTape
     from qarig import sampling
     m = _model(use_encoder, heads=32, dim=256, hidden=512) if wide else _model(use_encoder)
     with torch.no_grad():
@@ -202,12 +219,18 @@ def test_cached_generation_matches_full_window_loop(use_encoder, num_beam, bw, b
     g = torch.Generator().manual_seed(4)
     lr_in = torch.randint(0, 40, (N, 6), generator=g).cuda() if use_encoder else None
     first = torch.randint(0, 40, (N, 1), generator=g).cuda()
-    outs = []
-    for cached in (False, True):
+
+    def run(cached):
         torch.manual_seed(11)
-        outs.append(sampling.generate_tokens(m, first, lr_in, total, 0.05, True, sw, end_token=40,
-                                             num_beam=num_beam, beam_width=bw, mode="generate",
-                                             batch_beams=batch_beams, use_kv_cache=cached))
+        return sampling.generate_tokens(m, first, lr_in, total, 0.05, True, sw, end_token=40,
+                                        num_beam=num_beam, beam_width=bw, mode="generate",
+                                        batch_beams=batch_beams, use_kv_cache=cached, sampler=sampler)
+    if sampler == "torch":
+        outs = [run(False), run(True)]
+    else:
+        tape = DrawTape(monkeypatch, tol=2e-5)
+        outs = [tape.record(lambda: run(False)), tape.replay(0, lambda: run(True))]
+        assert tape.fused_draws > 0
     assert outs[0].shape[1] >= total       # the loop overshoots to 1 + k*beam_width
     assert torch.equal(outs[0], outs[1])
 
@@ -230,16 +253,24 @@ def test_generation_with_head_dim_without_a_cache_kernel():
     assert torch.equal(outs[0], outs[1]) and outs[0].shape[1] >= 12
 
 
-def test_cached_train_mode_sampling_matches():
+@pytest.mark.parametrize("sampler", ["torch", "fused"])
+def test_cached_train_mode_sampling_matches(sampler, monkeypatch):
+    from conftest import DrawTape
     from qarig import sampling
     m = _model(False)
     N, total, sw = 2, 20, 32
     first = torch.randint(0, 40, (N, 1), generator=torch.Generator().manual_seed(9)).cuda()
-    outs = []
-    for cached in (False, True):
+
+    def run(cached):
         torch.manual_seed(5)
-        outs.append(sampling.generate_tokens(m, first, None, total, 0.05, True, sw, end_token=40,
-                                             mode="train", use_kv_cache=cached))
+        return sampling.generate_tokens(m, first, None, total, 0.05, True, sw, end_token=40,
+                                        mode="train", use_kv_cache=cached, sampler=sampler)
+    if sampler == "torch":
+        outs = [run(False), run(True)]
+    else:
+        tape = DrawTape(monkeypatch, tol=2e-5)
+        outs = [tape.record(lambda: run(False)), tape.replay(0, lambda: run(True))]
+        assert tape.fused_draws > 0
     assert outs[0].shape == (N, total + 1)
     assert torch.equal(outs[0], outs[1])
 
@@ -272,43 +303,37 @@ def test_config3_cascade_three_stages_readme_size_cached_equals_full_window(monk
                     p.copy_(torch.randn(p.shape, generator=g) * 0.02)
         return m.cuda().eval()
 
-    real_multinomial = torch.multinomial
-    record = []
+    from conftest import DrawTape
+    tape = DrawTape(monkeypatch)
 
-    def recording(probs, num_samples, *a, **k):
-        out = real_multinomial(probs, num_samples, *a, **k)
-        record.append((probs.detach().clone(), out.detach().clone()))
-        return out
-
-    state = {"d": 0, "worst": 0.0}
-
-    def injected(probs, num_samples, *a, **k):
-        want_p, tok = record[state["d"]]
-        err = float((probs - want_p).abs().max())
-        state["worst"] = max(state["worst"], err)
-        assert err < 1e-5, f"draw {state['d']}: cached probabilities differ by {err}"
-        state["d"] += 1
-        return tok
-
-    results = {}
-    for cached in (False, True):
-        monkeypatch.setattr(torch, "multinomial", injected if cached else recording)
+    def cascade(mode):
+        """mode None: the reference's algorithm, every stage recorded as one tape segment; else the cached
+        loop with that sampler, every stage replayed from its segment."""
         torch.manual_seed(69)
         prev = torch.randint(0, K, (N, 1), generator=torch.Generator().manual_seed(7)).cuda()
-        per_stage = []
+        per_stage, fused = [], 0
         for s in range(3):
             base = s == 0
             m = stage_model(s)
             first = prev if base else torch.full((N, 1), K, dtype=torch.int64, device="cuda")
-            toks = sampling.generate_tokens(m, first, None if base else prev, seqs[s], 1.0, True, 256,
-                                            end_token=K, shift=K if base else 0, num_beam=4, beam_width=4,
-                                            mode="generate", use_kv_cache=cached)
+            run = lambda: sampling.generate_tokens(m, first, None if base else prev, seqs[s], 1.0, True, 256,
+                                                   end_token=K, shift=K if base else 0, num_beam=4, beam_width=4,
+                                                   mode="generate", use_kv_cache=mode is not None, sampler=mode)
+            toks = tape.record(run) if mode is None else tape.replay(s, run, mode)
+            fused += tape.fused_draws if mode is not None else 0
             assert toks.shape[1] >= seqs[s]
             prev = (toks[:, 1:] - (K if base else 0))[:, :seqs[s]].contiguous()
             assert int(prev.min()) >= 0 and int(prev.max()) < K, "<end> or an out-of-vocabulary id was emitted"
             per_stage.append(prev.clone())
             del m
-        results[cached] = per_stage
-    assert state["d"] == len(record) == sum(seqs) * 4          # num_beam draws per accepted token
-    for s in range(3):
-        assert torch.equal(results[False][s], results[True][s]), s
+        return per_stage, fused
+
+    want, _ = cascade(None)
+    assert sum(len(seg) for seg in tape.segments) == sum(seqs) * 4          # num_beam draws per accepted token
+    for mode in ("torch", "fused"):
+        got, fused = cascade(mode)
+        # the fused sampler makes every draw but those of the last chunk of the 256-token stage, where the window
+        # starts to slide (its 4 candidates x 4 tokens come from cache steps + one full-window evaluation each)
+        assert fused == (sum(seqs) * 4 - 16 if mode == "fused" else 0)
+        for s in range(3):
+            assert torch.equal(want[s], got[s]), (mode, s)

@@ -86,8 +86,12 @@ def test_train_step_matches_reference_step(tag, table):
 
 
 @pytest.mark.parametrize("tag", ["base", "encdec"])
-@pytest.mark.parametrize("use_kv_cache", [False, True])
-def test_generation_loop_matches_reference_draw_by_draw(tag, use_kv_cache, monkeypatch):
+@pytest.mark.parametrize("loop", ["window", "cache-torch", "cache-fused"])
+def test_generation_loop_matches_reference_draw_by_draw(tag, loop, monkeypatch):
+    """The reference's sampling loop (generate_images.py:256-345) replayed draw by draw: full-window loop,
+    KV-cache loop with one torch.multinomial call per token, KV-cache loop with the fused in-graph sampler
+    (the reference's recorded tokens forced, its probability rows compared with the kernel's log)."""
+    from conftest import DrawTape
     from qarig import sampling
     g = load_golden("generation_" + tag)
     base = tag == "base"
@@ -95,25 +99,16 @@ def test_generation_loop_matches_reference_draw_by_draw(tag, use_kv_cache, monke
     m = _tiny(not base, K_lr + K_hr if base else K_hr + 1, K_lr, K_hr + 1)
     m.custom_load_state_dict(g["sd"])
     m = m.cuda().eval()
-    state = {"d": 0, "worst": 0.0}
-    probs_ref, toks_ref = g["draw_probs"], g["draw_tokens"]
-
-    def injected(probs, num_samples, *a, **k):
-        d = state["d"]
-        assert num_samples == 1 and d < toks_ref.shape[0], "more draws than the reference made"
-        err = float((probs.detach().cpu() - probs_ref[d]).abs().max())
-        state["worst"] = max(state["worst"], err)
-        assert err < 1e-5, f"draw {d}: probabilities differ from the reference's by {err}"
-        state["d"] = d + 1
-        return toks_ref[d].to(probs.device)[:, None]
-
-    monkeypatch.setattr(torch, "multinomial", injected)
-    got = sampling.generate_tokens(
+    tape = DrawTape(monkeypatch)
+    tape.add_segment(g["draw_probs"], g["draw_tokens"])
+    sampler = "fused" if loop == "cache-fused" else "torch"
+    got = tape.replay(0, lambda: sampling.generate_tokens(
         m, g["first_token"].cuda(), None if base else g["lr_input"].cuda(), int(g["total_seq"]),
         float(g["temperature"]), True, int(g["sliding_window"]), end_token=K_hr,
         shift=K_lr if base else 0, num_beam=int(g["num_beam"]), beam_width=int(g["beam_width"]),
-        mode="generate", use_kv_cache=use_kv_cache)
-    assert state["d"] == toks_ref.shape[0], "fewer draws than the reference made"
+        mode="generate", use_kv_cache=loop != "window", sampler=sampler), sampler)
+    if loop == "cache-fused":
+        assert tape.fused_draws > 0, "the fused sampler never ran"
     final = got[:, 1:].cpu() - (K_lr if base else 0)
     assert torch.equal(final, g["final_tokens"])
     bw = int(g["beam_width"])

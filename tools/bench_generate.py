@@ -43,7 +43,7 @@ def run_cascade(args, dev, K, N, patches, prev):
                                         shift=K if base else 0, num_beam=args.num_beam,
                                         beam_width=args.beam_width, mode="generate",
                                         batch_beams=args.batch_beams,
-                                        use_kv_cache=not args.no_kv_cache)
+                                        use_kv_cache=not args.no_kv_cache, sampler=args.sampler)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         prev = toks[:, 1:] - (K if base else 0)
@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--beam-width", type=int, default=4)
     ap.add_argument("--batch-beams", action="store_true")
     ap.add_argument("--no-kv-cache", action="store_true")
+    ap.add_argument("--sampler", choices=["fused", "torch"], default=None,
+                    help="cached loop: in-graph sampling kernel (default) or one torch.multinomial per token")
     ap.add_argument("--cold", action="store_true",
                     help="skip the untimed warm-up pass (code-object loads, allocator growth, "
                          "first graph instantiation then land in stage 0)")
@@ -77,7 +79,7 @@ def main():
                      latent_channel=4).to(dev).eval()
     out = {"config": f"cascade generate, {args.stages} stages, N={N}, num_beam={args.num_beam}, "
                      f"beam_width={args.beam_width}, window 256, fp32, batch_beams={args.batch_beams}, "
-                     f"kv_cache={not args.no_kv_cache}, warm={not args.cold}"}
+                     f"kv_cache={not args.no_kv_cache}, sampler={args.sampler or sampling.DEFAULT_SAMPLER}, warm={not args.cold}"}
     prev0 = torch.randint(0, K, (N, 1), device=dev)
     if not args.cold:
         run_cascade(args, dev, K, N, patches, prev0)
