@@ -623,16 +623,31 @@ using namespace qarig;
         case 32: { constexpr int HD = 32; __VA_ARGS__; } break;                         \
         case 64: { constexpr int HD = 64; __VA_ARGS__; } break;                         \
         default:                                                                 \
-            qarig_set_error("attention: head dim %d unsupported (4,8,16,32,64)", d); \
+            qarig_set_error("attention: head dim %d unsupported (4,8,16,32,64,128)", d); \
             return QARIG_ERR_ARG;                                                \
     }
+
+// csrc/attention_wide.hip: head dim 128 (heads of 65 ... 128 arrive zero-padded), exact fp32 in every precision mode
+int qarig_attention_wide_fwd(const float* q, const float* k, const float* v, int N, int Sq, int Sk, int H,
+                             int causal, float sqrt_d, float* o, float* lse, hipStream_t st);
+int qarig_attention_wide_bwd(const float* q, const float* k, const float* v, const float* o, const float* dO,
+                             const float* lse, int N, int Sq, int Sk, int H, int causal, float sqrt_d, float* dq,
+                             float* dk, float* dv, float* delta, hipStream_t st);
+static int attn_wide_check(int N, int Sq, int Sk, int H, int causal) {
+    QARIG_CHECK_ARG(N > 0 && Sq > 0 && Sk > 0 && H > 0, "attention: bad extents");
+    QARIG_CHECK_DIMS("attention", N, Sq, H);
+    QARIG_CHECK_DIMS("attention", N, Sk, H);
+    QARIG_CHECK_ARG(H <= 65535 && N <= 65535, "attention (wide heads): more than 65535 heads or sequences");
+    QARIG_CHECK_ARG(!causal || Sq == Sk, "attention: causal needs Sq == Sk (self-attention)");
+    return QARIG_OK;
+}
 
 static int attn_check(int N, int Sq, int Sk, int H, int d, int causal) {
     QARIG_CHECK_ARG(N > 0 && Sq > 0 && Sk > 0 && H > 0 && d > 0, "attention: bad extents");
     QARIG_CHECK_DIMS("attention", N, Sq, H);
     QARIG_CHECK_DIMS("attention", N, Sk, H);
     QARIG_CHECK_ARG(d == 4 || d == 8 || d == 16 || d == 32 || d == 64,
-                    "attention: head dim %d unsupported (4,8,16,32,64)", d);
+                    "attention: head dim %d unsupported (4,8,16,32,64,128)", d);
     QARIG_CHECK_ARG((long long)N * ((H + 3) / 4) * ((Sq > Sk ? Sq : Sk) / 64 + 1) < (1LL << 31),
                     "attention: too many workgroups");
     QARIG_CHECK_ARG(!causal || Sq == Sk, "attention: causal needs Sq == Sk (self-attention)");
@@ -684,6 +699,11 @@ template <bool LP>
 static int attention_fwd_impl(const float* q, const float* k, const float* v, int N, int Sq, int Sk,
                               int H, int d, int causal, float sqrt_d, float* o, float* lse, void* stream) {
     QARIG_CHECK_ARG(q && k && v && o && lse, "attention_fwd: null pointer");
+    if (d == 128) {
+        if (int e = attn_wide_check(N, Sq, Sk, H, causal)) return e;
+        QARIG_CHECK_ARG(sqrt_d > 0.0f, "attention: sqrt_d must be positive");
+        return qarig_attention_wide_fwd(q, k, v, N, Sq, Sk, H, causal, sqrt_d, o, lse, (hipStream_t)stream);
+    }
     if (int e = attn_check(N, Sq, Sk, H, d, causal)) return e;
     AttnDims a{N, Sq, Sk, H, causal, 1.4426950408889634f / sqrt_d, 1.0f / sqrt_d};
     // measured (tools/attn_bench.py, 64 x 256 tokens, 64 heads of 8): W = 1 / 2 / 4 -> 100 / 100 /
@@ -709,6 +729,12 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
                               void* stream) {
     QARIG_CHECK_ARG(q && k && v && o && dO && lse && dq && dk && dv && delta,
                     "attention_bwd: null pointer");
+    if (d == 128) {
+        if (int e = attn_wide_check(N, Sq, Sk, H, causal)) return e;
+        QARIG_CHECK_ARG(sqrt_d > 0.0f, "attention: sqrt_d must be positive");
+        return qarig_attention_wide_bwd(q, k, v, o, dO, lse, N, Sq, Sk, H, causal, sqrt_d, dq, dk, dv, delta,
+                                        (hipStream_t)stream);
+    }
     if (int e = attn_check(N, Sq, Sk, H, d, causal)) return e;
     AttnDims a{N, Sq, Sk, H, causal, 1.4426950408889634f / sqrt_d, 1.0f / sqrt_d};
     const int hgroups = (H + HPB - 1) / HPB;

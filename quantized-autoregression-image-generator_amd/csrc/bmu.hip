@@ -1174,6 +1174,20 @@ __device__ __forceinline__ float bmu_join3(uint32_t H, uint32_t M, uint32_t L, i
     return (h + m) + l;
 }
 
+// Bound of |coarse value - the definition's fp32 chain| in units of (|x|^2 + 2 max|w|^2).  The derivation charges
+// every one of the 7 x 16 additions inside the matrix core a rounding of u = 2^-24 of the running magnitude
+// (gamma_112 = 6.7e-6 on sum|terms|), plus the dropped piece products (2^-26 |x||2w| per element) and the 17-step
+// rounding of the definition's own chain: 7.7e-6 in all.  What v_mfma_f32_32x32x16_bf16 really does was measured
+// (tools/mfma_rounding_probe.hip, profiles/r04_mfma_rounding.log): the 16 products and C are aligned to the
+// largest exponent among them with ONE guard bit, bits below it are dropped (a product of 0.75 ulp beside 1.0
+// contributes 0.5 ulp; sixteen products of 1/16 ulp beside C = 1 vanish), the sum is then rounded to nearest even
+// (C = 1 plus 0.75 ulp gives 1 + 1 ulp, ties go to even).  Worst case per instruction: 16 x 2^-25 of the largest
+// addend from the alignment + 2^-24 from the final rounding = 9 u of it, i.e. 63 u over the seven instructions --
+// inside the 112 u the derivation charges.  So eps = 1e-5 stands; with the certificate's factor 3 the remaining true
+// gap exceeds 1.4e-5 of the scale, far above what clamp + sqrt can collapse (2^-22).  (2e-5 was tried: the 65,536 x
+// 512 x 16 launch re-scans 148 rows instead of 73 and takes 18.4 instead of 16.3 us.)
+// tests/test_gpu_core.py::test_bmu_coarse_pass_on_constructed_near_ties sweeps code pairs whose gap runs from
+// far below eps to above 4 eps.
 constexpr float BMU_COARSE_EPS = 1e-5f;
 
 // PREP: stages the image of a codebook (what every block of the search kernel builds in LDS) into

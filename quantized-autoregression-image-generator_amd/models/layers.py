@@ -239,7 +239,7 @@ class AttentionLayer(nn.Module):
         super().__init__()
         if in_dim % heads or ops.attention_head_dim(in_dim // heads) is None:
             # the reference accepts any divisor of in_dim; head dims that are not instantiated run
-            # zero-padded on the next one (QF.attention), only heads wider than 64 have no kernel
+            # zero-padded on the next one (QF.attention), only heads wider than 128 have no kernel
             raise ValueError(f"AttentionLayer: in_dim {in_dim} / heads {heads} gives head dim "
                              f"{in_dim / heads:g}; the MI355X kernels serve head dims up to "
                              f"{ops.ATTENTION_HEAD_DIMS[-1]} that divide in_dim")

@@ -567,7 +567,8 @@ def _pad_heads(t, heads, d, dp):
 
 def attention(q, k, v, heads, causal):
     """The reference accepts any `heads` that divides the model width (models/layers.py:433); the kernels
-    are instantiated for head dims 4, 8, 16, 32 and 64.  Any other head dim up to 64 runs on the next
+    are instantiated for head dims 4, 8, 16, 32, 64 (MFMA, csrc/attention.hip) and 128 (vector-ALU fma chains,
+    csrc/attention_wide.hip: the rare few-heads model).  Any other head dim up to 128 runs on the next
     instantiated one with every head zero-padded: the extra columns add exact zeros to q.k and produce
     output columns that are dropped again (softmax scale from the model's head dim), so the result is the
     reference's; pad and slice are torch ops (a rare shape: not a hot path)."""
@@ -676,7 +677,7 @@ class _Conv2dAct(torch.autograd.Function):
         if need and act:
             y, pre = ops.conv2d_fwd(x, weight, bias, stride, pad, act, want_preact=True)
         else:
-            y, pre = ops.conv2d_fwd(x, weight, bias, stride, pad, act, inference=not need), None
+            y, pre = ops.conv2d_fwd(x, weight, bias, stride, pad, act), None
         ctx.save_for_backward(x, weight, pre)
         ctx.cfg = (stride, pad, act, bias is not None)
         return y
@@ -691,6 +692,13 @@ class _Conv2dAct(torch.autograd.Function):
 
 
 def conv2d_act(x, weight, bias, stride=1, pad=1, act=0):
+    # decided HERE: inside an autograd.Function.forward grad mode is always off.  No grad: the weights are
+    # constants between optimiser steps, their re-ordered copies are cached per weight (ops._conv_workspace);
+    # a training forward re-orders into the shared scratch on every call
+    if _no_grad():
+        require_cuda(x, weight, bias)
+        assert weight.is_contiguous() and weight.dtype == torch.float32, "conv weight must be dense fp32"
+        return ops.conv2d_fwd(f32c(x), weight, bias, stride, pad, act, inference=True)
     return _Conv2dAct.apply(x, weight, bias, stride, pad, act)
 
 
@@ -706,7 +714,7 @@ class _ConvT2dAct(torch.autograd.Function):
         if need and act:
             y, pre = ops.conv_transpose2d_fwd(x, weight, bias, act, want_preact=True)
         else:
-            y, pre = ops.conv_transpose2d_fwd(x, weight, bias, act, inference=not need), None
+            y, pre = ops.conv_transpose2d_fwd(x, weight, bias, act), None
         ctx.save_for_backward(x, weight, pre)
         ctx.cfg = (act, bias is not None)
         return y
@@ -720,6 +728,10 @@ class _ConvT2dAct(torch.autograd.Function):
 
 
 def conv_transpose2d_act(x, weight, bias, act=0):
+    if _no_grad():          # (see conv2d_act)
+        require_cuda(x, weight, bias)
+        assert weight.is_contiguous() and weight.dtype == torch.float32, "conv weight must be dense fp32"
+        return ops.conv_transpose2d_fwd(f32c(x), weight, bias, act, inference=True)
     return _ConvT2dAct.apply(x, weight, bias, act)
 
 

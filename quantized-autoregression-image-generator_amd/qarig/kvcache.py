@@ -43,6 +43,8 @@ from . import ops
 # per encoder-decoder layer and token.  False: the separate launches (the tests compare both).
 FUSE_NORMS = True
 
+_WARM_SHAPES = set()        # step shapes that have run eagerly once in this process (begin_search)
+
 
 def _rows(t, B):
     """A (D,) row of the per-position table as the (B, D) operand the general kernels take."""
@@ -411,12 +413,22 @@ class DecodeCache:
         s.ids.copy_(first.repeat_interleave(NB))
         self.ctl.zero_()
         s.gen, s.T, s.end, s.shift = bool(generate_mode), float(temperature), int(end_token), int(shift)
-        # the first token's step, eagerly (it sizes the workspaces; a capture records without running)
-        self._forward(s.ids, None, 0, self.ctl, out=s.logits)
-        s.last.copy_(s.logits)
+        # A capture records launches without running them, and the first launch of a kernel in a process (code
+        # object load) or a workspace that has to grow cannot happen inside one: the first step of a given
+        # shape in this process runs eagerly once; later stages of that shape go straight to the capture and
+        # evaluate their first token by replaying it.
+        sig = (B, D, V, self.heads, len(self.model.decoder_layers), tuple(c is not None for c in self.cross),
+               self._table is not None, self._stacked, FUSE_NORMS,
+               tuple(k.shape[2] for c in self.cross if c is not None for k in c[:1]))
+        if sig not in _WARM_SHAPES:
+            self._forward(s.ids, None, 0, self.ctl, out=s.logits)
+            self.ctl.zero_()
+            _WARM_SHAPES.add(sig)
         s.g_step = torch.cuda.CUDAGraph()
         with torch.cuda.graph(s.g_step):
             self._forward(s.ids, None, 0, self.ctl, out=s.logits)
+        s.g_step.replay()                      # the first token, window index 0
+        s.last.copy_(s.logits)
         # chunk search starts behind the first token: window index 1
         self.ctl.copy_(torch.tensor([1, 1] + [0] * (ops.DECODE_CTL_WORDS - 2), dtype=torch.int32))
         self._search = s

@@ -897,7 +897,8 @@ def mul_rows_bwd(dy, a, tab, idx):
     return da, db
 
 
-ATTENTION_HEAD_DIMS = (4, 8, 16, 32, 64)   # csrc/attention.hip instantiations
+ATTENTION_HEAD_DIMS = (4, 8, 16, 32, 64, 128)   # csrc/attention.hip instantiations; 128: csrc/attention_wide.hip
+DECODE_HEAD_DIMS = (4, 8, 16, 32, 64)           # csrc/decode.hip decode_attention_kernel (key/value cache)
 
 
 def attention_head_dim(d):
@@ -1095,9 +1096,9 @@ def scale_by(x, s):
 
 # -------------------------------------------------------------------------- conv
 def _conv_workspace(weight, nbytes, geom, tag, inference):
-    """(scratch tensor, flags) of a conv forward.  Training (`inference` False: some input of the autograd
-    node requires a gradient -- the caller decides, torch.is_grad_enabled() is always False inside an
-    autograd.Function.forward): the shared scratch, weights re-ordered in every call.  Inference (the
+    """(scratch tensor, flags) of a conv forward.  Training (`inference` False -- the caller decides, outside
+    its autograd node: torch.is_grad_enabled() is always False inside an autograd.Function.forward, and
+    functional.conv2d_act samples it before .apply): the shared scratch, weights re-ordered in every call.  Inference (the
     weights are constants between optimiser steps): one scratch per weight and geometry, kept while the
     weight is unchanged (address / version / LP_EPOCH, as the bf16 shadows), so the re-ordering launch runs
     once (QARIG_CONV_PACKED_VALID).  Inside a stream capture always the shared scratch: a captured launch

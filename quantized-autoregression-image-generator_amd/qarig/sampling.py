@@ -39,7 +39,7 @@ def _cacheable(model, hr_input, use_sliding_window):
     # head dims that run zero-padded (QF.attention) keep the full-window loop: the cache kernel takes the
     # instantiated head dims only
     from . import ops
-    return all(m.head_dim in ops.ATTENTION_HEAD_DIMS for m in model.modules() if hasattr(m, "head_dim"))
+    return all(m.head_dim in ops.DECODE_HEAD_DIMS for m in model.modules() if hasattr(m, "head_dim"))
 
 
 # Which sampler the cached loop uses: "fused" (default) draws inside the captured graphs
@@ -227,6 +227,8 @@ def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_slidi
         else:
             hr_input, pos = _generate_cached(*args)
 
+    pos_bound = stop_len + beam_width + pos_off + 1
+
     def last_logits(t_in, t_start, t_pos):
         """Logits of the window's last token.  While no token has left the window the key/value cache of the
         fused phase is still the window's: the last chunk of a stage that ends where the window starts to slide
@@ -236,7 +238,11 @@ def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_slidi
         if cache is not None and n - 1 < cache.max_len and t_in.shape[0] == cache.batch and \
                 (not use_sliding_window or n < sliding_window):
             return cache.step(t_in[:, -1], None, n - 1)
-        return model.decode(t_in[:, t_start:].contiguous(), enc_eval, t_pos)[:, -1, :]
+        # the loop's positions are whole numbers (cur + tok + pos_off): as int64 the model evaluates the
+        # conditioning path once per POSITION instead of once per token (Transformer._cond; same values)
+        if t_pos is None or not hasattr(model, "_cond"):
+            return model.decode(t_in[:, t_start:].contiguous(), enc_eval, t_pos)[:, -1, :]
+        return model.decode(t_in[:, t_start:].contiguous(), enc_eval, t_pos.long(), pos_bound=pos_bound)[:, -1, :]
 
     tail = _Timer()
     enc_eval = enc

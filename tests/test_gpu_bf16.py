@@ -111,6 +111,30 @@ def test_bf16_gemm_is_exact_on_rounded_operands(bf16_mode, M, N, K, splitk, ak, 
     assert torch.equal(C, ops.gemm(A, B, ak, bk, splitk=splitk))      # deterministic
 
 
+def test_bf16_classifier_products_at_config5_shapes(bf16_mode):
+    """BASELINE configs[4]'s largest products at their own extents -- the classifier over the 8192-entry
+    codebook (+ <end>, padded to 8320 columns) on a shard of 8 x 4096 tokens: forward x W^T
+    (32768 x 8320 x 2048), input gradient dY W (reduction 8320) and weight gradient dY^T x (reduction 32768) --
+    against the fp64 contraction of the bf16-rounded operands (reference models/Transformer.py:193-200)."""
+    ops = bf16_mode
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M, N, K = 32768, 8320, 2048
+    x = torch.randn((M, K), generator=g, device="cuda")
+    W = torch.randn((N, K), generator=g, device="cuda") * 0.05
+    dY = torch.randn((M, N), generator=g, device="cuda")
+    r = lambda t: t.bfloat16().double()
+    cases = ((x, W, True, True, K, lambda: r(x) @ r(W).t()),                    # forward
+             (dY, W, True, False, N, lambda: r(dY) @ r(W)),                      # input gradient
+             (dY, x, False, False, M, lambda: r(dY).t() @ r(x)))                 # weight gradient
+    for A, B, ak, bk, red, ref in cases:
+        C = ops.gemm(A, B, ak, bk)
+        want = ref()
+        assert C.shape == want.shape
+        err = float((C.double() - want).abs().max() / want.abs().max())
+        assert err < 3e-6 * (red / 512) ** 0.5, (ak, bk, err)
+        del C, want
+
+
 def test_bf16_gemm_epilogues_and_accumulate(bf16_mode):
     ops = bf16_mode
     from oracle import ref_models as rm
@@ -262,7 +286,10 @@ def test_lp_qkv_and_residual_nodes_track_fp32_nodes(bf16_mode):
 
 @pytest.mark.parametrize("N,Sq,Sk,H,d,causal", [(2, 300, 300, 6, 8, True), (1, 1024, 1024, 8, 8, True),
                                                 (2, 200, 333, 5, 8, False), (1, 130, 130, 4, 16, True),
-                                                (1, 96, 96, 2, 64, False)])
+                                                (1, 96, 96, 2, 64, False),
+                                                # BASELINE configs[4]: one 4096-token sequence x 64 heads of 8, and its
+                                                # cross-attention over the previous stage's 1024 tokens
+                                                (1, 4096, 4096, 64, 8, True), (1, 4096, 1024, 64, 8, False)])
 def test_lp_attention_tracks_fp64(bf16_mode, N, Sq, Sk, H, d, causal):
     """Attention with the QK^T / PV (and backward) products on the bf16 MFMA, fp32 softmax and
     accumulation: against fp64 attention of the bf16-ROUNDED q, k, v the remaining error is the

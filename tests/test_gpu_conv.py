@@ -224,6 +224,53 @@ def test_encoder_readme_shape_latent_vs_oracle_fp64():
     assert rel_err(z, ref) < PIX_TOL
 
 
+def test_config0_autoencoder_train_step_vs_oracle_fp64():
+    """BASELINE configs[0] as a step: README autoencoder (256 / 512 channels, 2 levels, latent 4), batch 4 of
+    64 x 64 x 3, reconstruction MSE + backward + Adam(0.5, 0.999) (reference train_autoencoder.py:203-226) --
+    loss, EVERY parameter gradient and the post-Adam weights against the oracle evaluated in fp64."""
+    from conftest import grad_err
+    from models.Autoencoder import Autoencoder
+    from oracle import ref_models as rm
+    from qarig import functional as QF
+    from qarig.optim import FlatAdam
+    torch.manual_seed(3)
+    m = Autoencoder(num_layers=2, image_channel=3, min_channel=256, max_channel=512, latent_channel=4)
+    x = torch.rand((4, 3, 64, 64), generator=torch.Generator().manual_seed(0)) * 2 - 1
+    sd = {k: v.detach().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    names = list(sd)
+    recon = rm.autoencoder(sd, x.double())
+    ref_loss = torch.mean((recon - x.double()) ** 2)
+    ref_grads = torch.autograd.grad(ref_loss, [sd[k] for k in names])
+    before = {k: v.detach().clone() for k, v in sd.items()}
+    lr = 1e-4
+    with torch.no_grad():
+        rm.adam_step([sd[k] for k in names], ref_grads, [torch.zeros_like(sd[k]) for k in names],
+                     [torch.zeros_like(sd[k]) for k in names], 1, lr)
+    m = m.cuda()
+    opt = FlatAdam(m.parameters(), lr=lr, betas=(0.5, 0.999))
+    opt.zero_grad()
+    xg = x.cuda()
+    out = m(xg)
+    assert rel_err(out, recon) < PIX_TOL
+    loss = QF.mse_loss(out, xg)
+    loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 1e-5 * max(1.0, abs(float(ref_loss)))
+    got = dict(m.named_parameters())
+    assert set(got) == set(names)
+    for k, g in zip(names, ref_grads):
+        assert grad_err(got[k].grad, g) < 2e-5, k
+    opt.step()
+    for k, g in zip(names, ref_grads):
+        w = got[k].detach().double().cpu()
+        # first Adam step: the update is lr * g / (|g| + eps), i.e. +-lr wherever the gradient is not noise;
+        # compared where the fp64 gradient is well above the 2e-5 gradient tolerance, bounded by 2 lr elsewhere
+        # (a component inside the tolerance may legitimately take the other sign)
+        clear = g.abs() > 1e-3 * g.abs().max()
+        d = (w - sd[k].detach()).abs()
+        assert float(d[clear].max()) <= 2e-3 * lr + 1e-7 * float(before[k].abs().max()), k
+        assert float(d.max()) <= 2.0 * lr + 1e-7, k
+
+
 def test_conv_autograd_node_accepts_non_contiguous_input():
     """The autograd node normalises its input once and saves THAT tensor: a channels-last view
     must give the gradients of the dense tensor."""
@@ -464,10 +511,19 @@ def test_inference_weight_copies_are_cached_and_follow_the_weights():
         finally:
             _lib.set_option("conv_ring", old)
         assert rel_err(yb, ya) < 1e-5 and torch.equal(dec(z), ya)
-    # training mode (grad enabled) never uses the cache
+    # training mode (grad enabled) never uses the cache: no new entries, and no launch is told that the packed
+    # weights of an earlier call are still valid (flags = QARIG_CONV_PACKED_VALID) -- a write to the weights that
+    # torch's version counter does not see (a broadcast into the flat buffer, a raw-pointer kernel) must not meet
+    # stale copies in a training forward
     n = len(ops._lp_cache)
-    dec(z).sum().backward()
-    assert len(ops._lp_cache) == n
+    seen = []
+    real = ops._conv_workspace
+    ops._conv_workspace = lambda *a, **k: (seen.append(real(*a, **k)) or seen[-1])
+    try:
+        dec(z).sum().backward()
+    finally:
+        ops._conv_workspace = real
+    assert len(ops._lp_cache) == n and seen and all(flags == 0 for _, flags in seen)
 
 
 @pytest.mark.parametrize("kind,N,Cin,H,W,Cout", [

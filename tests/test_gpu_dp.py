@@ -97,10 +97,13 @@ def _worker(rank, world, port, overlap, q, backend="gloo", wide=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap,wide", [(False, False), (True, False), (True, True)])
-def test_dp2_step_equals_single_process(overlap, wide):
+@pytest.mark.parametrize("overlap,wide,world", [(False, False, 2), (True, False, 2), (True, True, 2),
+                                                # more than two ranks (one sample each): bucket ordering and completion
+                                                # tracking with world > 2, the per-layer grouping of the projections
+                                                (True, False, 4), (True, True, 4)])
+def test_dp2_step_equals_single_process(overlap, wide, world):
     """wide: the workers' position-table projections are grouped per decoder layer (what
-    torch.distributed with 2 ranks selects) and report their parameters to the overlapped
+    torch.distributed with more than one rank selects) and report their parameters to the overlapped
     all-reduce from the grouped backward; the reference step groups them in one launch."""
     global WIDE
     from qarig import pipeline
@@ -116,12 +119,12 @@ def test_dp2_step_equals_single_process(overlap, wide):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q, "gloo", wide)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, overlap, q, "gloo", wide)) for r in range(world)]
     for p in procs:
         p.start()
     import queue
     got = None
-    for _ in range(120):                      # poll: a crashed worker must not cost minutes
+    for _ in range(180):                      # poll: a crashed worker must not cost minutes
         try:
             got, _ = q.get(timeout=1)
             break

@@ -97,7 +97,12 @@ def test_layernorm_with_skip_adds_both_gradients_of_x(M, D):
                                                 # head dims without an instantiation run zero-padded on the next one
                                                 (2, 70, 70, 4, 12, True), (1, 40, 90, 3, 24, False),
                                                 (2, 33, 33, 2, 48, True), (2, 20, 20, 5, 2, True),
-                                                (1, 17, 17, 6, 1, False), (1, 50, 50, 2, 60, True)])
+                                                (1, 17, 17, 6, 1, False), (1, 50, 50, 2, 60, True),
+                                                # head dims 65 ... 128 (a 512-wide model with 4 heads): the wide-head
+                                                # family, directly and zero-padded; tiles that are not whole, cross
+                                                (2, 70, 70, 4, 128, True), (1, 200, 200, 2, 128, True),
+                                                (2, 33, 90, 3, 128, False), (1, 130, 130, 2, 96, True),
+                                                (1, 64, 5, 2, 72, False), (1, 65, 65, 1, 100, True)])
 def test_attention_fwd_bwd(N, Sq, Sk, H, d, causal):
     """The reference's attention takes any heads | in_dim (models/layers.py:433-474)."""
     from qarig import functional as QF
@@ -126,8 +131,9 @@ def test_attention_fwd_bwd(N, Sq, Sk, H, d, causal):
 
 
 def test_attention_layer_any_head_count_that_divides_the_width():
-    """heads=4 on a 48-wide model (head dim 12): the layer builds, trains and matches fp64
-    attention; heads wider than the widest kernel raise with the reason."""
+    """heads=4 on a 48-wide model (head dim 12) and heads=4 on a 512-wide one (head dim 128: what a README-width
+    model with few heads has): the layer builds, trains and matches fp64 attention; heads wider than the widest
+    kernel raise with the reason."""
     from models.layers import AttentionLayer
     torch.manual_seed(3)
     lay = AttentionLayer(heads=4, in_dim=48, hidden_dim=64, use_cross_attn=False, use_masked_attn=True).cuda()
@@ -141,8 +147,17 @@ def test_attention_layer_any_head_count_that_divides_the_width():
     want = _attn_ref64(q.double(), k.double(), v.double(), 4, True)
     assert rel_err(y, want) < 2e-6
     assert x.grad is not None and torch.isfinite(x.grad).all()
-    with pytest.raises(ValueError, match="head dim 128"):
-        AttentionLayer(heads=2, in_dim=256, hidden_dim=64, use_cross_attn=False)
+    wide = AttentionLayer(heads=4, in_dim=512, hidden_dim=64, use_cross_attn=False, use_masked_attn=True).cuda()
+    assert wide.head_dim == 128
+    xw = torch.randn(2, 70, 512).cuda().requires_grad_(True)
+    yw = wide(xw)
+    yw.square().sum().backward()
+    with torch.no_grad():
+        q, k, v = (blk(xw.detach()) for blk in (wide.q_block, wide.k_block, wide.v_block))
+    assert rel_err(yw, _attn_ref64(q.double(), k.double(), v.double(), 4, True)) < 2e-6
+    assert torch.isfinite(xw.grad).all() and float(xw.grad.abs().max()) > 0
+    with pytest.raises(ValueError, match="head dim 256"):
+        AttentionLayer(heads=2, in_dim=512, hidden_dim=64, use_cross_attn=False)
 
 
 def _attn_ref64(q, k, v, H, causal):

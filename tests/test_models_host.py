@@ -89,14 +89,16 @@ def test_readme_transformer_param_counts():
 
 def test_unsupported_head_dim_fails_at_construction():
     """The reference accepts any `heads` dividing in_dim; the HIP attention kernels serve every head
-    dim up to 64 (4/8/16/32/64 directly, the others zero-padded to the next), so a wider one must fail
+    dim up to 128 (4/8/16/32/64/128 directly, the others zero-padded to the next), so a wider one must fail
     when the model is built, not at the first forward."""
     import pytest
     from models.layers import AttentionLayer
     AttentionLayer(heads=64, in_dim=512, hidden_dim=64)
     assert AttentionLayer(heads=4, in_dim=48, hidden_dim=64).head_dim == 12     # runs padded to 16
+    assert AttentionLayer(heads=4, in_dim=512, hidden_dim=64).head_dim == 128    # the wide-head kernels
+    assert AttentionLayer(heads=5, in_dim=480, hidden_dim=64).head_dim == 96     # padded to 128
     with pytest.raises(ValueError, match="head dim"):
-        AttentionLayer(heads=4, in_dim=512, hidden_dim=64)      # d = 128
+        AttentionLayer(heads=2, in_dim=512, hidden_dim=64)      # d = 256
     with pytest.raises(ValueError, match="head dim"):
         AttentionLayer(heads=7, in_dim=512, hidden_dim=64)      # not a divisor
 
