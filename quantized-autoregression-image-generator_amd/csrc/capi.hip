@@ -40,7 +40,7 @@ extern "C" int qarig_set_option(const char* name, int value) {
         {"attn_bw", &g_qarig_opt.attn_bw},         {"lp_big", &g_qarig_opt.lp_big},
         {"lp_mfma16", &g_qarig_opt.lp_mfma16},     {"convt_pair", &g_qarig_opt.convt_pair},
         {"conv_ring", &g_qarig_opt.conv_ring},     {"gemm_xcd_splits", &g_qarig_opt.gemm_xcd_splits},
-        {"decode_stream", &g_qarig_opt.decode_stream},
+        {"decode_stream", &g_qarig_opt.decode_stream}, {"decode_rows", &g_qarig_opt.decode_rows},
     };
     if (name)
         for (const Entry& e : table)
@@ -50,6 +50,6 @@ extern "C" int qarig_set_option(const char* name, int value) {
                 return old;
             }
     qarig_set_error("set_option: unknown option %s (gemm_dma, gemm_pair, bmu_cs, bmu_groups, bmu_coarse, attn_qw, "
-                    "attn_bw, lp_big, lp_mfma16, convt_pair, conv_ring, gemm_xcd_splits, decode_stream)", name ? name : "(null)");
+                    "attn_bw, lp_big, lp_mfma16, convt_pair, conv_ring, gemm_xcd_splits, decode_stream, decode_rows)", name ? name : "(null)");
     return -2147483647 - 1;
 }

@@ -248,6 +248,156 @@ __global__ __launch_bounds__(256) void decode_linear_kernel(const float* __restr
 }
 
 
+// Which value's total lane `lane` holds after wave_sum_multi<V>, and whether it is that value's owner -- known
+// from the lane number alone, so a lane can request the epilogue operands of its output before anything else.
+template <int V>
+__device__ __forceinline__ int wave_sum_multi_index(int lane, bool& owner) {
+    int idx = 0, dup = 0, n = V;
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {
+        const int bit = step == 0 ? 8 : (step == 1 ? 4 : (step == 2 ? 2 : (step == 3 ? 1 : (step == 4 ? 16 : 32))));
+        if (n > 1) {
+            n >>= 1;
+            if (lane & bit) idx += n;
+        } else {
+            dup |= bit;
+        }
+    }
+    owner = (lane & dup) == 0;
+    return idx;
+}
+
+// 5 ... 16 activation rows (the candidate chunks of a few images as one batch): the ROWS are split over the four
+// waves of the workgroup -- wave w owns rows 4w .. 4w+3 -- and every wave streams the workgroup's whole run of
+// weight rows (CW columns; the three later waves hit the lines the first one brought in).  Against holding all 16
+// rows in every lane (decode_linear_kernel<16, ...>: 2,057 instructions in its LayerNorm form, every one of them on
+// the critical path of a single-wave-per-SIMD launch) a lane now carries 4 rows: a quarter of the LayerNorm and
+// statistics arithmetic, sums that stay inside the wave (no LDS hand-over, no workgroup barrier at all), the same
+// fma count.  KW: 256-float chunks of a weight row per lane (K = 256 KW); a lane's loads j = c KW + s cover chunk
+// s of column c.
+template <int LN, int CW, int KW>
+__global__ __launch_bounds__(256) void decode_linear_rows_kernel(const float* __restrict__ Xb, const float* __restrict__ Wb,
+                                                                 int64_t ldx, int64_t ldw, int M, int N, int K, int act,
+                                                                 int64_t x_gs, int64_t w_gs, DecLin p) {
+    static_assert(LN >= 0 && LN <= 3 && CW * 4 <= 64, "");
+    constexpr int V = CW * 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (4 * w >= M) return;                 // a whole wave without rows (no barrier below)
+    const int g = blockIdx.y;
+    const int n0 = blockIdx.x * CW;
+    const float* X = Xb + (int64_t)g * x_gs;
+    const float* W = Wb + (int64_t)g * w_gs;
+    const int Ml = M - 1, Nl = N - 1;
+    float4 xv[KW][4];
+#pragma unroll
+    for (int s = 0; s < KW; ++s)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            xv[s][m] = ld4(X + (int64_t)min(4 * w + m, Ml) * ldx + 4 * (lane + 64 * s));
+    float4 lg[(LN == 1 || LN == 3) ? KW : 1], lb[(LN == 1 || LN == 3) ? KW : 1];
+    float4 ls[LN == 2 ? KW : 1][4], lh[LN == 2 ? KW : 1][4];
+    if (LN == 1 || LN == 3) {
+#pragma unroll
+        for (int s = 0; s < KW; ++s) {
+            lg[s] = ld4((LN == 1 ? p.gamma : p.scale) + 4 * (lane + 64 * s));
+            lb[s] = ld4((LN == 1 ? p.beta : p.shift) + 4 * (lane + 64 * s));
+        }
+    }
+    if (LN == 2) {
+#pragma unroll
+        for (int s = 0; s < KW; ++s)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int64_t mo = (int64_t)min(4 * w + m, Ml) * p.ldmod + 4 * (lane + 64 * s);
+                ls[s][m] = ld4(p.scale + mo);
+                lh[s][m] = ld4(p.shift + mo);
+            }
+    }
+    bool own;
+    const int oidx = wave_sum_multi_index<V>(lane, own);
+    const int om = 4 * w + (oidx & 3), on = n0 + (oidx >> 2);
+    const bool oval = own && om < M && on < N;
+    const int omc = min(om, Ml), onc = min(on, Nl);
+    const float eb = *(p.bias ? p.bias + (int64_t)g * p.bias_gs + onc : X);
+    const float er = *(p.residual ? p.residual + (int64_t)omc * p.ldr + onc : X);
+    const float em = *(p.mul ? p.mul + (int64_t)omc * p.ldmul + onc : X);
+    float4 wv[CW * KW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c)
+#pragma unroll
+        for (int s = 0; s < KW; ++s)
+            wv[c * KW + s] = ld4_nt(W + (int64_t)min(n0 + c, Nl) * ldw + 4 * (lane + 64 * s));
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (LN) {
+        const float invK = 1.0f / (float)K;
+        float s1[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float a = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KW; ++s) a += (xv[s][m].x + xv[s][m].y) + (xv[s][m].z + xv[s][m].w);
+            s1[m] = a;
+        }
+        bool o4;
+        wave_sum_multi<4>(s1, lane, o4);          // value m's total on the lanes with (lane >> 2) & 3 == m
+        float mean[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) mean[m] = __shfl(s1[0], 4 * m, 64) * invK;
+        float s2[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float q = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KW; ++s) {
+                float4& x = xv[s][m];
+                x.x -= mean[m]; x.y -= mean[m]; x.z -= mean[m]; x.w -= mean[m];
+                q = fmaf(x.x, x.x, q); q = fmaf(x.y, x.y, q); q = fmaf(x.z, x.z, q); q = fmaf(x.w, x.w, q);
+            }
+            s2[m] = q;
+        }
+        wave_sum_multi<4>(s2, lane, o4);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float rstd = __builtin_amdgcn_rsqf(__shfl(s2[0], 4 * m, 64) * invK + p.eps);
+#pragma unroll
+            for (int s = 0; s < KW; ++s) {
+                float4& x = xv[s][m];
+                const float4 gg = LN == 2 ? ls[LN == 2 ? s : 0][m] : lg[LN == 2 ? 0 : s];
+                const float4 hh = LN == 2 ? lh[LN == 2 ? s : 0][m] : lb[LN == 2 ? 0 : s];
+                x.x = fmaf(x.x * rstd, gg.x, hh.x); x.y = fmaf(x.y * rstd, gg.y, hh.y);
+                x.z = fmaf(x.z * rstd, gg.z, hh.z); x.w = fmaf(x.w * rstd, gg.w, hh.w);
+            }
+        }
+    }
+
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CW; ++c)
+#pragma unroll
+        for (int s = 0; s < KW; ++s)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 wq = wv[c * KW + s];
+                float a = acc[c * 4 + m];
+                a = fmaf(wq.x, xv[s][m].x, a); a = fmaf(wq.y, xv[s][m].y, a);
+                a = fmaf(wq.z, xv[s][m].z, a); a = fmaf(wq.w, xv[s][m].w, a);
+                acc[c * 4 + m] = a;
+            }
+    bool own2;
+    wave_sum_multi<V>(acc, lane, own2);        // lands where wave_sum_multi_index said
+    if (oval) {
+        float v = acc[0];
+        if (p.bias) v += eb;
+        if (p.residual) v += er;
+        v = act == ACT_SILU ? v * sigmoid_f(v) : act_fwd(v, act);
+        if (p.mul) v *= em;
+        p.C[(int64_t)g * p.c_gs + (int64_t)om * p.ldc + on] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Device-resident state of the sampling loop (generate_images.py:256-345): the host replays captured
 // graphs and never reads a token back between them.  int32 control words:
@@ -657,6 +807,30 @@ static void launch_decode_linear(const DecLinHead& h, const DecLin& p, int group
 }
 
 /* C-ABI: see include/qarig.h */
+// 5 ... 16 rows, K <= 2048: the row-split kernel.  CW columns per workgroup: 16 KB of weights while that leaves
+// >= 256 workgroups, else a quarter of it.
+template <int LN>
+static bool launch_decode_linear_rows(const DecLinHead& h, const DecLin& p, int groups, hipStream_t st) {
+    const int kw = h.K / 256;
+    auto wgs = [&](int cw) { return (int64_t)((h.N + cw - 1) / cw) * groups; };
+#define QARIG_DR(CW, KW)                                                                                              \
+    hipLaunchKernelGGL((decode_linear_rows_kernel<LN, CW, KW>), dim3((h.N + CW - 1) / CW, groups), dim3(256), 0, st, \
+                       h.X, h.W, h.ldx, h.ldw, h.M, h.N, h.K, h.act, h.x_gs, h.w_gs, p)
+    switch (kw) {
+        case 1: if (wgs(16) >= 256) QARIG_DR(16, 1); else QARIG_DR(4, 1); return true;
+        case 2: if (wgs(8) >= 256) QARIG_DR(8, 2); else QARIG_DR(2, 2); return true;
+        case 4: if (wgs(4) >= 256) QARIG_DR(4, 4); else QARIG_DR(1, 4); return true;
+        case 8:
+            if constexpr (LN == 0) {
+                if (wgs(2) >= 256) QARIG_DR(2, 8); else QARIG_DR(1, 8);
+                return true;
+            }
+            return false;
+        default: return false;
+    }
+#undef QARIG_DR
+}
+
 extern "C" int qarig_decode_linear_f32(const float* X, int64_t ldx, int64_t x_gs, float eps,
                                        const float* gamma, const float* beta, const float* scale,
                                        const float* shift, int64_t ldmod, const float* W, int64_t ldw,
@@ -693,7 +867,17 @@ extern "C" int qarig_decode_linear_f32(const float* X, int64_t ldx, int64_t x_gs
         case 2: launch_decode_linear<MR, 2>(h, p, groups, st); break;          \
         default: launch_decode_linear<MR, 3>(h, p, groups, st); break;         \
     }
-    if (M <= 4) { QARIG_DL_LN(4) } else { QARIG_DL_LN(16) }
+    bool done = false;
+    if (M > 4 && g_qarig_opt.decode_rows != 0) {
+        switch (ln) {
+            case 0: done = launch_decode_linear_rows<0>(h, p, groups, st); break;
+            case 1: done = launch_decode_linear_rows<1>(h, p, groups, st); break;
+            case 2: done = launch_decode_linear_rows<2>(h, p, groups, st); break;
+            default: done = launch_decode_linear_rows<3>(h, p, groups, st); break;
+        }
+    }
+    if (done) {
+    } else if (M <= 4) { QARIG_DL_LN(4) } else { QARIG_DL_LN(16) }
 #undef QARIG_DL_LN
     QARIG_CHECK_LAUNCH("decode_linear");
     return QARIG_OK;

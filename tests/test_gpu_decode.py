@@ -36,7 +36,7 @@ def _ref(x, W, b, form, gam, bet, sc, sh, res, mul, act):
     (4, 1, 2048, 512), (4, 3, 2048, 512), (4, 1, 512, 2048), (4, 3, 512, 2048), (4, 1, 512, 512),
     (1, 1, 513, 2048), (3, 1, 513, 256), (2, 2, 77, 1024), (16, 1, 2048, 512), (16, 3, 512, 2048),
     (9, 1, 512, 512), (16, 1, 513, 2048), (5, 2, 40, 4096), (4, 1, 96, 4096), (16, 1, 8193, 2048),
-    (4, 1, 8, 256), (13, 1, 1030, 1024)])
+    (4, 1, 8, 256), (13, 1, 1030, 1024), (12, 1, 600, 256), (6, 3, 2048, 512), (8, 1, 20, 1024), (16, 1, 40, 2048)])
 @pytest.mark.parametrize("form", ["none", "affine", "adaln", "adaln_row"])
 def test_decode_linear_vs_fp64(M, G, N, K, form):
     from qarig import ops
@@ -115,6 +115,35 @@ def test_skinny_entry_points_route_small_batches_to_the_streaming_kernel():
     for a, c in zip(outs[1], outs[0]):
         assert rel_err(a, c) < 2e-6
     assert torch.equal(outs[1][0], ops.decode_linear(x, W, b, act=1))
+
+
+@pytest.mark.parametrize("M,G,N,K", [(16, 3, 2048, 512), (16, 1, 512, 2048), (9, 1, 512, 512), (5, 1, 96, 1024)])
+def test_row_split_and_all_rows_kernels_agree(M, G, N, K):
+    """5 ... 16 rows: the kernel that splits the rows over the waves (decode_rows = 1, the default) against the
+    one that holds all rows in every lane (decode_rows = 0) -- same results up to fp32 summation order, in the
+    LayerNorm / residual / gate forms."""
+    from qarig import ops, _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn((M, K), generator=g) * 1.5 + 0.3).cuda()
+    W = (torch.randn((G, N, K), generator=g) * 0.05).cuda()
+    b = torch.randn((G, N), generator=g).cuda()
+    sc, sh = torch.randn(K, generator=g).cuda(), torch.randn(K, generator=g).cuda()
+    res, mul = torch.randn((M, N), generator=g).cuda(), torch.randn(N, generator=g).cuda()
+    lib = _lib.load()
+    outs = {}
+    for v in (1, 0):
+        old = lib.qarig_set_option(b"decode_rows", v)
+        try:
+            o = [ops.decode_linear(x, W, b, act=1)]
+            if K <= 1024:
+                o.append(ops.decode_linear(x, W, b, act=1, scale=sc, shift=sh))
+            if G == 1:
+                o.append(ops.decode_linear(x, W[0], b[0], act=1, residual=res, mul=mul))
+            outs[v] = o
+        finally:
+            lib.qarig_set_option(b"decode_rows", old)
+    for a_, c_ in zip(outs[1], outs[0]):
+        assert rel_err(a_, c_) < 2e-6 and not torch.equal(a_, c_) or M * N < 64
 
 
 def test_decode_embed_row_and_position_table():
