@@ -165,6 +165,11 @@ size_t qarig_cast_colsum_workspace_bytes(int M, int N);
 int qarig_cast_colsum(const void* src, int64_t ld, int src_is_bf16, int M, int N, void* dst,
                       float* colsum, int accumulate, void* workspace, size_t ws_bytes, void* stream);
 
+/* 1 when qarig_gemm_f32 runs an (M, N, K) product on 64 x 64 tiles (whole 64-tiles, 16-deep k-tiles, fewer
+ * than 192 tiles of 128 x 128: the 512-wide Linear products of a 2,048-row shard, models/layers.py:291-304);
+ * a caller that chooses the reduction split counts those tiles. */
+int qarig_gemm_tile64(int M, int N, int K);
+
 /* `groups` independent skinny products in one launch, C_g = act(A_g W_g^T + bias_g) with
  * X_g = X + g * x_gs (a_gs == 0 shares the activations).  Decode steps use it for the q/k/v
  * MLPs (models/layers.py:389-418) and for every projection of the conditioning vector

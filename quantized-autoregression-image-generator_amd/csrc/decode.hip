@@ -812,17 +812,20 @@ static void launch_decode_linear(const DecLinHead& h, const DecLin& p, int group
 template <int LN>
 static bool launch_decode_linear_rows(const DecLinHead& h, const DecLin& p, int groups, hipStream_t st) {
     const int kw = h.K / 256;
+    // one wave per 4 rows; <= 4 rows: single-wave workgroups, so four times the workgroups for the bytes per CU
+    const int threads = 64 * ((h.M + 3) / 4);
+    const int64_t want = h.M <= 4 ? 1024 : 256;
     auto wgs = [&](int cw) { return (int64_t)((h.N + cw - 1) / cw) * groups; };
-#define QARIG_DR(CW, KW)                                                                                              \
-    hipLaunchKernelGGL((decode_linear_rows_kernel<LN, CW, KW>), dim3((h.N + CW - 1) / CW, groups), dim3(256), 0, st, \
+#define QARIG_DR(CW, KW)                                                                                                  \
+    hipLaunchKernelGGL((decode_linear_rows_kernel<LN, CW, KW>), dim3((h.N + CW - 1) / CW, groups), dim3(threads), 0, st, \
                        h.X, h.W, h.ldx, h.ldw, h.M, h.N, h.K, h.act, h.x_gs, h.w_gs, p)
     switch (kw) {
-        case 1: if (wgs(16) >= 256) QARIG_DR(16, 1); else QARIG_DR(4, 1); return true;
-        case 2: if (wgs(8) >= 256) QARIG_DR(8, 2); else QARIG_DR(2, 2); return true;
-        case 4: if (wgs(4) >= 256) QARIG_DR(4, 4); else QARIG_DR(1, 4); return true;
+        case 1: if (wgs(16) >= want) QARIG_DR(16, 1); else QARIG_DR(4, 1); return true;
+        case 2: if (wgs(8) >= want) QARIG_DR(8, 2); else QARIG_DR(2, 2); return true;
+        case 4: if (wgs(4) >= want) QARIG_DR(4, 4); else QARIG_DR(1, 4); return true;
         case 8:
             if constexpr (LN == 0) {
-                if (wgs(2) >= 256) QARIG_DR(2, 8); else QARIG_DR(1, 8);
+                if (wgs(2) >= want) QARIG_DR(2, 8); else QARIG_DR(1, 8);
                 return true;
             }
             return false;
@@ -868,7 +871,7 @@ extern "C" int qarig_decode_linear_f32(const float* X, int64_t ldx, int64_t x_gs
         default: launch_decode_linear<MR, 3>(h, p, groups, st); break;         \
     }
     bool done = false;
-    if (M > 4 && g_qarig_opt.decode_rows != 0) {
+    if ((M > 4 && g_qarig_opt.decode_rows != 0) || g_qarig_opt.decode_rows == 2) {
         switch (ln) {
             case 0: done = launch_decode_linear_rows<0>(h, p, groups, st); break;
             case 1: done = launch_decode_linear_rows<1>(h, p, groups, st); break;

@@ -735,6 +735,10 @@ static void launch_skinny(const float* A, int64_t lda, const float* B, int64_t l
 #undef QARIG_SKINNY
 }
 
+// csrc/gemm64.hip
+int qarig_gemm64_launch(const float* A, int64_t lda, int a_kcontig, const float* B, int64_t ldb, int b_kcontig,
+                        const GemmEpilogue& ep, int M, int N, int K, int splitk, float* slabs, hipStream_t st);
+
 static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float* B,
                          int64_t ldb, int b_kcontig, float* C, int64_t ldc, int M, int N,
                          int K, const float* bias, const float* residual, int64_t ldr,
@@ -798,9 +802,16 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     // workgroup per CU; option gemm_pair = 0 disables it, 1 forces it wherever it is eligible
     const int pair_env = g_qarig_opt.gemm_pair;
     const int nk_block = per / BK;
+    // 64 x 64 tiles (gemm64.hip) where 128 x 128 tiles would leave most CUs without a workgroup: the 512-wide
+    // products of a 2,048-row shard, the window evaluations of sliding-window generation
+    const bool t64 = g_qarig_opt.gemm_tile64 != 0 && va && vb && M % 64 == 0 && N % 64 == 0 && K % BK == 0 &&
+                     (splitk == 1 || (K % per == 0 && per % BK == 0)) && !(a_rowsum && a_kcontig) &&
+                     qarig_gemm_tile64(M, N, K);
     const bool pair_ok = dma_on && fast && vec_epi && !(a_rowsum && a_kcontig) && !(!a_kcontig && b_kcontig) &&
                          nk_block % 2 == 0 && nk_block >= 4;
-    if (pair_ok && pair_env != 0 && (pair_env == 1 || (long)grid.x * grid.z <= 256)) {
+    if (t64 && pair_env != 1) {           // (gemm_pair = 1 forces the two-team kernel: the cross-check of this one)
+        qarig_gemm64_launch(A, lda, a_kcontig, B, ldb, b_kcontig, ep, M, N, K, splitk, slabs, st);
+    } else if (pair_ok && pair_env != 0 && (pair_env == 1 || (long)grid.x * grid.z <= 256)) {
         constexpr int PAIR_LDS = 2 * PF_STAGES * DMA_STAGE_FLOATS * (int)sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {

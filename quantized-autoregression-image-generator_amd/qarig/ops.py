@@ -599,9 +599,25 @@ def auto_splitk(M, N, K):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= 192 or K < 256 or K % 64:
         return 1
+    s64 = _tile64_splitk(M, N, K)
+    if s64:
+        return s64
     if tiles < 64:
         return max(1, min(256 // tiles, K // 64))
     return max(1, min(512 // tiles, K // 128))
+
+
+def _tile64_splitk(M, N, K):
+    """Reduction split of a product the library runs on 64 x 64 tiles (qarig_gemm_tile64): none when the tiles
+    fill the chip, else the smallest split of whole 16-deep k-tiles, at least 128 deep, that gives >= 256
+    workgroups.  0: not a 64-tile shape."""
+    if not _lib.load().qarig_gemm_tile64(int(M), int(N), int(K)):
+        return 0
+    tiles = (M // 64) * (N // 64)
+    s = 1
+    while tiles * s < 256 and K % (2 * s) == 0 and (K // (2 * s)) % 16 == 0 and K // (2 * s) >= 128:
+        s *= 2
+    return s
 
 
 def pick_splitk(M, N, K):
@@ -609,6 +625,9 @@ def pick_splitk(M, N, K):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     if tiles >= 256:
         return 1
+    s64 = _tile64_splitk(M, N, K)
+    if s64:
+        return s64
     if K < 2048:
         # short reductions over few tiles (weight gradients of the position-table layers,
         # K = a few hundred positions): a handful of workgroups would each walk the whole

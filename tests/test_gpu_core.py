@@ -146,6 +146,73 @@ def test_gemm_paired_teams(M, N, K, ak, bk, splitk):
         assert rel_err(rs, A.double().cpu().sum(0)) < 2e-6 * max(1, K / 512) ** 0.5
 
 
+@pytest.mark.parametrize("M,N,K,ak,bk,splitk", [
+    (2048, 512, 512, True, True, 1),       # the 512 -> 512 residual Linear of an 8-sequence shard: 256 tiles of 64 x 64
+    (2048, 512, 512, True, False, 1),      # its input gradient
+    (512, 512, 2048, False, False, 4),     # its weight gradient: 64 tiles x 4 slabs, bias row sums riding on it
+    (1024, 512, 2048, True, True, 2),      # a 4 x 255-row window evaluation's second MLP layer
+    (64, 64, 16, True, True, 1),           # one tile, one k-tile
+    (192, 320, 48, False, True, 1),        # tile-contiguous A against reduction-contiguous B
+    (4096, 2048, 512, True, True, 1),      # forced onto 64-tiles although 128-tiles would fill the chip
+])
+def test_gemm_64_tiles(M, N, K, ak, bk, splitk):
+    """csrc/gemm64.hip: products whose 128 x 128 tiling leaves CUs idle run on 64 x 64 tiles -- every operand
+    layout, every epilogue option, split reductions with the bias row sums, against fp64, and against the
+    128-tile kernels (option gemm_tile64 = 0) up to the summation order."""
+    from qarig import ops, _lib
+    from oracle import ref_models as rm
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + splitk)
+    A = torch.randn((M, K) if ak else (K, M), generator=g).cuda()
+    B = (torch.randn((N, K) if bk else (K, N), generator=g) * 0.1).cuda()
+    b = torch.randn((N,), generator=g).cuda()
+    R = torch.randn((M, N), generator=g).cuda()
+    Z = torch.randn((M, N), generator=g).cuda()
+    ref = _ref_gemm(A, B, ak, bk)
+    tol = GEMM_TOL * max(1, K / 512) ** 0.5
+
+    def run():
+        out = [ops.gemm(A, B, ak, bk, splitk=splitk)]
+        Y, pre = ops.gemm(A, B, ak, bk, bias=b, residual=R, want_preact=True, act=1, splitk=splitk)
+        out += [Y, pre, ops.gemm(A, B, ak, bk, gradz=Z, gact=1, splitk=splitk)]
+        acc = R.clone()
+        ops.gemm(A, B, ak, bk, out=acc, accumulate=True, splitk=splitk)
+        out.append(acc)
+        if not ak:
+            rs = torch.zeros(M, device="cuda")
+            out += [ops.gemm(A, B, ak, bk, splitk=splitk, a_rowsum=rs), rs]
+        return out
+    old = _lib.set_option("gemm_tile64", 1)
+    try:
+        assert _lib.load().qarig_gemm_tile64(M, N, K) == 1
+        got = run()
+        assert torch.equal(got[0], ops.gemm(A, B, ak, bk, splitk=splitk))      # deterministic
+        _lib.set_option("gemm_tile64", 0)
+        assert _lib.load().qarig_gemm_tile64(M, N, K) == 0
+        other = run()
+    finally:
+        _lib.set_option("gemm_tile64", old)
+    t = ref + b.double().cpu() + R.double().cpu()
+    Zd = Z.double().cpu().requires_grad_(True)
+    rm.activation(Zd, "silu").sum().backward()
+    want = [ref, rm.activation(t, "silu"), t, ref * Zd.grad, R.double().cpu() + ref]
+    if not ak:
+        want += [ref, A.double().cpu().sum(0)]
+    for i, (x, y, w) in enumerate(zip(got, other, want)):
+        assert rel_err(x, w) < (5e-6 if i in (1, 3) else tol) * (2 if i == 6 else 1), i
+        assert rel_err(x, y) < 2 * tol, i
+
+
+def test_gemm_tile64_is_the_default_for_small_grids():
+    from qarig import _lib
+    lib = _lib.load()
+    assert lib.qarig_gemm_tile64(2048, 512, 512) == 1 and lib.qarig_gemm_tile64(1020, 512, 512) == 0
+    assert lib.qarig_gemm_tile64(16384, 2048, 512) == 0          # 128-tiles fill the chip
+    from qarig import ops
+    assert lib.qarig_gemm_tile64(2048, 512, 2048) == 0           # long reduction on 64 tiles of 128: the split-K ring
+    assert ops.auto_splitk(2048, 512, 512) == 1 and ops.auto_splitk(1024, 512, 512) == 2
+    assert ops.pick_splitk(512, 512, 2048) == 4
+
+
 def test_gemm_xcd_split_mapping():
     """Split reductions whose split count is a multiple of 8 run one split per XCD on a flat grid (placement
     only): the weight-gradient shapes of the bench step with 8 and 16 splits, row sums riding, accumulate --

@@ -30,7 +30,8 @@ def test_unknown_option_is_refused():
     assert _lib.set_option("gemm_dma", 1) == 1      # default, and the call returns the previous value
 
 
-@pytest.mark.parametrize("name,value", [("gemm_dma", 0), ("gemm_pair", 0), ("gemm_pair", 1), ("gemm_xcd_splits", 0)])
+@pytest.mark.parametrize("name,value", [("gemm_dma", 0), ("gemm_pair", 0), ("gemm_pair", 1), ("gemm_xcd_splits", 0),
+                                        ("gemm_tile64", 0), ("gemm_tile64", 1)])
 def test_gemm_options(option, name, value):
     import test_gpu_core as core
     import test_gpu_grouped as grouped
