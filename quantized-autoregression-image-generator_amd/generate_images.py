@@ -29,6 +29,10 @@ def parse_args():
     p.add_argument("--batch-beams", action="store_true",
                    help="(additive) evaluate the num_beam candidate chunks as one batch per model "
                         "call; different RNG consumption order than the sequential reference loop.")
+    p.add_argument("--sampler", choices=["fused", "torch"], default=None,
+                   help="(additive) cached decoding: 'fused' (default) draws inside the decode loop's own kernel from "
+                        "uniforms of the device generator -- the whole chunk search stays on the GPU; 'torch' makes one "
+                        "torch.multinomial call per token like the reference (its generator stream for a given --seed).")
     p.add_argument("--no-kv-cache", action="store_true",
                    help="re-run the whole window for every token like the reference instead of "
                         "decoding one token per step from a key/value cache")
@@ -94,7 +98,7 @@ def main():
                 md["sliding_window"], end_token=k_hr, shift=shift, num_beam=data["num_beam"],
                 beam_width=data["beam_width"], mode="generate",
                 progress=lambda i, t: print(f"{i:,} / {t:,}"), batch_beams=args["batch_beams"],
-                use_kv_cache=not args["no_kv_cache"])
+                use_kv_cache=not args["no_kv_cache"], sampler=args["sampler"])
             hr_input = hr_input[:, 1:] - shift
             recon = decoder_model(hr_codebook.get_quantized_image(indices=hr_input,
                                                                   unpatchify_input=True))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Full validation of a build: every GPU test, the entry-point smoke, the three bench configurations, the
+# Full validation of a build: every GPU test, the entry-point smoke, the four bench configurations, the
 # generation / decode-step / BMU micro-benchmarks (everything lands in gpurun_out/<tag>_*).
 TAG=${1:-val}
 cd "$GRAFT_REPO_ROOT"
@@ -10,8 +10,12 @@ step 200 $O/${TAG}_smoke.log python -c "import __graft_entry__ as g; g.smoke(); 
 step 400 $O/${TAG}_bench_c2.json python bench.py; cut -c1-330 $O/${TAG}_bench_c2.json
 step 300 $O/${TAG}_bench_c4.json python bench.py --config c4 --steps 10 --warmup 3 --no-cpu-baseline; cut -c1-330 $O/${TAG}_bench_c4.json
 step 400 $O/${TAG}_bench_c5.json python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline; cut -c1-330 $O/${TAG}_bench_c5.json
+step 400 $O/${TAG}_bench_c3.json python bench.py --config c3 --steps 1 --warmup 1; cut -c1-330 $O/${TAG}_bench_c3.json
 step 300 $O/${TAG}_generate_c3_sequential.json python tools/bench_generate.py; cat $O/${TAG}_generate_c3_sequential.json
 step 300 $O/${TAG}_generate_c3_batched_beams.json python tools/bench_generate.py --batch-beams; cat $O/${TAG}_generate_c3_batched_beams.json
 step 300 $O/${TAG}_decode_step_rows4.json python tools/decode_step_probe.py --rows 4; cat $O/${TAG}_decode_step_rows4.json
 step 300 $O/${TAG}_decode_step_rows16.json python tools/decode_step_probe.py --rows 16; cat $O/${TAG}_decode_step_rows16.json
+step 200 $O/${TAG}_decode_chain_rows4.json python tools/decode_chain_bench.py --rows 4; cat $O/${TAG}_decode_chain_rows4.json
+step 200 $O/${TAG}_decode_chain_rows16.json python tools/decode_chain_bench.py --rows 16; cat $O/${TAG}_decode_chain_rows16.json
 step 200 $O/${TAG}_bmu_bench.log python tools/bmu_bench.py; tail -12 $O/${TAG}_bmu_bench.log
+step 200 $O/${TAG}_c1_autoencoder.log python tools/c1_autoencoder.py; tail -2 $O/${TAG}_c1_autoencoder.log
