@@ -259,8 +259,10 @@ def bmu_side_measure(device, K=512):
 
 
 def run_c3(args):
-    """BASELINE config 3 on one GPU: the cascade of generate_images.py:101-366 (reference order = the
-    candidates of a chunk one after the other; and with the candidates batched), the decode step alone
+    """BASELINE config 3 on one GPU: the cascade of generate_images.py:101-366 -- in the reference's draw order
+    (the independent candidates of a chunk run as rows of one batch, every draw numbered as the reference's
+    candidate-after-candidate loop numbers it: same draws -> same tokens), the same with the candidates
+    literally one after the other, and with --batch-beams (draws numbered by row) -- the decode step alone
     (graph replay) with its weight-streaming roofline, and codebook gather + conv decoder.  `steps` timed
     cascades after `warmup` untimed ones; value = accepted image tokens per second in the reference's order."""
     import torch
@@ -277,8 +279,11 @@ def run_c3(args):
     torch.manual_seed(69)
     prev0 = torch.randint(0, K, (N, 1), device=dev)
     res = {}
-    for name, batched in (("sequential", False), ("batched_beams", True)):
+    from qarig import sampling
+    ordered_rows = sampling.ORDERED_ROWS
+    for name, batched in (("sequential", False), ("sequential_one_by_one", False), ("batched_beams", True)):
         ns.batch_beams = batched
+        sampling.ORDERED_ROWS = 0 if name == "sequential_one_by_one" else ordered_rows
         for _ in range(max(1, args.warmup)):
             bg.run_cascade(ns, dev, K, N, patches, prev0)
         torch.cuda.synchronize()
@@ -292,6 +297,7 @@ def run_c3(args):
         res[name] = {"accepted_tokens_per_s": round(toks / gen_s, 1), "cascade_ms": round(gen_s * 1e3, 2),
                      "wall_ms_with_model_builds": round(dt * 1e3, 1),
                      "stage_tokens_per_s": [st["accepted_tokens_per_s"] for st in stages]}
+    sampling.ORDERED_ROWS = ordered_rows
     # the decode step alone: encoder-decoder stage, 4 and 16 rows, graph replay; algorithmic bytes = the fp32
     # weights one step streams (every Linear of the decoder blocks + classifier; the cond projections are a
     # per-position table row, the embedding one row per sequence)
@@ -331,23 +337,28 @@ def run_c3(args):
             dec(cb.get_quantized_image(prev))
         torch.cuda.synchronize()
         img_s = N / ((time.perf_counter() - t0) / 20)
-    gbps = wbytes / (step[4] * 1e-3) / 1e9
+    gbps = wbytes / (step[16] * 1e-3) / 1e9
     out = {"metric": METRIC, "value": res["sequential"]["accepted_tokens_per_s"], "unit": "image-tokens/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": res["sequential"]["cascade_ms"], "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": C3_NAME, "images": N, "num_beam": 4, "beam_width": 4, "window": 256,
                       "sampler": "fused in-graph sampling kernel (inverse CDF from device-generator uniforms)",
-                      "step": "one cascade = 1344 accepted tokens (value: reference order, candidates one after "
-                              "the other; batched_beams: the 4 candidates of a chunk as rows of one batch)"},
-           "c3": {"sequential": res["sequential"], "batched_beams": res["batched_beams"],
+                      "step": "one cascade = 1344 accepted tokens (value: the reference's draw order -- the 4 "
+                              "independent candidates of a chunk as rows of one batch, each draw numbered as the "
+                              "reference's candidate loop numbers it; sequential_one_by_one: the candidates "
+                              "literally one after the other; batched_beams: draws numbered by row)"},
+           "c3": {"sequential": res["sequential"], "sequential_one_by_one": res["sequential_one_by_one"],
+                  "batched_beams": res["batched_beams"],
                   "decode_step_ms_rows4": round(step[4], 4), "decode_step_ms_rows16": round(step[16], 4),
                   "decoder_images_per_s": round(img_s, 1)},
            "roofline": {"bound": "hbm", "kernel": "qarig::decode_linear_kernel<*> chain of one encoder-decoder "
-                                                  "decode step (80 dependent launches, 4 rows, HIP graph replay)",
+                                                  "decode step (80 dependent launches, 16 rows = 4 images x 4 "
+                                                  "candidates, HIP graph replay)",
                         "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
                         "algorithmic_bytes_per_step": wbytes,
+                        "rows4_GBps": round(wbytes / (step[4] * 1e-3) / 1e9, 1),
                         "note": "weights streamed once per step / replay time; the step is bound by its ~80 "
                                 "dependent launch boundaries (1.7 us each measured) and memory round trips, "
                                 "not by bytes"}}

@@ -251,18 +251,22 @@ int qarig_decode_attention(const float* q, const float* k_new, const float* v_ne
  * torch.multinomial consumes its generator differently: same distribution, not the same stream), comb[b] *= probs[token], train mode maps <end> to 0,
  * token + shift goes to ids[b] and chunk[b][slot]; inc_len != 0 advances ctl[0].  forced (optional):
  * entries >= 0 are taken instead of drawing; probs_log (optional, (max_draws, B, V)): the rows
- * sampled from. */
+ * sampled from.  beams > 0: the B rows are `beams` independent candidate chunks per image evaluated as
+ * one batch while every draw keeps the number the reference's candidate-after-candidate loop gives it
+ * (generate_images.py:262-304): row image * beams + c reads column `image` of draw row
+ * ctl[2] + c * beam_width + slot; uniforms / forced / probs_log then have B / beams columns. */
 int qarig_decode_sample(const float* logits, int64_t ldl, int B, int V, float temperature,
                         int end_token, int generate_mode, int64_t shift, const float* uniforms,
                         const int64_t* forced, int* ctl, int slot, int beam_width, int max_draws,
-                        int inc_len, int64_t* ids, int64_t* chunk, float* comb, float* probs_log,
-                        void* stream);
+                        int inc_len, int beams, int64_t* ids, int64_t* chunk, float* comb,
+                        float* probs_log, void* stream);
 
 /* After a candidate chunk: per image the beam with the largest product (first on ties) replaces the
  * kept chunk unless the kept product is >= (generate_images.py:325-337); take[n] = 1 + that beam or
- * 0; comb is reset to 1, ctl: candidate + 1, draws + beam_width, len back to the chunk start. */
-int qarig_decode_decide(int* ctl, int N, int NB, int beam_width, float* comb, const int64_t* chunk,
-                        float* best_p, int64_t* best_chunk, int* take, void* stream);
+ * 0; comb is reset to 1, ctl: candidate + 1, draws + `draws` (the draw rows the candidate set consumed),
+ * len back to the chunk start. */
+int qarig_decode_decide(int* ctl, int N, int NB, int beam_width, int draws, float* comb,
+                        const int64_t* chunk, float* best_p, int64_t* best_chunk, int* take, void* stream);
 
 /* Cache rows [ctl[1], ctl[1] + R) of the head-major kv (layers2 = layers * 2, N * NB, H, max_len, d):
  * restore == 0 copies the winning beam's rows of the images with take[n] > 0 into staged

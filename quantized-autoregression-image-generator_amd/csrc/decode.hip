@@ -609,12 +609,17 @@ __device__ __forceinline__ int wave_max_int(int x) {
 __global__ __launch_bounds__(64) void decode_sample_kernel(
     const float* __restrict__ logits, int64_t ldl, int B, int V, float temperature, int end_token,
     int generate_mode, int64_t shift, const float* __restrict__ uniforms, const int64_t* __restrict__ forced,
-    int* __restrict__ ctl, int slot, int bw, int max_draws, int inc_len, int64_t* __restrict__ ids,
+    int* __restrict__ ctl, int slot, int bw, int max_draws, int inc_len, int beams, int64_t* __restrict__ ids,
     int64_t* __restrict__ chunk, float* __restrict__ comb, float* __restrict__ probs_log) {
     __shared__ float part[64];
     const int b = blockIdx.x, lane = threadIdx.x;
     if (slot < 0) slot = min(max(ctl[CTL_TOK], 0), bw - 1);     // the slot the device counts
-    const int d = min(max(ctl[CTL_DRAW] + slot, 0), max_draws - 1);
+    // beams == 0: row b draws from column b of draw row ctl[2] + slot (B columns).  beams > 0: the rows are
+    // `beams` candidate chunks per image evaluated as one batch, and every draw keeps the number the reference's
+    // candidate-after-candidate loop gives it (generate_images.py:262-304): row b = image * beams + candidate
+    // reads column `image` of draw row ctl[2] + candidate * bw + slot (B / beams columns)
+    const int dcol = beams > 0 ? b / beams : b, dcols = beams > 0 ? B / beams : B;
+    const int d = min(max(ctl[CTL_DRAW] + (beams > 0 ? (b - dcol * beams) * bw : 0) + slot, 0), max_draws - 1);
     const float* z = logits + (int64_t)b * ldl;
     const int per = (V + 63) / 64, i0 = min(V, lane * per), i1 = min(V, i0 + per);
     float mx = -INFINITY;
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(64) void decode_sample_kernel(
     };
     float ps = 0.0f;
     int last_nz = -1;
-    float* lg = probs_log ? probs_log + ((int64_t)d * B + b) * V : nullptr;
+    float* lg = probs_log ? probs_log + ((int64_t)d * dcols + dcol) * V : nullptr;
     for (int i = i0; i < i1; ++i) {
         const float pr = prob(i);
         ps += pr;
@@ -645,7 +650,7 @@ __global__ __launch_bounds__(64) void decode_sample_kernel(
         if (k == lane) base = total;
         total += part[k];
     }
-    const float target = uniforms[(int64_t)d * B + b] * total;
+    const float target = uniforms[(int64_t)d * dcols + dcol] * total;
     int cand = 0x7fffffff;
     float run = base;
     for (int i = i0; i < i1; ++i) {
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(64) void decode_sample_kernel(
     const int fallback = wave_max_int(last_nz);       // rounding left the target at or past the total
     int64_t nxt = cand == 0x7fffffff ? max(fallback, 0) : cand;
     if (forced) {
-        const int64_t f = forced[(int64_t)d * B + b];
+        const int64_t f = forced[(int64_t)d * dcols + dcol];
         if (f >= 0 && f < V) nxt = f;
     }
     if (lane == 0) {
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(64) void decode_sample_kernel(
 // generate_images.py:325-337 keeps the earlier candidate unless the new product is larger -- and the
 // counters move on: next candidate, the draws it consumed, the cache position back at the chunk start.
 // take[n] = 1 + winning beam when the new chunk replaces the kept one, else 0.
-__global__ __launch_bounds__(64) void decode_decide_kernel(int* __restrict__ ctl, int N, int NB, int bw,
+__global__ __launch_bounds__(64) void decode_decide_kernel(int* __restrict__ ctl, int N, int NB, int bw, int draws,
                                                            float* __restrict__ comb,
                                                            const int64_t* __restrict__ chunk,
                                                            float* __restrict__ best_p,
@@ -697,7 +702,7 @@ __global__ __launch_bounds__(64) void decode_decide_kernel(int* __restrict__ ctl
     __syncthreads();
     if (threadIdx.x == 0) {
         ctl[CTL_CAND] = cand + 1;
-        ctl[CTL_DRAW] += bw;
+        ctl[CTL_DRAW] += draws;
         ctl[CTL_LEN] = ctl[CTL_CUR];
         ctl[CTL_TOK] = 0;
     }
@@ -958,8 +963,8 @@ extern "C" int qarig_decode_attention(const float* q, const float* k_new, const 
 extern "C" int qarig_decode_sample(const float* logits, int64_t ldl, int B, int V, float temperature,
                                    int end_token, int generate_mode, int64_t shift, const float* uniforms,
                                    const int64_t* forced, int* ctl, int slot, int beam_width, int max_draws,
-                                   int inc_len, int64_t* ids, int64_t* chunk, float* comb, float* probs_log,
-                                   void* stream) {
+                                   int inc_len, int beams, int64_t* ids, int64_t* chunk, float* comb,
+                                   float* probs_log, void* stream) {
     QARIG_CHECK_ARG(logits && uniforms && ctl && ids && chunk && comb, "decode_sample: null pointer");
     QARIG_CHECK_ARG(B > 0 && V > 0 && beam_width > 0 && max_draws > 0 && slot >= -1 && slot < beam_width,
                     "decode_sample: bad extents");
@@ -967,21 +972,22 @@ extern "C" int qarig_decode_sample(const float* logits, int64_t ldl, int B, int 
     QARIG_CHECK_DIMS("decode_sample", max_draws, B);
     QARIG_CHECK_DIMS("decode_sample", B, beam_width);
     QARIG_CHECK_ARG(ldl >= V && temperature > 0.0f, "decode_sample: ldl < V or temperature <= 0");
+    QARIG_CHECK_ARG(beams >= 0 && (beams == 0 || B % beams == 0), "decode_sample: beams must divide the rows");
     QARIG_CHECK_ARG(!probs_log || qarig_dims_ok({max_draws, B, V}), "decode_sample: probability log too large");
     hipLaunchKernelGGL(decode_sample_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, ldl, B, V,
                        temperature, end_token, generate_mode, shift, uniforms, forced, ctl, slot, beam_width,
-                       max_draws, inc_len, ids, chunk, comb, probs_log);
+                       max_draws, inc_len, beams, ids, chunk, comb, probs_log);
     QARIG_CHECK_LAUNCH("decode_sample");
     return QARIG_OK;
 }
 
-extern "C" int qarig_decode_decide(int* ctl, int N, int NB, int beam_width, float* comb, const int64_t* chunk,
-                                   float* best_p, int64_t* best_chunk, int* take, void* stream) {
+extern "C" int qarig_decode_decide(int* ctl, int N, int NB, int beam_width, int draws, float* comb,
+                                   const int64_t* chunk, float* best_p, int64_t* best_chunk, int* take, void* stream) {
     QARIG_CHECK_ARG(ctl && comb && chunk && best_p && best_chunk && take, "decode_decide: null pointer");
-    QARIG_CHECK_ARG(N > 0 && NB > 0 && beam_width > 0, "decode_decide: bad extents");
+    QARIG_CHECK_ARG(N > 0 && NB > 0 && beam_width > 0 && draws >= 0 && draws <= (1 << 24), "decode_decide: bad extents");
     QARIG_CHECK_DIMS("decode_decide", N, NB, beam_width);
-    hipLaunchKernelGGL(decode_decide_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, N, NB, beam_width, comb,
-                       chunk, best_p, best_chunk, take);
+    hipLaunchKernelGGL(decode_decide_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ctl, N, NB, beam_width, draws,
+                       comb, chunk, best_p, best_chunk, take);
     QARIG_CHECK_LAUNCH("decode_decide");
     return QARIG_OK;
 }

@@ -27,8 +27,9 @@ def parse_args():
                    help="File path to load json config file.")
     p.add_argument("--out-dir", required=True, type=pathlib.Path, help="File path to output directory.")
     p.add_argument("--batch-beams", action="store_true",
-                   help="(additive) evaluate the num_beam candidate chunks as one batch per model "
-                        "call; different RNG consumption order than the sequential reference loop.")
+                   help="(additive) number the draws of the num_beam candidate chunks by batch row instead of "
+                        "candidate after candidate as the reference loop does (the candidates are evaluated as one "
+                        "batch either way when images x num_beam <= 16; with --sampler torch this is what batches them).")
     p.add_argument("--sampler", choices=["fused", "torch"], default=None,
                    help="(additive) cached decoding: 'fused' (default) draws inside the decode loop's own kernel from "
                         "uniforms of the device generator -- the whole chunk search stays on the GPU; 'torch' makes one "

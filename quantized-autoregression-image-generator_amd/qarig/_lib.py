@@ -80,8 +80,8 @@ SIGNATURES = {
                                     P]),
     "qarig_decode_embed": (I, [P, I, I, I, P, P, P, I, I, P, L, P, P, P, P]),
     "qarig_decode_attention": (I, [P, P, P, P, P, I, I, I, I, P, I, L, L, L, F, P, L, P, P]),
-    "qarig_decode_sample": (I, [P, L, I, I, F, I, I, L, P, P, P, I, I, I, I, P, P, P, P, P]),
-    "qarig_decode_decide": (I, [P, I, I, I, P, P, P, P, P, P]),
+    "qarig_decode_sample": (I, [P, L, I, I, F, I, I, L, P, P, P, I, I, I, I, I, P, P, P, P, P]),
+    "qarig_decode_decide": (I, [P, I, I, I, I, P, P, P, P, P, P]),
     "qarig_decode_rows": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "qarig_decode_commit": (I, [P, I, I, I, P, P, L, P, P]),
     "qarig_decode_advance": (I, [P, I, P]),

@@ -374,12 +374,18 @@ class DecodeCache:
     # -- device-resident chunk search ----------------------------------------------------------
     @torch.no_grad()
     def begin_search(self, first_ids, images, beams, beam_width, temperature, end_token, shift, generate_mode,
-                     max_chunks, candidates, forced=None, log_probs=False, generator=None):
+                     max_chunks, candidates, forced=None, log_probs=False, generator=None, reference_order=False):
         """Prepares the search of generate_images.py:256-345 on `images` x `beams` cache rows (beams > 1:
         the candidate chunks of an image as rows of one batch; beams == 1: `candidates` chunks one after the
         other): evaluates the first token (window index 0), captures the step's graph, draws the uniforms of
-        every draw the stage can make (ONE call of the device generator).  forced: optional (draws, rows)
-        int64, entries >= 0 replace the draw (tests); log_probs: keep every probability row sampled from."""
+        every draw the stage can make (ONE call of the device generator).  forced: optional (draws, columns)
+        int64, entries >= 0 replace the draw (tests); log_probs: keep every probability row sampled from.
+
+        reference_order (beams > 1): the candidates of a chunk are independent given the kept prefix, so they
+        run as rows of one batch, but every draw keeps the number the reference's candidate-after-candidate
+        loop gives it -- draw (chunk * beams + candidate) * beam_width + slot, one column per image -- and the
+        first best candidate wins as in the reference's `>` comparison: the same tokens from the same draws as
+        beams == 1 with `candidates` = beams, at the cost of the batched search."""
         N, NB, bw = int(images), int(beams), int(beam_width)
         B, D, dev = self.batch, self.dim, self.kv.device
         if N * NB != B or self.dim % 4:
@@ -387,15 +393,21 @@ class DecodeCache:
         if self.model.use_pos_cond and self._table is None:
             raise ValueError("begin_search: a position-conditioned model needs the cache built with `positions`")
         V = _lin_params(self.model.classifier[1])[0].shape[0]
-        draws = max(1, int(max_chunks) * int(candidates) * bw)
-        s = SimpleNamespace(N=N, NB=NB, bw=bw, draws=draws, used=0, chunks=0, candidates=int(candidates))
-        s.uniforms = torch.rand((draws, B), device=dev, generator=generator)
+        ordered = bool(reference_order) and NB > 1
+        if ordered and int(candidates) != 1:
+            raise ValueError("begin_search: reference_order runs every candidate as a row (candidates must be 1)")
+        per_chunk = (NB if ordered else int(candidates)) * bw       # draw rows one chunk position consumes
+        cols = N if ordered else B
+        draws = max(1, int(max_chunks) * per_chunk)
+        s = SimpleNamespace(N=N, NB=NB, bw=bw, draws=draws, used=0, chunks=0, candidates=int(candidates),
+                            beams=NB if ordered else 0, per_set=NB * bw if ordered else bw)
+        s.uniforms = torch.rand((draws, cols), device=dev, generator=generator)
         s.forced = None
         if forced is not None:
-            s.forced = torch.full((draws, B), -1, dtype=torch.int64, device=dev)
-            f = torch.as_tensor(forced, dtype=torch.int64, device=dev).reshape(-1, B)[:draws]
+            s.forced = torch.full((draws, cols), -1, dtype=torch.int64, device=dev)
+            f = torch.as_tensor(forced, dtype=torch.int64, device=dev).reshape(-1, cols)[:draws]
             s.forced[:f.shape[0]] = f
-        s.probs = torch.zeros((draws, B, V), dtype=torch.float32, device=dev) if log_probs else None
+        s.probs = torch.zeros((draws, cols, V), dtype=torch.float32, device=dev) if log_probs else None
         s.ids = torch.zeros(B, dtype=torch.int64, device=dev)
         s.comb = torch.ones(B, dtype=torch.float32, device=dev)
         s.chunk = torch.zeros((B, bw), dtype=torch.int64, device=dev)
@@ -437,7 +449,7 @@ class DecodeCache:
     def _draw(self, slot, src, inc):
         s = self._search
         ops.decode_sample(src, s.T, s.end, s.gen, s.shift, s.uniforms, self.ctl, slot, s.bw, s.ids, s.chunk, s.comb,
-                          forced=s.forced, probs_log=s.probs, inc_len=inc)
+                          forced=s.forced, probs_log=s.probs, inc_len=inc, beams=s.beams)
 
     @torch.no_grad()
     def run_chunk(self, last=False):
@@ -451,7 +463,7 @@ class DecodeCache:
             for _ in range(1, bw):
                 s.g_step.replay()                           # the token just drawn, at window index ctl[0]
                 self._draw(-1, s.logits, True)              # slot = steps since the candidate began (ctl[4])
-            ops.decode_decide(self.ctl, N, NB, bw, s.comb, s.chunk, s.best_p, s.best_chunk, s.take)
+            ops.decode_decide(self.ctl, N, NB, bw, s.comb, s.chunk, s.best_p, s.best_chunk, s.take, draws=s.per_set)
             if bw > 1:
                 ops.decode_rows(self.ctl, self.kv, s.staged, s.take, N, NB, restore=False)
         if bw > 1:
@@ -461,7 +473,7 @@ class DecodeCache:
             s.g_step.replay()
             s.last.copy_(s.logits)
         ops.decode_advance(self.ctl, bw)
-        s.used += s.candidates * bw
+        s.used += s.candidates * s.per_set
         s.chunks += 1
 
     def finish_search(self):

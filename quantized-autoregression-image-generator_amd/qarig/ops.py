@@ -998,28 +998,33 @@ def decode_embed(ids, table, pe, ctl=None, length=0, proj_table=None, proj_row=N
 
 
 def decode_sample(logits, temperature, end_token, generate_mode, shift, uniforms, ctl, slot, beam_width, ids,
-                  chunk, comb, forced=None, probs_log=None, inc_len=False):
-    """One draw per row of logits (B, V): see include/qarig.h qarig_decode_sample."""
+                  chunk, comb, forced=None, probs_log=None, inc_len=False, beams=0):
+    """One draw per row of logits (B, V): see include/qarig.h qarig_decode_sample.  beams > 0: candidate-major
+    draw numbering, uniforms / forced / probs_log have B // beams columns."""
     require_cuda(logits, uniforms, ctl, ids, chunk, comb, forced, probs_log)
     B, V = logits.shape
     max_draws = uniforms.shape[0]
-    assert logits.stride(1) == 1 and uniforms.shape == (max_draws, B) and uniforms.is_contiguous()
+    cols = B // beams if beams else B
+    assert logits.stride(1) == 1 and uniforms.shape == (max_draws, cols) and uniforms.is_contiguous()
     assert ids.dtype == chunk.dtype == torch.int64 and ids.numel() == B and chunk.shape == (B, beam_width)
     assert comb.shape == (B,) and comb.dtype == torch.float32 and ctl.dtype == torch.int32
-    assert forced is None or (forced.shape == (max_draws, B) and forced.dtype == torch.int64 and forced.is_contiguous())
-    assert probs_log is None or (probs_log.shape == (max_draws, B, V) and probs_log.is_contiguous())
+    assert forced is None or (forced.shape == (max_draws, cols) and forced.dtype == torch.int64 and forced.is_contiguous())
+    assert probs_log is None or (probs_log.shape == (max_draws, cols, V) and probs_log.is_contiguous())
     check(_lib.load().qarig_decode_sample(ptr(logits), logits.stride(0), B, V, float(temperature), int(end_token),
                                           int(bool(generate_mode)), int(shift), ptr(uniforms), ptr(forced), ptr(ctl),
-                                          int(slot), int(beam_width), max_draws, int(bool(inc_len)), ptr(ids),
-                                          ptr(chunk), ptr(comb), ptr(probs_log), stream()), "qarig_decode_sample")
+                                          int(slot), int(beam_width), max_draws, int(bool(inc_len)), int(beams),
+                                          ptr(ids), ptr(chunk), ptr(comb), ptr(probs_log), stream()),
+          "qarig_decode_sample")
 
 
-def decode_decide(ctl, N, NB, beam_width, comb, chunk, best_p, best_chunk, take):
+def decode_decide(ctl, N, NB, beam_width, comb, chunk, best_p, best_chunk, take, draws=None):
+    """draws: draw rows the candidate set consumed (default beam_width: one candidate chunk per row)."""
     require_cuda(ctl, comb, chunk, best_p, best_chunk, take)
     assert comb.numel() == N * NB and chunk.shape == (N * NB, beam_width) and best_chunk.shape == (N, beam_width)
     assert best_p.numel() == N and take.numel() == N and take.dtype == torch.int32
-    check(_lib.load().qarig_decode_decide(ptr(ctl), N, NB, beam_width, ptr(comb), ptr(chunk), ptr(best_p),
-                                          ptr(best_chunk), ptr(take), stream()), "qarig_decode_decide")
+    check(_lib.load().qarig_decode_decide(ptr(ctl), N, NB, beam_width, int(beam_width if draws is None else draws),
+                                          ptr(comb), ptr(chunk), ptr(best_p), ptr(best_chunk), ptr(take), stream()),
+          "qarig_decode_decide")
 
 
 def decode_rows(ctl, kv, staged, take, N, NB, restore):

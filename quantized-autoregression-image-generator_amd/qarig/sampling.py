@@ -48,6 +48,7 @@ def _cacheable(model, hr_input, use_sliding_window):
 # the reference does on --device cuda (same generator stream as the reference for a given seed, ~8 extra
 # launches and a graph boundary per token).  QARIG_SAMPLER overrides the default.
 DEFAULT_SAMPLER = "fused"
+ORDERED_ROWS = 16        # images x candidates the reference-order search runs as one batch (decode kernels: <= 16 rows)
 
 # Test hook of the fused sampler: {"forced": (draws, rows) int64 tensor or None, "log": bool}; after a stage
 # "probs" holds the (draws, rows, V) probability rows it sampled from and "draws" their number.
@@ -87,7 +88,12 @@ def _generate_fused(model, hr_input, enc, total_seq, temperature, use_sliding_wi
     the kept tokens but the last) serves the evaluations of the next chunk that come before the window slides."""
     device = hr_input.device
     N = hr_input.shape[0]
-    B = num_beam if batch_beams and num_beam > 1 else 1
+    # The candidate chunks of a position are independent given the kept prefix: they run as rows of one batch
+    # either way.  Without --batch-beams every draw keeps the number the reference's candidate loop gives it
+    # (begin_search reference_order: same draws -> same tokens as one candidate after the other) as long as the
+    # rows fit the single-token kernels (16); beyond that the candidates run one after the other.
+    ordered = not batch_beams and num_beam > 1 and N * num_beam <= ORDERED_ROWS
+    B = num_beam if (batch_beams or ordered) and num_beam > 1 else 1
     cap = stop_len + beam_width
     limit = min(cap, sliding_window) if use_sliding_window else cap
     pos = torch.zeros((N, 1), device=device) if use_sliding_window else None
@@ -106,7 +112,8 @@ def _generate_fused(model, hr_input, enc, total_seq, temperature, use_sliding_wi
     tm.mark("cache")
     dbg = FUSED_DEBUG or {}
     cache.begin_search(hr_input[:, 0], N, B, beam_width, temperature, end_token, shift, mode == "generate",
-                       chunks, 1 if B > 1 else num_beam, forced=dbg.get("forced"), log_probs=bool(dbg.get("log")))
+                       chunks, 1 if B > 1 else num_beam, forced=dbg.get("forced"), log_probs=bool(dbg.get("log")),
+                       reference_order=ordered)
     tm.mark("capture")
     for c in range(chunks):
         cache.run_chunk(last=c == chunks - 1)
@@ -235,9 +242,11 @@ def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_slidi
         (256 tokens in a 256-token window) evaluates all but its final token from it instead of re-running the
         window (each candidate rewrites the rows it reads; nothing reads the cache after this chunk)."""
         n = t_in.shape[1]
-        if cache is not None and n - 1 < cache.max_len and t_in.shape[0] == cache.batch and \
+        if cache is not None and n - 1 < cache.max_len and cache.batch % t_in.shape[0] == 0 and \
                 (not use_sliding_window or n < sliding_window):
-            return cache.step(t_in[:, -1], None, n - 1)
+            k = cache.batch // t_in.shape[0]        # cache rows per sequence (candidates ran as rows): all equal
+            ids = t_in[:, -1] if k == 1 else t_in[:, -1].repeat_interleave(k)
+            return cache.step(ids, None, n - 1)[::k]
         # the loop's positions are whole numbers (cur + tok + pos_off): as int64 the model evaluates the
         # conditioning path once per POSITION instead of once per token (Transformer._cond; same values)
         if t_pos is None or not hasattr(model, "_cond"):

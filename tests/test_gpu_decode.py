@@ -232,6 +232,50 @@ def test_decode_sample_is_the_references_draw(V):
     assert float((comb[2].double() - 0.5 * want[2, end])).__abs__() < 1e-6           # the product saw p[<end>]
 
 
+def test_decode_sample_candidate_major_draw_numbers():
+    """beams > 0: row image * beams + c draws with the number the reference's candidate loop gives that draw --
+    (candidate c) * beam_width + slot behind ctl[2], one column per image (generate_images.py:262-304) -- so the
+    candidates run as rows of one batch and still consume the draws of the sequential order."""
+    from qarig import ops
+    g = torch.Generator().manual_seed(5)
+    N, NB, bw, V, end, T = 3, 4, 4, 41, 40, 0.9
+    B, draws = N * NB, 2 * NB * bw
+    logits = (torch.randn((B, V), generator=g) * 2).cuda()
+    uniforms = torch.rand((draws, N), generator=g).cuda()
+    ctl = torch.zeros(ops.DECODE_CTL_WORDS, dtype=torch.int32, device="cuda")
+    base, slot = NB * bw, 2
+    ctl[2] = base
+    ids = torch.zeros(B, dtype=torch.int64, device="cuda")
+    chunk = torch.zeros((B, bw), dtype=torch.int64, device="cuda")
+    comb = torch.ones(B, device="cuda")
+    probs = torch.zeros((draws, N, V), device="cuda")
+    ops.decode_sample(logits, T, end, True, 0, uniforms, ctl, slot, bw, ids, chunk, comb, probs_log=probs, beams=NB)
+    want = torch.softmax(logits.double() / T, dim=1)
+    want[:, end] = 0
+    cdf = torch.cumsum(want, dim=1)
+    used = torch.zeros(draws, dtype=torch.bool)
+    for n in range(N):
+        for c in range(NB):
+            r, d = n * NB + c, base + c * bw + slot
+            used[d] = True
+            assert float((probs[d, n].double() - want[r]).abs().max()) < 1e-6
+            target = float(uniforms[d, n].double() * cdf[r, -1])
+            tok = int(ids[r])
+            assert float(cdf[r, tok] - want[r, tok]) - 1e-6 <= target < float(cdf[r, tok]) + 1e-6
+            assert abs(float(comb[r]) - float(want[r, tok])) < 1e-6
+    assert not probs[~used].any()
+    # forced entries follow the same numbering
+    forced = torch.full((draws, N), -1, dtype=torch.int64, device="cuda")
+    for n in range(N):
+        for c in range(NB):
+            forced[base + c * bw + slot, n] = (7 * n + c) % end
+    ops.decode_sample(logits, T, end, True, 0, uniforms, ctl, slot, bw, ids, chunk, comb, forced=forced, beams=NB)
+    assert ids.view(N, NB).tolist() == [[(7 * n + c) % end for c in range(NB)] for n in range(N)]
+    with pytest.raises(Exception):
+        ops.decode_sample(logits[:B - 1], T, end, True, 0, uniforms, ctl, slot, bw, ids[:B - 1], chunk[:B - 1],
+                          comb[:B - 1], beams=NB)
+
+
 def test_decode_sample_frequencies_follow_the_distribution():
     from qarig import ops
     g = torch.Generator().manual_seed(0)
@@ -285,9 +329,10 @@ def test_chunk_bookkeeping_kernels_follow_the_reference_rule(N, NB, bw):
         ref_p = cbest.clone() if ref_p is None else torch.where(tk, cbest, ref_p)
         ref_chunk = chunk[pick].clone() if ref_chunk is None else torch.where(tk[:, None], chunk[pick], ref_chunk)
         ref_rows = new_rows if ref_rows is None else torch.where(tk[None, None, :, None, None, None], new_rows, ref_rows)
-        ops.decode_decide(ctl, N, NB, bw, comb, chunk, best_p, best_chunk, take)
+        per_set = NB * bw if NB == 2 else bw          # (one case counts the draws of a candidate-major set)
+        ops.decode_decide(ctl, N, NB, bw, comb, chunk, best_p, best_chunk, take, draws=per_set)
         assert torch.equal(take.bool(), tk) and torch.equal(take[tk].long() - 1, pb[tk])
-        assert (comb == 1).all() and int(ctl[3]) == c + 1 and int(ctl[2]) == 40 + (c + 1) * bw and int(ctl[0]) == cur
+        assert (comb == 1).all() and int(ctl[3]) == c + 1 and int(ctl[2]) == 40 + (c + 1) * per_set and int(ctl[0]) == cur
         if bw > 1:
             ops.decode_rows(ctl, kv, staged, take, N, NB, restore=False)
         assert torch.equal(best_p, ref_p) and torch.equal(best_chunk, ref_chunk)
@@ -303,4 +348,4 @@ def test_chunk_bookkeeping_kernels_follow_the_reference_rule(N, NB, bw):
     assert torch.equal(tokens[:, cur:cur + bw], ref_chunk) and not tokens[:, :cur].any() and not tokens[:, cur + bw:].any()
     assert torch.equal(ids, ref_chunk[:, -1].repeat_interleave(NB)) and int(ctl[0]) == cur + bw - 1
     ops.decode_advance(ctl, bw)
-    assert ctl[:4].tolist() == [cur + bw, cur + bw, 40 + cands * bw, 0]
+    assert ctl[:4].tolist() == [cur + bw, cur + bw, 40 + cands * per_set, 0]

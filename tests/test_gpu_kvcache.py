@@ -199,7 +199,7 @@ def test_decode_cache_step_matches_full_window(use_encoder, graph, wide):
             cache.step(ids[:, 0], pos[:, 0], S)
 
 
-@pytest.mark.parametrize("sampler", ["torch", "fused"])
+@pytest.mark.parametrize("sampler", ["torch", "fused", "fused-one-by-one"])
 @pytest.mark.parametrize("use_encoder,num_beam,bw,batch_beams,wide", [
     (False, 1, 1, False, False), (False, 3, 4, False, False), (True, 2, 4, False, False),
     (True, 3, 2, True, False), (False, 2, 4, True, False), (True, 2, 4, False, True),
@@ -209,9 +209,16 @@ def test_cached_generation_matches_full_window_loop(use_encoder, num_beam, bw, b
     """The cached loop (then its windowed continuation once the window slides) must emit the tokens of the
     reference-style full-window loop.  sampler "torch": same seed, same torch.multinomial call order;
     "fused": the full-window run's draws are recorded and forced into the in-graph sampler, whose probability
-    row must equal the recorded one at every draw."""
+    row must equal the recorded one at every draw -- without batch_beams the candidates of a chunk run as rows of
+    one batch under the reference's draw numbers; "fused-one-by-one": the candidates one after the other (what
+    more than 16 rows fall back to)."""
     from conftest import DrawTape
     from qarig import sampling
+    if sampler == "fused-one-by-one":
+        if batch_beams or num_beam == 1:
+            pytest.skip("same path as 'fused'")
+        monkeypatch.setattr(sampling, "ORDERED_ROWS", 0)
+        sampler = "fused"
     m = _model(use_encoder, heads=32, dim=256, hidden=512) if wide else _model(use_encoder)
     with torch.no_grad():
         m.classifier[1].linear_layer[0].bias[40] -= 20.0     # <end> out of the way

@@ -136,8 +136,8 @@ call("qarig_decode_linear_f32", X, 2048, 0, 0.0, None, None, None, None, 0, X, 2
 call("qarig_decode_embed", X, 16, 512, 1025, X, X, X, 0, 256, X, 63 * 512, X, X, X, None)
 call("qarig_decode_attention", X, X, X, X, X, 16, 64, 8, 0, X, 256, 256 * 512, 256 * 8, 8, 8.0 ** 0.5, X, 0, X, None)
 call("qarig_decode_attention", X, None, None, X, X, 4, 64, 8, 64, None, 64, 64 * 512, 8, 512, 8.0 ** 0.5, None, 0, X, None)
-call("qarig_decode_sample", X, 513, 16, 513, 1.0, 512, 1, 512, X, None, X, 3, 4, 1024, 1, X, X, X, None, None)
-call("qarig_decode_decide", X, 4, 4, 4, X, X, X, X, X, None)
+call("qarig_decode_sample", X, 513, 16, 513, 1.0, 512, 1, 512, X, None, X, 3, 4, 1024, 1, 4, X, X, X, None, None)
+call("qarig_decode_decide", X, 4, 4, 4, 16, X, X, X, X, X, None)
 call("qarig_decode_rows", X, X, X, X, 14, 4, 4, 64, 3, 8, 256, 0, None)
 call("qarig_decode_rows", X, X, X, None, 14, 4, 1, 64, 3, 8, 256, 1, None)
 call("qarig_decode_commit", X, 4, 4, 4, X, X, 260, X, None)

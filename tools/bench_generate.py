@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--num-beam", type=int, default=4)
     ap.add_argument("--beam-width", type=int, default=4)
     ap.add_argument("--batch-beams", action="store_true")
+    ap.add_argument("--one-by-one", action="store_true",
+                    help="fused sampler without --batch-beams: run the candidates of a chunk literally one after the "
+                         "other instead of as rows of one batch under the reference's draw numbers")
     ap.add_argument("--no-kv-cache", action="store_true")
     ap.add_argument("--sampler", choices=["fused", "torch"], default=None,
                     help="cached loop: in-graph sampling kernel (default) or one torch.multinomial per token")
@@ -69,6 +72,8 @@ def main():
                     help="skip the untimed warm-up pass (code-object loads, allocator growth, "
                          "first graph instantiation then land in stage 0)")
     args = ap.parse_args()
+    if args.one_by_one:
+        sampling.ORDERED_ROWS = 0
     dev = torch.device("cuda", 0)
     torch.manual_seed(69)
     K, N = 512, args.images
@@ -79,6 +84,7 @@ def main():
                      latent_channel=4).to(dev).eval()
     out = {"config": f"cascade generate, {args.stages} stages, N={N}, num_beam={args.num_beam}, "
                      f"beam_width={args.beam_width}, window 256, fp32, batch_beams={args.batch_beams}, "
+                     f"candidates={'one by one' if args.one_by_one else 'rows of one batch'}, "
                      f"kv_cache={not args.no_kv_cache}, sampler={args.sampler or sampling.DEFAULT_SAMPLER}, warm={not args.cold}"}
     prev0 = torch.randint(0, K, (N, 1), device=dev)
     if not args.cold:

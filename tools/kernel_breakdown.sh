@@ -6,7 +6,7 @@ set -e -o pipefail
 TAG=$1; STEPS=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 W=1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -- python3 bench.py --steps $STEPS --warmup $W --no-kernel-events --no-cpu-baseline "$@" > gpurun_out/${TAG}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -- python3 bench.py --steps $STEPS --warmup $W --no-kernel-events --no-cpu-baseline --no-side-configs "$@" > gpurun_out/${TAG}_stats.log 2>&1
 F=$(find gpurun_out/${TAG}_stats -name '*kernel_stats.csv' | head -1)
 cp "$F" gpurun_out/${TAG}_kernel_stats.csv
 rm -rf gpurun_out/${TAG}_stats

@@ -5,7 +5,7 @@
 # The program itself follows `--` (python3 bench.py ...), never a shell wrapper.
 set -e -o pipefail
 TAG=${1:-r02}; shift || true
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-side-configs $*"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1
