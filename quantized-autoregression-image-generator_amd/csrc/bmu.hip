@@ -1132,11 +1132,16 @@ using namespace qarig;
 //   * every operand is split into three bf16 pieces, v = h + m + l EXACTLY (3 x 8 = 24 mantissa
 //     bits, successive round-to-nearest remainders), and the six products hh, hm, mh, hl, lh, mm are
 //     accumulated in fp32 by six v_mfma_f32_32x32x16_bf16 (K = 16 = the whole patch width in one
-//     instruction); |w|^2 (its exact fp32 chain, split the same way) enters through a seventh MFMA
-//     against a row of ones.  7 x 32 = 224 matrix cycles per tile, under the scan's ~256.
-//   * what the coarse value can be off by: the three dropped products (<= 2^-26 |x||2w| per element)
-//     and the rounding of at most 7 x 16 fp32 additions, against the definition's own 17-step chain:
-//     |t~ - t| <= eps = 1e-5 (|x|^2 + 2 max|w|^2)  (gamma_112 = 6.7e-6 on sum|terms| <= 2|x||w| + |w|^2).
+//     instruction); |w|^2 (its exact fp32 chain) is the accumulator's initial value, read from an LDS
+//     copy in accumulator order.  6 x 32 = 192 matrix cycles per tile, beside the scan's ~200.
+//   * the scan is three vector instructions per candidate: the candidate's register number (which of the
+//     16 codes of its tile and lane half) replaces the low four bits of its value (v_and_or_b32), then
+//     second = median(min, t, second), min = median(min, t, -inf): no compare / select pair, and the
+//     minimum's code comes out of its own low bits.
+//   * what the coarse value can be off by: the three dropped products (<= 2^-26 |x||2w| per element),
+//     the rounding of the 6 x 16 fp32 additions inside the matrix core, the four replaced bits
+//     (15 ulp), against the definition's own 17-step chain:
+//     |t~ - t| <= eps = 1e-5 (|x|^2 + 2 max|w|^2)  (sum|terms| <= 2|x||w| + |w|^2; BMU_COARSE_EPS below).
 //   * certificate: the scan keeps (min, its first index, second-smallest) of t~ per row.  If
 //     second - min > 3 eps, the exact minimum is the same candidate and no other candidate can tie
 //     with it after the definition's `+ |x|^2`, clamp and sqrt (those collapse values closer than
@@ -1166,6 +1171,12 @@ __device__ __forceinline__ bool bmu_split3(float a, float b, uint32_t& H, uint32
     const float la = __uint_as_float(L << 16), lb = __uint_as_float(L & 0xffff0000u);
     return (ha + ma) + la == a && (hb + mb) + lb == b;
 }
+// where code k's |w|^2 sits in the accumulator-ordered copy: the accumulator register r of lane half h of tile T
+// holds code 32 T + 4 h + (r & 3) + 8 (r >> 2)
+__device__ __forceinline__ int bmu_w2_at(int k) {
+    const int c = k & 31;
+    return ((k >> 5) * 2 + ((c >> 2) & 1)) * 16 + (c & 3) + 4 * (c >> 3);
+}
 __device__ __forceinline__ float bmu_join3(uint32_t H, uint32_t M, uint32_t L, int hi) {
     const uint32_t mask = hi ? 0xffff0000u : 0u;
     const float h = __uint_as_float(hi ? (H & mask) : (H << 16));
@@ -1174,24 +1185,27 @@ __device__ __forceinline__ float bmu_join3(uint32_t H, uint32_t M, uint32_t L, i
     return (h + m) + l;
 }
 
-// Bound of |coarse value - the definition's fp32 chain| in units of (|x|^2 + 2 max|w|^2).  The derivation charges
-// every one of the 7 x 16 additions inside the matrix core a rounding of u = 2^-24 of the running magnitude
-// (gamma_112 = 6.7e-6 on sum|terms|), plus the dropped piece products (2^-26 |x||2w| per element) and the 17-step
-// rounding of the definition's own chain: 7.7e-6 in all.  What v_mfma_f32_32x32x16_bf16 really does was measured
+// Bound of |coarse value - the definition's fp32 chain| in units of S = |x|^2 + 2 max|w|^2 (u = 2^-24):
+//   * the 6 x 16 additions inside the matrix core, each charged a rounding of u of the running magnitude
+//     (<= sum|terms| <= 2|x||w| + |w|^2 <= S):                                     gamma_96  = 5.7e-6
+//   * the three dropped piece products, 2^-26 |x||2w| per element:                              0.05e-6
+//   * the candidate's register number in its low four bits: <= 15 ulp = 30 u:                   1.8e-6
+//   * the 17-step rounding of the definition's own chain:                                       1.0e-6
+//   in all 8.6e-6 <= eps = 1e-5.  What v_mfma_f32_32x32x16_bf16 really does was measured
 // (tools/mfma_rounding_probe.hip, profiles/r04_mfma_rounding.log): the 16 products and C are aligned to the
 // largest exponent among them with ONE guard bit, bits below it are dropped (a product of 0.75 ulp beside 1.0
 // contributes 0.5 ulp; sixteen products of 1/16 ulp beside C = 1 vanish), the sum is then rounded to nearest even
 // (C = 1 plus 0.75 ulp gives 1 + 1 ulp, ties go to even).  Worst case per instruction: 16 x 2^-25 of the largest
-// addend from the alignment + 2^-24 from the final rounding = 9 u of it, i.e. 63 u over the seven instructions --
-// inside the 112 u the derivation charges.  So eps = 1e-5 stands; with the certificate's factor 3 the remaining true
-// gap exceeds 1.4e-5 of the scale, far above what clamp + sqrt can collapse (2^-22).  (2e-5 was tried: the 65,536 x
+// addend from the alignment + 2^-24 from the final rounding = 9 u of it, i.e. 54 u = 3.2e-6 over the six
+// instructions -- inside the 96 u the derivation charges.  With the certificate's factor 3 the remaining true
+// gap exceeds 1e-5 of the scale, far above what clamp + sqrt can collapse (2^-22).  (2e-5 was tried: the 65,536 x
 // 512 x 16 launch re-scans 148 rows instead of 73 and takes 18.4 instead of 16.3 us.)
 // tests/test_gpu_core.py::test_bmu_coarse_pass_on_constructed_near_ties sweeps code pairs whose gap runs from
 // far below eps to above 4 eps.
 constexpr float BMU_COARSE_EPS = 1e-5f;
 
 // PREP: stages the image of a codebook (what every block of the search kernel builds in LDS) into
-// `image` instead: [planes: K x 128 B][|w|^2: K x 4 B][max |w|^2, inexact flag: 8 B].  A frozen
+// `image` instead: [3 planes: K x 96 B][|w|^2 in accumulator order: K x 4 B][max |w|^2, inexact flag: 8 B].  A frozen
 // codebook (tokenising a dataset, the Transformer training loop) is prepared once and its image
 // copied into LDS by every later launch (qarig_bmu_prepare).
 template <bool PREP>
@@ -1201,12 +1215,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_coarse_kernel(PatchGeom g, Pa
                                                                  unsigned* __restrict__ stats,
                                                                  const unsigned char* __restrict__ image_in,
                                                                  unsigned char* __restrict__ image_out) {
-    // planes [hi | mid | lo | w2-pieces] of fragments: [plane][tile][half][code] x 16 B
+    // planes [hi | mid | lo] of fragments: [plane][tile][half][code] x 16 B
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     bmu_u32x4* frag = reinterpret_cast<bmu_u32x4*>(lds_raw);
     const int NT = K >> 5;
     const int plane = NT * 64;                                  // fragments per plane
-    float* W2 = reinterpret_cast<float*>(frag + 4 * plane);     // [K] exact |w|^2 chains
+    // exact |w|^2 chains in the accumulator's order: [tile][lane half][register] (bmu_w2_at)
+    float* W2 = reinterpret_cast<float*>(frag + 3 * plane);
     float* XS = W2 + K;                                         // [128][16] the block's patch rows, fp32
     float* red = XS + 128 * 16;                                 // [8] reductions, [8..12) flag masks, [12] inexact
     unsigned* flagmask = reinterpret_cast<unsigned*>(red + 8);
@@ -1233,23 +1248,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_coarse_kernel(PatchGeom g, Pa
     // pass with all eight 16-B loads in flight
     float w2max = 0.0f;
     int inexact = 0;
-    const size_t image_bytes = (size_t)K * 132;               // planes + |w|^2 (a multiple of 16: K % 32 == 0)
+    const size_t image_bytes = (size_t)K * 100;               // planes + |w|^2 (a multiple of 16: K % 32 == 0)
     if (!PREP && image_in) {
-        // a prepared image: straight into LDS, 16 B per lane, every load of a pass in flight
+        // a prepared image: global -> LDS without a register round trip (1 KiB per wave instruction, every piece
+        // of the image in flight at once); the last partial KiB through registers
+        const int n16 = (int)(image_bytes >> 4);
+        const int nblk = n16 >> 6;
+        for (int b = wave; b < nblk; b += NTHREADS / 64)
+            __builtin_amdgcn_global_load_lds(
+                (__attribute__((address_space(1))) const void*)(image_in + ((size_t)b * 64 + lane) * 16),
+                (__attribute__((address_space(3))) void*)(lds_raw + (size_t)b * 1024), 16, 0, 0);
         const uint4* src = reinterpret_cast<const uint4*>(image_in);
         uint4* dst = reinterpret_cast<uint4*>(lds_raw);
-        const int n16 = (int)(image_bytes >> 4);
-        for (int i = tid; i < n16; i += 8 * NTHREADS) {
-            uint4 t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = src[min(i + u * NTHREADS, n16 - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (i + u * NTHREADS < n16) dst[i + u * NTHREADS] = t[u];
-        }
+        if (nblk * 64 + tid < n16) dst[nblk * 64 + tid] = src[nblk * 64 + tid];
         const float* hdr = reinterpret_cast<const float*>(image_in + image_bytes);
         w2max = hdr[0];
         inexact = hdr[1] != 0.0f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the barrier below publishes the image)
     } else
     for (int k0 = tid; k0 < K; k0 += 2 * NTHREADS) {
         float4 raw[2][4];
@@ -1272,7 +1287,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_coarse_kernel(PatchGeom g, Pa
             float w2 = 0.0f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) w2 = e < D ? fmaf(v[e], v[e], w2) : w2;
-            W2[k] = w2;
+            W2[bmu_w2_at(k)] = w2;
             w2max = fmaxf(w2max, w2);
             if (!(w2 <= 3.0e38f)) inexact = 1;          // a NaN / Inf code: the definition's clamp decides, exactly
             const int T = k >> 5, c = k & 31;
@@ -1290,17 +1305,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_coarse_kernel(PatchGeom g, Pa
                 frag[plane + at] = M;
                 frag[2 * plane + at] = L;
             }
-            // |w|^2 = three bf16 pieces (k = 0, 1, 2 of the seventh MFMA, against ones)
-            const float q0 = __uint_as_float(bmu_pack_bf16(w2, 0.0f) << 16);
-            const float r1 = w2 - q0;
-            const uint32_t P01 = bmu_pack_bf16(w2, r1);
-            const float q1 = __uint_as_float(P01 & 0xffff0000u);
-            const float r2 = r1 - q1;
-            const uint32_t P2 = bmu_pack_bf16(r2, 0.0f);
-            if ((q0 + q1) + __uint_as_float(P2 << 16) != w2) inexact = 1;
-            const int at = (T * 2) * 32 + c;
-            frag[3 * plane + at] = bmu_u32x4{P01, P2, 0u, 0u};
-            frag[3 * plane + at + 32] = bmu_u32x4{0u, 0u, 0u, 0u};
         }
     }
     float x2a = 0.0f;
@@ -1319,7 +1323,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_coarse_kernel(PatchGeom g, Pa
         for (int q = 0; q < 8; ++q) XS[(wave * 32 + cl) * 16 + 8 * h + q] = xv[q];
         x2a += __shfl_xor(x2a, 32);
     }
-    const bmu_u32x4 ONES = h == 0 ? bmu_u32x4{0x3f803f80u, 0x00003f80u, 0u, 0u} : bmu_u32x4{0u, 0u, 0u, 0u};
     // block-wide max |w|^2 and the inexact flag
     w2max = wave_max(w2max);
     inexact = __any(inexact);
@@ -1340,80 +1343,88 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_coarse_kernel(PatchGeom g, Pa
     }
 
     const long long tc1 = stats ? clock64() : 0;
-    // ---- the coarse scan, software-pipelined: the seven MFMAs of tile T+1 (a dependent chain of
+    // ---- the coarse scan, software-pipelined: the six MFMAs of tile T+1 (a dependent chain of
     // 32-cycle instructions on the matrix pipe) are issued between the scan steps of tile T (8
-    // vector-ALU instructions = 32 cycles each pair of steps), so neither pipe waits for the other
-    // scan state: (min, second-smallest) of t~ and WHERE the minimum first appeared -- the register index
-    // r inside its tile (an inline constant of the select: no per-candidate code arithmetic) and the tile
+    // vector-ALU instructions = 32 cycles per MFMA), so neither pipe waits for the other.
+    // scan state: (min, second-smallest) of t~, the minimum carrying its register number in its low four bits,
+    // and the tile in which the minimum last fell
     float best = INFINITY, sec = INFINITY;
-    int ridx = 0, tidx = -1;
+    int tidx = -1;
+    float ninf = -INFINITY;
+    asm volatile("" : "+v"(ninf));          // opaque: median(min, t, -inf) must stay ONE v_med3_f32 (as a constant the
+                                            // compiler turns it into v_max (canonicalise) + v_min)
     const bmu_bf16x8 bXH = __builtin_bit_cast(bmu_bf16x8, XH), bXM = __builtin_bit_cast(bmu_bf16x8, XM),
-                     bXL = __builtin_bit_cast(bmu_bf16x8, XL), bON = __builtin_bit_cast(bmu_bf16x8, ONES);
+                     bXL = __builtin_bit_cast(bmu_bf16x8, XL);
     const bmu_u32x4* fl = frag + h * 32 + cl;
-    f32x16 zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
-    // fragments of a tile: [0] hi, [1] mid, [2] lo, [3] |w|^2 pieces; double-buffered, a tile's fragments
-    // are read from LDS one whole step before the MFMAs that take them
-#define BMU_FRAGS(F, T_)                                                                            \
+    const float4* w2l = reinterpret_cast<const float4*>(W2) + h * 4;
+    // fragments of a tile: [0] hi, [1] mid, [2] lo; its |w|^2 (accumulator order) goes straight into the
+    // accumulator that will chain it.  Three sets in rotation: while tile T is scanned (CUR) and tile T + 1 chained
+    // (NXT, from fragments read a step ago), the fragments and |w|^2 of tile T + 2 land in the third set (NN, whose
+    // last scan ended a step ago) -- no LDS read is waited for in the step that issued it, no register copies
+#define BMU_FRAGS(F, ACC, T_)                                                                       \
     {                                                                                               \
-        const int t_ = min(T_, NT - 1) * 64;                                                         \
+        const int tt_ = min(T_, NT - 1);                                                             \
+        const int t_ = tt_ * 64;                                                                     \
         F[0] = __builtin_bit_cast(bmu_bf16x8, fl[t_]);                                               \
         F[1] = __builtin_bit_cast(bmu_bf16x8, fl[plane + t_]);                                       \
         F[2] = __builtin_bit_cast(bmu_bf16x8, fl[2 * plane + t_]);                                   \
-        F[3] = __builtin_bit_cast(bmu_bf16x8, fl[3 * plane + t_]);                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                           \
+            const float4 w_ = w2l[tt_ * 8 + q_];                                                     \
+            ACC[4 * q_] = w_.x; ACC[4 * q_ + 1] = w_.y; ACC[4 * q_ + 2] = w_.z; ACC[4 * q_ + 3] = w_.w; \
+        }                                                                                            \
     }
 #define BMU_MFMA(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC, 0, 0, 0)
-    // one candidate: 4 vector-ALU instructions (v_med3, v_cmp, 2 x v_cndmask)
+    // one candidate: 3 vector-ALU instructions (v_and_or_b32, 2 x v_med3_f32)
 #define BMU_SCAN(ACC, r)                                                                            \
     {                                                                                               \
-        const float t_ = ACC[r];                                                                    \
+        const float t_ = __uint_as_float((__float_as_uint(ACC[r]) & 0xfffffff0u) | (unsigned)(r));   \
         sec = __builtin_amdgcn_fmed3f(best, t_, sec);                                               \
-        const bool lt_ = t_ < best;                                                                 \
-        ridx = lt_ ? (r) : ridx;                                                                    \
-        best = lt_ ? t_ : best;                                                                     \
+        best = __builtin_amdgcn_fmed3f(best, t_, ninf);                                             \
     }
-    // NXT = chain of tile TC + 1 from the fragments FC (read a step ago), interleaved with the scan of
-    // CUR (tile TC); FN receives the fragments of tile TC + 2 (clamped past the end: harmless repeats)
-#define BMU_STEP(CUR, NXT, TC, FC, FN)                                                              \
+    // scans CUR (tile TC), chains NXT (tile TC + 1, fragments FC), loads tile TC + 2 into (FN, NN) (clamped
+    // past the end: harmless repeats)
+#define BMU_STEP(CUR, NXT, NN, TC, FC, FN)                                                          \
     {                                                                                               \
-        BMU_FRAGS(FN, (TC) + 2)                                                                      \
+        BMU_FRAGS(FN, NN, (TC) + 2)                                                                  \
         const float before_ = best;                                                                 \
-        NXT = zero16;                                                                                \
-        BMU_MFMA(NXT, FC[3], bON); BMU_SCAN(CUR, 0) BMU_SCAN(CUR, 1)                                 \
-        BMU_MFMA(NXT, FC[2], bXH); BMU_SCAN(CUR, 2) BMU_SCAN(CUR, 3)                                 \
-        BMU_MFMA(NXT, FC[0], bXL); BMU_SCAN(CUR, 4) BMU_SCAN(CUR, 5)                                 \
-        BMU_MFMA(NXT, FC[1], bXM); BMU_SCAN(CUR, 6) BMU_SCAN(CUR, 7)                                 \
-        BMU_MFMA(NXT, FC[1], bXH); BMU_SCAN(CUR, 8) BMU_SCAN(CUR, 9)                                 \
-        BMU_MFMA(NXT, FC[0], bXM); BMU_SCAN(CUR, 10) BMU_SCAN(CUR, 11) BMU_SCAN(CUR, 12)             \
-        BMU_MFMA(NXT, FC[0], bXH); BMU_SCAN(CUR, 13) BMU_SCAN(CUR, 14) BMU_SCAN(CUR, 15)             \
+        BMU_MFMA(NXT, FC[2], bXH); BMU_SCAN(CUR, 0) BMU_SCAN(CUR, 1) BMU_SCAN(CUR, 2)                \
+        BMU_MFMA(NXT, FC[0], bXL); BMU_SCAN(CUR, 3) BMU_SCAN(CUR, 4) BMU_SCAN(CUR, 5)                \
+        BMU_MFMA(NXT, FC[1], bXM); BMU_SCAN(CUR, 6) BMU_SCAN(CUR, 7) BMU_SCAN(CUR, 8)                \
+        BMU_MFMA(NXT, FC[1], bXH); BMU_SCAN(CUR, 9) BMU_SCAN(CUR, 10) BMU_SCAN(CUR, 11)              \
+        BMU_MFMA(NXT, FC[0], bXM); BMU_SCAN(CUR, 12) BMU_SCAN(CUR, 13)                               \
+        BMU_MFMA(NXT, FC[0], bXH); BMU_SCAN(CUR, 14) BMU_SCAN(CUR, 15)                               \
         tidx = best < before_ ? (TC) : tidx;                                                         \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                           \
-        _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) {                                           \
+        __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                           \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);                                       \
         }                                                                                            \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                           \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
-            __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);                                      \
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);                                       \
         }                                                                                            \
     }
-    f32x16 accA = zero16, accB;
-    bmu_bf16x8 fA[4], fB[4];
-    BMU_FRAGS(fA, 0)
-    BMU_FRAGS(fB, 1)
-    BMU_MFMA(accA, fA[3], bON); BMU_MFMA(accA, fA[2], bXH); BMU_MFMA(accA, fA[0], bXL); BMU_MFMA(accA, fA[1], bXM);
+    f32x16 accA, accB, accC;
+    bmu_bf16x8 fA[3], fB[3], fC[3];
+    BMU_FRAGS(fA, accA, 0)
+    BMU_FRAGS(fB, accB, 1)
+    BMU_MFMA(accA, fA[2], bXH); BMU_MFMA(accA, fA[0], bXL); BMU_MFMA(accA, fA[1], bXM);
     BMU_MFMA(accA, fA[1], bXH); BMU_MFMA(accA, fA[0], bXM); BMU_MFMA(accA, fA[0], bXH);
     int T = 0;
-    for (; T + 2 <= NT; T += 2) {
-        BMU_STEP(accA, accB, T, fB, fA)          // scans tile T, chains tile T+1 (fB), reads tile T+2 into fA
-        BMU_STEP(accB, accA, T + 1, fA, fB)      // scans tile T+1, chains tile T+2 (fA), reads tile T+3 into fB
+    for (; T + 3 <= NT; T += 3) {
+        BMU_STEP(accA, accB, accC, T, fB, fC)            // scans tile T, chains T+1 (fB), loads T+2 into (fC, accC)
+        BMU_STEP(accB, accC, accA, T + 1, fC, fA)
+        BMU_STEP(accC, accA, accB, T + 2, fA, fB)
     }
-    if (T < NT) BMU_STEP(accA, accB, T, fB, fA)
+    if (T < NT) {
+        BMU_STEP(accA, accB, accC, T, fB, fC)
+        if (T + 1 < NT) BMU_STEP(accB, accC, accA, T + 1, fC, fA)
+    }
 #undef BMU_STEP
 #undef BMU_SCAN
 #undef BMU_MFMA
 #undef BMU_FRAGS
+    const int ridx = (int)(__float_as_uint(best) & 15u);
     const long long tc2 = stats ? clock64() : 0;
     // ---- merge the two lane halves of a row, certify
     const int idx = tidx < 0 ? INT_MAX : tidx * 32 + 4 * h + (ridx & 3) + 8 * (ridx >> 2);
@@ -1467,7 +1478,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_coarse_kernel(PatchGeom g, Pa
             float acc = 0.0f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc = e < D ? fmaf(m2[e], xs[e], acc) : acc;
-            const float d = sqrtf(fmaxf((acc + W2[k]) + x2, 0.0f));
+            const float d = sqrtf(fmaxf((acc + W2[bmu_w2_at(k)]) + x2, 0.0f));
             if (d < bd) { bd = d; bi = k; }
         }
 #pragma unroll
@@ -1529,7 +1540,7 @@ static void bmu_patch_offsets(const PatchGeom& g, PatchOffsets& po) {
     magic(g.gw, po.m_gw, po.sh_gw);
 }
 
-static size_t bmu_coarse_lds(int K) { return (size_t)K * 128 + (size_t)K * 4 + 128 * 16 * 4 + 16 * 4; }
+static size_t bmu_coarse_lds(int K) { return (size_t)K * 96 + (size_t)K * 4 + 128 * 16 * 4 + 16 * 4; }
 static void bmu_coarse_attr(size_t shm) {
     static size_t attr_shm = 0;
     if (shm > attr_shm) {
@@ -1555,7 +1566,7 @@ static int bmu_coarse_launch(const PatchGeom& g, const float* codebook, int K, i
 // that writes it.  0 bytes = the coarse form does not take this codebook.
 extern "C" size_t qarig_bmu_prepare_bytes(int K, int D) {
     if (D < 1 || D > 16 || D % 4 || K < 32 || K > 1024 || K % 32) return 0;
-    return (size_t)K * 132 + 16;
+    return (size_t)K * 100 + 16;
 }
 extern "C" int qarig_bmu_prepare(const float* codebook, int K, int D, void* image, void* stream) {
     QARIG_CHECK_ARG(codebook && image, "bmu_prepare: null pointer");
