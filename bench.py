@@ -231,12 +231,14 @@ def cpu_baseline(cfg, budget_s=float(os.environ.get("QARIG_CPU_BASELINE_SECONDS"
 
 def bmu_side_measure(device, K=512):
     """BMU argmin GB/s on a C4-sized launch (65,536 patch rows, K=512, D=16), timed
-    with HIP events on the launch stream; algorithmic bytes = 4*D + 8 per row."""
+    with HIP events on the launch stream; algorithmic bytes = 4*D + 8 per row.  The codebook is a frozen
+    nn.Parameter, as models/Codebook.py hands it over in the Transformer training loop (from its second search on
+    the launch takes the codebook's prepared image)."""
     import torch
     from qarig import ops
     g = torch.Generator().manual_seed(9)
     x = torch.tanh(torch.randn((64, 4, 64, 64), generator=g)).to(device)
-    w = torch.tanh(torch.randn((K, 16), generator=g)).to(device)
+    w = torch.nn.Parameter(torch.tanh(torch.randn((K, 16), generator=g)).to(device), requires_grad=False)
     for _ in range(2):
         ops.bmu(x, w, (2, 2))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

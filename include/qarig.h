@@ -58,8 +58,16 @@ int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH, int pW,
                   const float* codebook, int K, int D, int64_t* out_idx, void* workspace,
                   size_t ws_bytes, void* stream);
 
+/* qarig_bmu_fwd with the codebook's prepared image (qarig_bmu_prepare below; NULL = none): where the
+ * dispatch takes the coarse-pass kernel, its workgroups copy the image into LDS (global -> LDS DMA) instead
+ * of each converting the codebook.  For a codebook that does not change between calls (tokenising a
+ * dataset, the Transformer training loop); same indices. */
+int qarig_bmu_fwd_prepared(const float* x, int N, int C, int H, int W, int pH, int pW,
+                           const float* codebook, int K, int D, int64_t* out_idx, void* workspace,
+                           size_t ws_bytes, const void* prepared, void* stream);
+
 /* The same search through a coarse pass on the bf16 MFMA (every operand split into three bf16
- * pieces that add up to it exactly, six products + |w|^2 per 32 x 32 tile), a per-row certificate
+ * pieces that add up to it exactly, six products on top of |w|^2 per 32 x 32 tile), a per-row certificate
  * (second-smallest - smallest > 3 eps, eps a proven bound of the coarse error) and the literal
  * fp32 re-scan of every row without one: bit-identical indices to qarig_bmu_fwd's exact kernels.
  * qarig_bmu_fwd takes this form by itself where it applies (D <= 16, D % 4 == 0, K % 32 == 0,

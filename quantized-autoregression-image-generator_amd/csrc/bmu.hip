@@ -1151,6 +1151,10 @@ using namespace qarig;
 //     to the fp32 codebook in memory instead), the row's fp32 values from an LDS copy -- so the
 //     result is bit-identical to oracle/bmu_oracle.c on every input, as before.
 typedef __bf16 bmu_bf16x8 __attribute__((ext_vector_type(8)));
+// v128 .. v224: the registers the scan loop's asm statement names (tools/gen_bmu_scan.py)
+#define BMU_V8(a) "v" #a "0", "v" #a "1", "v" #a "2", "v" #a "3", "v" #a "4", "v" #a "5", "v" #a "6", "v" #a "7", "v" #a "8", "v" #a "9"
+#define BMU_SCAN_CLOBBERS "v128", "v129", BMU_V8(13), BMU_V8(14), BMU_V8(15), BMU_V8(16), BMU_V8(17), BMU_V8(18), \
+    BMU_V8(19), BMU_V8(20), BMU_V8(21), "v220", "v221", "v222", "v223", "v224"
 typedef unsigned int bmu_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t bmu_pack_bf16(float a, float b) {   // a in the low half
@@ -1264,7 +1268,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_coarse_kernel(PatchGeom g, Pa
         const float* hdr = reinterpret_cast<const float*>(image_in + image_bytes);
         w2max = hdr[0];
         inexact = hdr[1] != 0.0f;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the barrier below publishes the image)
     } else
     for (int k0 = tid; k0 < K; k0 += 2 * NTHREADS) {
         float4 raw[2][4];
@@ -1323,6 +1326,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_coarse_kernel(PatchGeom g, Pa
         for (int q = 0; q < 8; ++q) XS[(wave * 32 + cl) * 16 + 8 * h + q] = xv[q];
         x2a += __shfl_xor(x2a, 32);
     }
+    // the image's DMA has run under the split of the patch rows: landed before the barrier publishes it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // block-wide max |w|^2 and the inexact flag
     w2max = wave_max(w2max);
     inexact = __any(inexact);
@@ -1343,87 +1348,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void bmu_coarse_kernel(PatchGeom g, Pa
     }
 
     const long long tc1 = stats ? clock64() : 0;
-    // ---- the coarse scan, software-pipelined: the six MFMAs of tile T+1 (a dependent chain of
-    // 32-cycle instructions on the matrix pipe) are issued between the scan steps of tile T (8
-    // vector-ALU instructions = 32 cycles per MFMA), so neither pipe waits for the other.
-    // scan state: (min, second-smallest) of t~, the minimum carrying its register number in its low four bits,
-    // and the tile in which the minimum last fell
+    // ---- the coarse scan, software-pipelined over three accumulator sets in rotation: while tile T is scanned,
+    // the six MFMAs of tile T+1 (a dependent chain of 32-cycle instructions on the matrix pipe, started from the
+    // tile's |w|^2) are issued with seven scan instructions behind each, and the fragments and |w|^2 of tile T+2
+    // come in from LDS -- no LDS read is waited for in the step that issued it, no register copies, no idle wait
+    // states behind a chain.  The loop is one inline-asm statement (tools/gen_bmu_scan.py writes it and documents
+    // its registers): hipcc's scheduler did not keep this shape under any sched_group_barrier pipeline.
+    // scan state: (min, second-smallest) of t~, the minimum carrying its register number in its low four bits
+    // (3 vector instructions per candidate: v_and_or_b32, 2 x v_med3_f32), and the tile in which the minimum fell
     float best = INFINITY, sec = INFINITY;
     int tidx = -1;
-    float ninf = -INFINITY;
-    asm volatile("" : "+v"(ninf));          // opaque: median(min, t, -inf) must stay ONE v_med3_f32 (as a constant the
-                                            // compiler turns it into v_max (canonicalise) + v_min)
-    const bmu_bf16x8 bXH = __builtin_bit_cast(bmu_bf16x8, XH), bXM = __builtin_bit_cast(bmu_bf16x8, XM),
-                     bXL = __builtin_bit_cast(bmu_bf16x8, XL);
-    const bmu_u32x4* fl = frag + h * 32 + cl;
-    const float4* w2l = reinterpret_cast<const float4*>(W2) + h * 4;
-    // fragments of a tile: [0] hi, [1] mid, [2] lo; its |w|^2 (accumulator order) goes straight into the
-    // accumulator that will chain it.  Three sets in rotation: while tile T is scanned (CUR) and tile T + 1 chained
-    // (NXT, from fragments read a step ago), the fragments and |w|^2 of tile T + 2 land in the third set (NN, whose
-    // last scan ended a step ago) -- no LDS read is waited for in the step that issued it, no register copies
-#define BMU_FRAGS(F, ACC, T_)                                                                       \
-    {                                                                                               \
-        const int tt_ = min(T_, NT - 1);                                                             \
-        const int t_ = tt_ * 64;                                                                     \
-        F[0] = __builtin_bit_cast(bmu_bf16x8, fl[t_]);                                               \
-        F[1] = __builtin_bit_cast(bmu_bf16x8, fl[plane + t_]);                                       \
-        F[2] = __builtin_bit_cast(bmu_bf16x8, fl[2 * plane + t_]);                                   \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                           \
-            const float4 w_ = w2l[tt_ * 8 + q_];                                                     \
-            ACC[4 * q_] = w_.x; ACC[4 * q_ + 1] = w_.y; ACC[4 * q_ + 2] = w_.z; ACC[4 * q_ + 3] = w_.w; \
-        }                                                                                            \
+    if constexpr (!PREP) {
+        const bmu_bf16x8 bXH = __builtin_bit_cast(bmu_bf16x8, XH), bXM = __builtin_bit_cast(bmu_bf16x8, XM),
+                         bXL = __builtin_bit_cast(bmu_bf16x8, XL);
+        const unsigned f0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)(frag + h * 32 + cl);
+        const unsigned wa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)(W2 + h * 16);
+        const int plane_bytes = __builtin_amdgcn_readfirstlane(plane * 16), nt = __builtin_amdgcn_readfirstlane(NT);
+        int st_, su_;
+        asm volatile(
+#include "bmu_scan_asm.inc"
+            : [best] "=&v"(best), [sec] "=&v"(sec), [tidx] "=&v"(tidx), [t] "=&s"(st_), [u] "=&s"(su_)
+            : [xh] "v"(bXH), [xm] "v"(bXM), [xl] "v"(bXL), [f0] "v"(f0), [pl] "s"(plane_bytes), [w] "v"(wa), [nt] "s"(nt)
+            : "vcc", "scc", "memory", BMU_SCAN_CLOBBERS);
     }
-#define BMU_MFMA(ACC, A_, B_) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, ACC, 0, 0, 0)
-    // one candidate: 3 vector-ALU instructions (v_and_or_b32, 2 x v_med3_f32)
-#define BMU_SCAN(ACC, r)                                                                            \
-    {                                                                                               \
-        const float t_ = __uint_as_float((__float_as_uint(ACC[r]) & 0xfffffff0u) | (unsigned)(r));   \
-        sec = __builtin_amdgcn_fmed3f(best, t_, sec);                                               \
-        best = __builtin_amdgcn_fmed3f(best, t_, ninf);                                             \
-    }
-    // scans CUR (tile TC), chains NXT (tile TC + 1, fragments FC), loads tile TC + 2 into (FN, NN) (clamped
-    // past the end: harmless repeats)
-#define BMU_STEP(CUR, NXT, NN, TC, FC, FN)                                                          \
-    {                                                                                               \
-        BMU_FRAGS(FN, NN, (TC) + 2)                                                                  \
-        const float before_ = best;                                                                 \
-        BMU_MFMA(NXT, FC[2], bXH); BMU_SCAN(CUR, 0) BMU_SCAN(CUR, 1) BMU_SCAN(CUR, 2)                \
-        BMU_MFMA(NXT, FC[0], bXL); BMU_SCAN(CUR, 3) BMU_SCAN(CUR, 4) BMU_SCAN(CUR, 5)                \
-        BMU_MFMA(NXT, FC[1], bXM); BMU_SCAN(CUR, 6) BMU_SCAN(CUR, 7) BMU_SCAN(CUR, 8)                \
-        BMU_MFMA(NXT, FC[1], bXH); BMU_SCAN(CUR, 9) BMU_SCAN(CUR, 10) BMU_SCAN(CUR, 11)              \
-        BMU_MFMA(NXT, FC[0], bXM); BMU_SCAN(CUR, 12) BMU_SCAN(CUR, 13)                               \
-        BMU_MFMA(NXT, FC[0], bXH); BMU_SCAN(CUR, 14) BMU_SCAN(CUR, 15)                               \
-        tidx = best < before_ ? (TC) : tidx;                                                         \
-        __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);                                           \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                           \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
-            __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);                                       \
-        }                                                                                            \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                           \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
-            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);                                       \
-        }                                                                                            \
-    }
-    f32x16 accA, accB, accC;
-    bmu_bf16x8 fA[3], fB[3], fC[3];
-    BMU_FRAGS(fA, accA, 0)
-    BMU_FRAGS(fB, accB, 1)
-    BMU_MFMA(accA, fA[2], bXH); BMU_MFMA(accA, fA[0], bXL); BMU_MFMA(accA, fA[1], bXM);
-    BMU_MFMA(accA, fA[1], bXH); BMU_MFMA(accA, fA[0], bXM); BMU_MFMA(accA, fA[0], bXH);
-    int T = 0;
-    for (; T + 3 <= NT; T += 3) {
-        BMU_STEP(accA, accB, accC, T, fB, fC)            // scans tile T, chains T+1 (fB), loads T+2 into (fC, accC)
-        BMU_STEP(accB, accC, accA, T + 1, fC, fA)
-        BMU_STEP(accC, accA, accB, T + 2, fA, fB)
-    }
-    if (T < NT) {
-        BMU_STEP(accA, accB, accC, T, fB, fC)
-        if (T + 1 < NT) BMU_STEP(accB, accC, accA, T + 1, fC, fA)
-    }
-#undef BMU_STEP
-#undef BMU_SCAN
-#undef BMU_MFMA
-#undef BMU_FRAGS
     const int ridx = (int)(__float_as_uint(best) & 15u);
     const long long tc2 = stats ? clock64() : 0;
     // ---- merge the two lane halves of a row, certify
@@ -1604,10 +1551,22 @@ extern "C" int qarig_bmu_fwd_coarse(const float* x, int N, int C, int H, int W, 
     return bmu_coarse_launch(g, codebook, K, out_idx, uncertified, prepared, (hipStream_t)stream);
 }
 
+extern "C" int qarig_bmu_fwd_prepared(const float* x, int N, int C, int H, int W, int pH, int pW,
+                                      const float* codebook, int K, int D, int64_t* out_idx,
+                                      void* workspace, size_t ws_bytes, const void* prepared, void* stream);
 extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH, int pW,
                              const float* codebook, int K, int D, int64_t* out_idx,
                              void* workspace, size_t ws_bytes, void* stream) {
+    return qarig_bmu_fwd_prepared(x, N, C, H, W, pH, pW, codebook, K, D, out_idx, workspace, ws_bytes, nullptr, stream);
+}
+
+// qarig_bmu_fwd with the codebook's prepared image (qarig_bmu_prepare; NULL = none): where the dispatch takes the
+// coarse-pass kernel its workgroups copy the image into LDS instead of converting the codebook themselves.
+extern "C" int qarig_bmu_fwd_prepared(const float* x, int N, int C, int H, int W, int pH, int pW,
+                                      const float* codebook, int K, int D, int64_t* out_idx,
+                                      void* workspace, size_t ws_bytes, const void* prepared, void* stream) {
     QARIG_CHECK_ARG(x && codebook && out_idx, "bmu: null pointer");
+    QARIG_CHECK_ARG(!prepared || (((uintptr_t)prepared) & 15) == 0, "bmu: prepared image must be 16-B aligned");
     QARIG_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && pH > 0 && pW > 0 && K > 0,
                     "bmu: bad extents");
     QARIG_CHECK_ARG(pH <= H && pW <= W, "bmu: patch larger than the latent");
@@ -1668,7 +1627,7 @@ extern "C" int qarig_bmu_fwd(const float* x, int N, int C, int H, int W, int pH,
     // qarig_bmu_fwd_coarse instead: qarig.ops.bmu)
     const int coarse_env = g_qarig_opt.bmu_coarse;
     if (bmu_coarse_ok(g, K, codebook) && coarse_env != 0 && (coarse_env == 1 || g.R >= 24576))
-        return bmu_coarse_launch(g, codebook, K, out_idx, nullptr, nullptr, st);
+        return bmu_coarse_launch(g, codebook, K, out_idx, nullptr, prepared, st);
     if (D <= 16) {
         const int ks = D <= 4 ? 2 : (D <= 8 ? 4 : 8);
         const int bpc = (2 * ks + 1) * 4;                         // LDS bytes per code

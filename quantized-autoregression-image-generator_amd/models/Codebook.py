@@ -102,7 +102,9 @@ class Codebook(nn.Module):
 
     # reference Codebook.py:77-99
     def get_patches_bmu(self, x, reshape=False):
-        idx = ops.bmu(x, self.codebook.weight.detach(), self.patch_dim)
+        # (the Parameter itself, not a detached alias: ops.bmu follows its version counter and its optimiser's step
+        #  count to know when a prepared image of the codebook is still the codebook)
+        idx = ops.bmu(x, self.codebook.weight, self.patch_dim)
         if reshape:
             idx = idx.reshape(x.shape[0], -1)
         return idx

@@ -28,6 +28,7 @@ SIGNATURES = {
     "qarig_set_option": (I, [c_char_p, I]),
     "qarig_bmu_workspace_bytes": (Z, [L, I]),
     "qarig_bmu_fwd": (I, [P, I, I, I, I, I, I, P, I, I, P, P, Z, P]),
+    "qarig_bmu_fwd_prepared": (I, [P, I, I, I, I, I, I, P, I, I, P, P, Z, P, P]),
     "qarig_bmu_fwd_coarse": (I, [P, I, I, I, I, I, I, P, I, I, P, P, P, P]),
     "qarig_bmu_prepare_bytes": (Z, [I, I]),
     "qarig_bmu_prepare": (I, [P, I, I, P, P]),

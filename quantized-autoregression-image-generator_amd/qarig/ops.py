@@ -21,25 +21,48 @@ def act_id(name):
 
 # --------------------------------------------------------------------------- BMU
 _bmu_images = {}
+_bmu_seen = {}               # id(codebook) -> state key of the last search (bmu_image only_if_stable)
+BMU_IMAGE_MIN_ROWS = 24576   # the dispatch takes the coarse-pass kernel (the image's consumer) from here up
 
 
-def bmu_image(codebook):
+def bmu_invalidate():
+    """Forget every prepared codebook image (after a write into parameters that neither torch's version counter
+    nor FlatAdam's step count sees, e.g. parallel.broadcast_params)."""
+    _bmu_images.clear()
+    _bmu_seen.clear()
+
+
+def _bmu_key(codebook):
+    owner = getattr(codebook, "_qarig_owner", None)
+    K, D = codebook.shape
+    return (codebook.data_ptr(), K, D, codebook._version, owner.step_count if owner is not None else -1)
+
+
+def bmu_image(codebook, only_if_stable=False):
     """Prepared image of a codebook for the coarse-pass search (include/qarig.h qarig_bmu_prepare), or
     None where that form does not apply.  Cached per codebook tensor until it changes: torch's version
     counter, and -- for a parameter FlatAdam owns, whose updates bypass that counter -- the optimiser's
-    step count."""
+    step count.  only_if_stable: build the image only for a codebook that an earlier call already saw in
+    this state (a codebook under training changes between searches: preparing it every time would cost a
+    launch for nothing)."""
     K, D = codebook.shape
     lib = _lib.load()
     nb = lib.qarig_bmu_prepare_bytes(K, D)
     if nb == 0 or codebook.data_ptr() % 16:
         return None
-    owner = getattr(codebook, "_qarig_owner", None)
-    key = (codebook.data_ptr(), K, D, codebook._version, owner.step_count if owner is not None else -1)
+    key = _bmu_key(codebook)
     hit = _bmu_images.get(id(codebook))
     if hit is not None and hit[0] == key and hit[1]() is codebook:
         return hit[2]
     if torch.cuda.is_current_stream_capturing():
         return None                       # no allocation / caching inside a capture: the kernel stages by itself
+    if only_if_stable:
+        seen = _bmu_seen.get(id(codebook))
+        _bmu_seen[id(codebook)] = key
+        if len(_bmu_seen) > 256:
+            _bmu_seen.clear()
+        if seen != key:
+            return None
     import weakref
     img = torch.empty(nb, dtype=torch.uint8, device=codebook.device)
     check(lib.qarig_bmu_prepare(ptr(codebook), K, D, ptr(img), stream()), "qarig_bmu_prepare")
@@ -63,13 +86,21 @@ def bmu(x, codebook, patch_dim):
     rows = N * (H // pH) * (W // pW)
     out = torch.empty(rows, dtype=torch.int64, device=x.device)
     lib = _lib.load()
-    # (large launches take the coarse-pass kernel inside qarig_bmu_fwd; a prepared codebook image --
-    # bmu_image / bmu_coarse(prepared=True) -- measured the same launch time as staging the codebook in
-    # every workgroup: that phase is bound by the latency of the patch gather, not by the conversion)
+    # Large launches take the coarse-pass kernel inside qarig_bmu_fwd.  A codebook that an earlier search saw in
+    # its present state (frozen: tokenising a dataset, the Transformer training loop) goes in as its prepared
+    # image, which the workgroups DMA into LDS instead of each converting the codebook (65,536 x 512 x 16:
+    # 14.3 -> 13.x us).  Never inside a graph capture: a replay would search the image of the codebook as it was
+    # when the graph was captured.
+    # Only for an nn.Parameter: its identity is stable, torch's version counter sees every in-place update
+    # through torch, FlatAdam's step count (p._qarig_owner) those made through the flat buffer.
+    img = None
+    if rows >= BMU_IMAGE_MIN_ROWS and cb is codebook and isinstance(codebook, torch.nn.Parameter) and \
+            not torch.cuda.is_current_stream_capturing():
+        img = bmu_image(cb, only_if_stable=True)
     nb = lib.qarig_bmu_workspace_bytes(rows, K)
     ws = workspace(nb, x.device)
-    check(lib.qarig_bmu_fwd(ptr(x), N, C, H, W, pH, pW, ptr(cb), K, D, ptr(out), ptr(ws),
-                            ws.numel(), stream()), "qarig_bmu_fwd")
+    check(lib.qarig_bmu_fwd_prepared(ptr(x), N, C, H, W, pH, pW, ptr(cb), K, D, ptr(out), ptr(ws),
+                                     ws.numel(), ptr(img), stream()), "qarig_bmu_fwd_prepared")
     return out
 
 

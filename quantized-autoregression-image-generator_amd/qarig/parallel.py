@@ -81,6 +81,7 @@ def broadcast_params(optim, src=0):
         dist.broadcast(flat, src=src)
     from . import ops
     ops.lp_invalidate()
+    ops.bmu_invalidate()
     if hasattr(optim, "_shadow_versions"):
         optim._shadow_versions = None
 

@@ -433,6 +433,47 @@ def test_bmu_coarse_pass_bit_exact(N, C, H, W, p, K, kind):
     assert np.array_equal(ops.bmu(x.cuda(), w.cuda(), (p, p)).cpu().numpy(), want)
 
 
+def test_bmu_takes_the_prepared_image_of_a_stable_parameter_and_follows_its_updates():
+    """ops.bmu on an nn.Parameter codebook (what models/Codebook.py passes): the second search of an unchanged
+    codebook builds its prepared image, later ones DMA it; an in-place update through torch (version counter) or
+    through an optimiser that owns the flat buffer (step count) drops it.  Indices equal the oracle's throughout."""
+    from qarig import ops
+    from oracle import bmu as obmu
+    g = torch.Generator().manual_seed(77)
+    x = torch.tanh(torch.randn((32, 4, 64, 64), generator=g))           # 32,768 rows: the coarse-pass kernel
+    w = torch.nn.Parameter(torch.tanh(torch.randn((512, 16), generator=g)).cuda(), requires_grad=False)
+    xc = x.cuda()
+    ops.bmu_invalidate()
+    want = obmu.bmu(x.numpy(), w.detach().cpu().numpy(), (2, 2))
+    for call in range(3):
+        assert np.array_equal(ops.bmu(xc, w, (2, 2)).cpu().numpy(), want), call
+        assert (id(w) in ops._bmu_images) == (call >= 1)                 # built by the second search
+    img = ops._bmu_images[id(w)][2]
+    with torch.no_grad():
+        w.mul_(-0.5)                                                     # through torch: the version counter moves
+    want2 = obmu.bmu(x.numpy(), w.detach().cpu().numpy(), (2, 2))
+    assert not np.array_equal(want, want2)
+    assert np.array_equal(ops.bmu(xc, w, (2, 2)).cpu().numpy(), want2)   # (unprepared: first search of this state)
+    assert np.array_equal(ops.bmu(xc, w, (2, 2)).cpu().numpy(), want2)
+    assert ops._bmu_images[id(w)][2] is not img
+
+    class Owner:                                                         # FlatAdam's contract: p._qarig_owner.step_count
+        step_count = 3
+    w._qarig_owner = Owner()
+    for _ in range(2):
+        assert np.array_equal(ops.bmu(xc, w, (2, 2)).cpu().numpy(), want2)
+    w.data.mul_(-1.0)                                                    # behind the version counter's back ...
+    w._qarig_owner.step_count = 4                                        # ... as the optimiser's step does
+    want3 = obmu.bmu(x.numpy(), w.detach().cpu().numpy(), (2, 2))
+    assert np.array_equal(ops.bmu(xc, w, (2, 2)).cpu().numpy(), want3)
+    assert np.array_equal(ops.bmu(xc, w, (2, 2)).cpu().numpy(), want3)
+    # a plain tensor (a detached alias, unknown provenance) never gets an image
+    t = w.detach()
+    for _ in range(3):
+        assert np.array_equal(ops.bmu(xc, t, (2, 2)).cpu().numpy(), want3)
+    assert id(t) not in ops._bmu_images
+
+
 def test_bmu_coarse_pass_on_constructed_near_ties():
     """Adversarial input for the coarse pass's certificate: the codebook is made of PAIRS w, w + s e_j with s
     swept over 1e-6 ... 3e-3, so every patch's best code has a twin whose squared distance differs by anything

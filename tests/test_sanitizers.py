@@ -88,6 +88,7 @@ for (G, M, N, K, ak, bk, sk, sumg, rs) in ((3, 2048, 2048, 512, 1, 1, 1, 0, 0), 
          X, 1 << 40, None)
 for (N, C, H, W, p, K) in ((64, 4, 32, 32, 2, 512), (64, 4, 32, 32, 32, 512), (64, 4, 64, 64, 1, 8192), (3, 4, 12, 20, 2, 77)):
     call("qarig_bmu_fwd", X, N, C, H, W, p, p, X, K, C * p * p, X, X, 1 << 40, None)
+    call("qarig_bmu_fwd_prepared", X, N, C, H, W, p, p, X, K, C * p * p, X, X, 1 << 40, X, None)
 for (N, Sq, Sk, H, d, causal) in ((64, 256, 256, 64, 8, 1), (2, 4096, 4096, 64, 8, 1), (2, 4096, 1024, 64, 8, 0),
                                   (3, 12, 5, 2, 16, 0), (1, 130, 130, 2, 64, 0)):
     call("qarig_attention_fwd", X, X, X, N, Sq, Sk, H, d, causal, float(d) ** 0.5, X, X, None)

@@ -35,6 +35,8 @@ def main():
     for name, shape, patch, K in SHAPES:
         x = torch.tanh(torch.randn(shape, generator=g)).to(dev)
         w = torch.tanh(torch.randn((K, shape[1] * patch[0] * patch[1]), generator=g)).to(dev)
+        if os.environ.get("BMU_FROZEN", "1") != "0":     # a frozen nn.Parameter, as models/Codebook.py passes it:
+            w = torch.nn.Parameter(w, requires_grad=False)   # large launches take its prepared image (ops.bmu)
         for _ in range(3):
             ops.bmu(x, w, patch)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
