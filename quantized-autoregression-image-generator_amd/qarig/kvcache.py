@@ -76,15 +76,8 @@ class DecodeCache:
                               dtype=torch.float32, device=dev)
         self.pe = model._sequence_pe(max_len, self.dim, dev)
         self.ctl = torch.zeros(ops.DECODE_CTL_WORDS, dtype=torch.int32, device=dev)
-        self.cross = []
-        with torch.no_grad():
-            for layer in model.decoder_layers:
-                if layer.use_cross_attn:
-                    at = layer.cross_attn_block.cross_attn
-                    hm = lambda t: t.reshape(t.shape[0], t.shape[1], at.heads, -1).permute(0, 2, 1, 3).contiguous()
-                    self.cross.append((hm(_mlp2_forward(at.k_block, enc)), hm(_mlp2_forward(at.v_block, enc))))
-                else:
-                    self.cross.append(None)
+        self.cross = self._cross_kv(enc)
+        self._enc_shape = None if enc is None else tuple(enc.shape)
         self._stack_weights()
         self._table = None
         if positions is not None and model.use_pos_cond and self._proj_lin and self.dim % 4 == 0:
@@ -95,6 +88,35 @@ class DecodeCache:
             graph = os.environ.get("QARIG_DECODE_GRAPH", "1") != "0"
         if graph:
             self._capture()
+
+    @torch.no_grad()
+    def _cross_kv(self, enc):
+        """Per decoder layer: the encoder memory's (k, v) of its cross-attention, head-major, or None."""
+        out = []
+        for layer in self.model.decoder_layers:
+            if layer.use_cross_attn:
+                at = layer.cross_attn_block.cross_attn
+                hm = lambda t: t.reshape(t.shape[0], t.shape[1], at.heads, -1).permute(0, 2, 1, 3).contiguous()
+                out.append((hm(_mlp2_forward(at.k_block, enc)), hm(_mlp2_forward(at.v_block, enc))))
+            else:
+                out.append(None)
+        return out
+
+    @torch.no_grad()
+    def rebind(self, enc):
+        """The cache for another generation with the SAME model weights, batch and window: the encoder memory's
+        keys / values are recomputed into the tensors the captured graphs read, the sequence starts over.  What
+        stays: the per-position table of conditioning projections, the stacked weights, the captured step graph
+        and the search's buffers (sampling keeps such caches per model: `sampling.decode_cache`).  False when
+        the encoder memory's shape differs (the caller builds a new cache)."""
+        if (None if enc is None else tuple(enc.shape)) != self._enc_shape:
+            return False
+        for old, new in zip(self.cross, self._cross_kv(enc)):
+            if old is not None:
+                old[0].copy_(new[0])
+                old[1].copy_(new[1])
+        self.ctl.zero_()
+        return True
 
     def _capture(self):
         """Static input buffers, one eager warm-up (sizes the GEMM workspaces outside the
@@ -399,8 +421,30 @@ class DecodeCache:
         per_chunk = (NB if ordered else int(candidates)) * bw       # draw rows one chunk position consumes
         cols = N if ordered else B
         draws = max(1, int(max_chunks) * per_chunk)
-        s = SimpleNamespace(N=N, NB=NB, bw=bw, draws=draws, used=0, chunks=0, candidates=int(candidates),
-                            beams=NB if ordered else 0, per_set=NB * bw if ordered else bw)
+        # The buffers the captured step graph reads and writes, and the graph itself, are kept across searches of
+        # the same geometry (a cache that sampling.decode_cache handed out again): no capture, no eager warm-up.
+        s = self._search
+        fresh = s is None or (s.N, s.NB, s.bw, s.V) != (N, NB, bw, V)
+        if fresh:
+            s = SimpleNamespace(N=N, NB=NB, bw=bw, V=V)
+            s.ids = torch.zeros(B, dtype=torch.int64, device=dev)
+            s.comb = torch.ones(B, dtype=torch.float32, device=dev)
+            s.chunk = torch.zeros((B, bw), dtype=torch.int64, device=dev)
+            s.best_p = torch.zeros(N, dtype=torch.float32, device=dev)
+            s.best_chunk = torch.zeros((N, bw), dtype=torch.int64, device=dev)
+            s.take = torch.zeros(N, dtype=torch.int32, device=dev)
+            R = max(bw - 1, 1)
+            s.staged = torch.zeros((self.kv.shape[0], 2, N, self.heads, R, D // self.heads), dtype=torch.float32,
+                                   device=dev)
+            s.tokens = torch.zeros((N, self.max_len + bw), dtype=torch.int64, device=dev)
+            s.last = torch.zeros((B, V), dtype=torch.float32, device=dev)
+            s.logits = torch.zeros((B, V), dtype=torch.float32, device=dev)
+            s.g_step = None
+        else:
+            s.comb.fill_(1.0)
+            s.tokens.zero_()
+        s.draws, s.used, s.chunks, s.candidates = draws, 0, 0, int(candidates)
+        s.beams, s.per_set = (NB if ordered else 0), (NB * bw if ordered else bw)
         s.uniforms = torch.rand((draws, cols), device=dev, generator=generator)
         s.forced = None
         if forced is not None:
@@ -408,41 +452,31 @@ class DecodeCache:
             f = torch.as_tensor(forced, dtype=torch.int64, device=dev).reshape(-1, cols)[:draws]
             s.forced[:f.shape[0]] = f
         s.probs = torch.zeros((draws, cols, V), dtype=torch.float32, device=dev) if log_probs else None
-        s.ids = torch.zeros(B, dtype=torch.int64, device=dev)
-        s.comb = torch.ones(B, dtype=torch.float32, device=dev)
-        s.chunk = torch.zeros((B, bw), dtype=torch.int64, device=dev)
-        s.best_p = torch.zeros(N, dtype=torch.float32, device=dev)
-        s.best_chunk = torch.zeros((N, bw), dtype=torch.int64, device=dev)
-        s.take = torch.zeros(N, dtype=torch.int32, device=dev)
-        R = max(bw - 1, 1)
-        s.staged = torch.zeros((self.kv.shape[0], 2, N, self.heads, R, D // self.heads), dtype=torch.float32,
-                               device=dev)
-        s.tokens = torch.zeros((N, self.max_len + bw), dtype=torch.int64, device=dev)
-        s.last = torch.zeros((B, V), dtype=torch.float32, device=dev)
-        s.logits = torch.zeros((B, V), dtype=torch.float32, device=dev)
         first = first_ids.reshape(N).to(torch.int64)
         s.tokens[:, 0] = first
         s.ids.copy_(first.repeat_interleave(NB))
         self.ctl.zero_()
         s.gen, s.T, s.end, s.shift = bool(generate_mode), float(temperature), int(end_token), int(shift)
-        # A capture records launches without running them, and the first launch of a kernel in a process (code
-        # object load) or a workspace that has to grow cannot happen inside one: the first step of a given
-        # shape in this process runs eagerly once; later stages of that shape go straight to the capture and
-        # evaluate their first token by replaying it.
-        sig = (B, D, V, self.heads, len(self.model.decoder_layers), tuple(c is not None for c in self.cross),
-               self._table is not None, self._stacked, FUSE_NORMS,
-               tuple(k.shape[2] for c in self.cross if c is not None for k in c[:1]))
-        if sig not in _WARM_SHAPES:
-            self._forward(s.ids, None, 0, self.ctl, out=s.logits)
-            self.ctl.zero_()
-            _WARM_SHAPES.add(sig)
-        s.g_step = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(s.g_step):
-            self._forward(s.ids, None, 0, self.ctl, out=s.logits)
+        if s.g_step is None:
+            # A capture records launches without running them, and the first launch of a kernel in a process (code
+            # object load) or a workspace that has to grow cannot happen inside one: the first step of a given
+            # shape in this process runs eagerly once; later stages of that shape go straight to the capture and
+            # evaluate their first token by replaying it.
+            sig = (B, D, V, self.heads, len(self.model.decoder_layers), tuple(c is not None for c in self.cross),
+                   self._table is not None, self._stacked, FUSE_NORMS,
+                   tuple(k.shape[2] for c in self.cross if c is not None for k in c[:1]))
+            if sig not in _WARM_SHAPES:
+                self._forward(s.ids, None, 0, self.ctl, out=s.logits)
+                self.ctl.zero_()
+                _WARM_SHAPES.add(sig)
+            s.g_step = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(s.g_step):
+                self._forward(s.ids, None, 0, self.ctl, out=s.logits)
         s.g_step.replay()                      # the first token, window index 0
         s.last.copy_(s.logits)
         # chunk search starts behind the first token: window index 1
-        self.ctl.copy_(torch.tensor([1, 1] + [0] * (ops.DECODE_CTL_WORDS - 2), dtype=torch.int32))
+        self.ctl.zero_()
+        self.ctl[0:2].fill_(1)
         self._search = s
         return s
 

@@ -16,6 +16,7 @@ import os
 
 import torch
 
+from . import ops
 from .kvcache import DecodeCache
 
 
@@ -79,6 +80,45 @@ class _Timer:
             print("[qarig generate] " + ", ".join(self.marks), file=sys.stderr)
 
 
+# Decode caches kept per model between generations (a process that generates more than once with the same
+# weights: a server, a CLI run over several batches): what a cache holds beyond the sequence itself -- the
+# per-position table of the conditioning projections, the stacked weights, the captured step graph, the search's
+# buffers -- depends on the weights, the batch and the window only.  Keyed by the model object and the state of
+# every parameter (data pointer, torch's version counter, the owning FlatAdam's step count); a write into the
+# weights that none of those sees (p.data arithmetic) needs decode_cache_clear().
+_DECODE_CACHES = {}
+DECODE_CACHE_SLOTS = 8
+
+
+def decode_cache_clear():
+    _DECODE_CACHES.clear()
+
+
+def _weights_key(model):
+    key = []
+    for p in model.parameters():
+        owner = getattr(p, "_qarig_owner", None)
+        key.append((p.data_ptr(), p._version, owner.step_count if owner is not None else -1))
+    return tuple(key)
+
+
+def decode_cache(model, enc, batch, limit, positions):
+    """A DecodeCache(model, enc, batch, limit, positions=positions) -- a kept one re-bound to `enc` when the
+    model's weights have not changed since it was built, a new one otherwise."""
+    import weakref
+    slot = (id(model), batch, limit, None if positions is None else tuple(positions),
+            None if enc is None else tuple(enc.shape))
+    wkey = _weights_key(model)
+    hit = _DECODE_CACHES.get(slot)
+    if hit is not None and hit[0]() is model and hit[1] == wkey and hit[2].rebind(enc):
+        return hit[2]
+    cache = DecodeCache(model, enc, batch, limit, graph=False, positions=positions)
+    if len(_DECODE_CACHES) >= DECODE_CACHE_SLOTS:
+        _DECODE_CACHES.pop(next(iter(_DECODE_CACHES)))
+    _DECODE_CACHES[slot] = (weakref.ref(model), wkey, cache)
+    return cache
+
+
 def _generate_fused(model, hr_input, enc, total_seq, temperature, use_sliding_window,
                     sliding_window, end_token, shift, num_beam, beam_width, mode, progress,
                     stop_len, pos_off, batch_beams):
@@ -106,14 +146,16 @@ def _generate_fused(model, hr_input, enc, total_seq, temperature, use_sliding_wi
     positions = [0.0] + [float(L + pos_off) for L in range(1, limit)] if use_sliding_window else None
     enc_b = enc.repeat_interleave(B, dim=0) if (enc is not None and B > 1) else enc
     tm = _Timer()
-    cache = DecodeCache(model, enc_b, N * B, limit, graph=False, positions=positions)
+    cache = decode_cache(model, enc_b, N * B, limit, positions)
     if cache.dim % 4 or (model.use_pos_cond and cache._table is None):
         return None
     tm.mark("cache")
     dbg = FUSED_DEBUG or {}
+    after = cur + chunks * beam_width                      # tokens (first included) once the cached chunks are in
+    tail_chunks = max(0, -(-(stop_len - after) // beam_width))          # chunks _fused_tail draws for
     cache.begin_search(hr_input[:, 0], N, B, beam_width, temperature, end_token, shift, mode == "generate",
-                       chunks, 1 if B > 1 else num_beam, forced=dbg.get("forced"), log_probs=bool(dbg.get("log")),
-                       reference_order=ordered)
+                       chunks + tail_chunks, 1 if B > 1 else num_beam, forced=dbg.get("forced"),
+                       log_probs=bool(dbg.get("log")), reference_order=ordered)
     tm.mark("capture")
     for c in range(chunks):
         cache.run_chunk(last=c == chunks - 1)
@@ -122,13 +164,63 @@ def _generate_fused(model, hr_input, enc, total_seq, temperature, use_sliding_wi
     hr_input = cache.finish_search()
     tm.mark(f"{chunks} chunks")
     tm.report()
-    if FUSED_DEBUG is not None:
-        FUSED_DEBUG["probs"] = cache._search.probs
-        FUSED_DEBUG["draws"] = cache._search.used
     if use_sliding_window:
         new = torch.tensor([float(L + pos_off) for L in range(cur, hr_input.shape[1])], device=device)
         pos = torch.cat((pos, new[None].expand(N, -1)), dim=1)
     return hr_input, pos, cache
+
+
+def _fused_tail(model, cache, hr_input, pos, enc, use_sliding_window, sliding_window, beam_width, progress,
+                total_seq, stop_len, pos_off, pos_bound):
+    """The chunks behind the cached ones (the window slides inside them: every evaluation from there on is the
+    reference's full-window evaluation, generate_images.py:275-286) on the state of the fused search: the candidates
+    stay rows of one batch, every draw is made by the sampling kernel from the search's uniforms under the
+    reference's draw numbers, the kept chunk is chosen by the decide kernel.  Evaluations that still fit the
+    window (the chunk in which it starts to slide: all but its last) are replays of the cache's step graph.
+    Enqueues only; nothing is read back."""
+    s = cache._search
+    N, NB, bw, ctl = s.N, s.NB, s.bw, cache.ctl
+    B = N * NB
+    device = hr_input.device
+    enc_eval = enc.repeat_interleave(NB, dim=0) if (enc is not None and NB > 1) else enc
+    whole = hasattr(model, "_cond")        # a Transformer: whole-number positions as int64 (one conditioning row each)
+    start = 0
+    while hr_input.shape[1] < stop_len:
+        cur = hr_input.shape[1]
+        for _ in range(s.candidates):
+            t_in = hr_input.repeat_interleave(NB, dim=0) if NB > 1 else hr_input
+            t_pos = (pos.repeat_interleave(NB, dim=0) if NB > 1 else pos) if use_sliding_window else None
+            t_start = start
+            for tok in range(bw):
+                if use_sliding_window and t_in.shape[1] >= sliding_window:
+                    t_start += 1
+                    t_pos = t_pos[:, 1:]
+                n = t_in.shape[1]
+                if n - 1 < cache.max_len and (not use_sliding_window or n < sliding_window):
+                    s.ids.copy_(t_in[:, -1])
+                    ctl[0:1].fill_(n - 1)
+                    s.g_step.replay()
+                    logits = s.logits
+                elif t_pos is None or not whole:
+                    logits = model.decode(t_in[:, t_start:].contiguous(), enc_eval, t_pos)[:, -1, :]
+                else:
+                    logits = model.decode(t_in[:, t_start:].contiguous(), enc_eval, t_pos.long(),
+                                          pos_bound=pos_bound)[:, -1, :]
+                ops.decode_sample(logits, s.T, s.end, s.gen, s.shift, s.uniforms, ctl, tok, bw, s.ids, s.chunk,
+                                  s.comb, forced=s.forced, probs_log=s.probs, inc_len=False, beams=s.beams)
+                t_in = torch.cat((t_in, s.ids[:, None]), dim=1)
+                if use_sliding_window:
+                    t_pos = torch.cat((t_pos, torch.full((B, 1), float(cur + tok + pos_off), device=device)), dim=1)
+            ops.decode_decide(ctl, N, NB, bw, s.comb, s.chunk, s.best_p, s.best_chunk, s.take, draws=s.per_set)
+        ops.decode_advance(ctl, bw)
+        s.used += s.candidates * s.per_set
+        hr_input = torch.cat((hr_input, s.best_chunk), dim=1)
+        start = t_start
+        if use_sliding_window:
+            pos = t_pos[::NB] if NB > 1 else t_pos
+        if progress is not None:
+            progress(hr_input.shape[1] - 1, total_seq)
+    return hr_input
 
 
 def _generate_cached(model, hr_input, enc, total_seq, temperature, use_sliding_window,
@@ -235,18 +327,19 @@ def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_slidi
             hr_input, pos = _generate_cached(*args)
 
     pos_bound = stop_len + beam_width + pos_off + 1
+    if cache is not None and cache._search is not None:
+        tail = _Timer()
+        hr_input = _fused_tail(model, cache, hr_input, pos, enc, use_sliding_window, sliding_window, beam_width,
+                               progress, total_seq, stop_len, pos_off, pos_bound)
+        tail.mark("windowed tail (fused draws)")
+        tail.report()
+        if FUSED_DEBUG is not None:
+            FUSED_DEBUG["probs"] = cache._search.probs
+            FUSED_DEBUG["draws"] = cache._search.used
+        return hr_input
 
     def last_logits(t_in, t_start, t_pos):
-        """Logits of the window's last token.  While no token has left the window the key/value cache of the
-        fused phase is still the window's: the last chunk of a stage that ends where the window starts to slide
-        (256 tokens in a 256-token window) evaluates all but its final token from it instead of re-running the
-        window (each candidate rewrites the rows it reads; nothing reads the cache after this chunk)."""
-        n = t_in.shape[1]
-        if cache is not None and n - 1 < cache.max_len and cache.batch % t_in.shape[0] == 0 and \
-                (not use_sliding_window or n < sliding_window):
-            k = cache.batch // t_in.shape[0]        # cache rows per sequence (candidates ran as rows): all equal
-            ids = t_in[:, -1] if k == 1 else t_in[:, -1].repeat_interleave(k)
-            return cache.step(ids, None, n - 1)[::k]
+        """Logits of the window's last token: the reference's full-window evaluation."""
         # the loop's positions are whole numbers (cur + tok + pos_off): as int64 the model evaluates the
         # conditioning path once per POSITION instead of once per token (Transformer._cond; same values)
         if t_pos is None or not hasattr(model, "_cond"):

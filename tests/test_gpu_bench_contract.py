@@ -47,7 +47,8 @@ def test_bench_line_contract():
         assert o["value"] > 0 and o["ms_per_step"] > 0
         assert {"bound", "achieved", "peak", "unit", "frac"} <= set(o["roofline"]), name
     c3 = side["c3"]
-    assert {"sequential", "sequential_one_by_one", "batched_beams", "decode_step_ms_rows4", "decode_step_ms_rows16",
+    assert {"sequential", "first_call", "sequential_one_by_one", "batched_beams", "decode_step_ms_rows4",
+            "decode_step_ms_rows16",
             "decoder_images_per_s"} <= set(c3)
     assert c3["sequential"]["accepted_tokens_per_s"] == c3["value"] and c3["roofline"]["bound"] == "hbm"
     # the reference's draw order with the candidates as rows of one batch beats running them one after the other

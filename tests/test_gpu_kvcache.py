@@ -242,6 +242,51 @@ def test_cached_generation_matches_full_window_loop(use_encoder, num_beam, bw, b
     assert torch.equal(outs[0], outs[1])
 
 
+def test_decode_caches_are_kept_per_model_rebound_to_new_inputs_and_follow_the_weights():
+    """sampling keeps a model's decode cache (conditioning table, stacked weights, captured step graph, search
+    buffers) between generations: a second generation re-binds it to its own encoder input -- same tokens as a
+    freshly built cache gives -- and a change of the weights drops it."""
+    from qarig import sampling
+    m = _model(True)
+    with torch.no_grad():
+        m.classifier[1].linear_layer[0].bias[40] -= 20.0
+    g = torch.Generator().manual_seed(21)
+    N = 3
+    lr_a, lr_b = (torch.randint(0, 40, (N, 6), generator=g).cuda() for _ in range(2))
+    first = torch.randint(0, 40, (N, 1), generator=g).cuda()
+
+    def run(lr):
+        """(tokens, the probability row of every draw)"""
+        torch.manual_seed(5)
+        sampling.FUSED_DEBUG = {"log": True}
+        try:
+            toks = sampling.generate_tokens(m, first, lr, 24, 0.7, True, 16, end_token=40, num_beam=2, beam_width=4,
+                                            mode="generate", use_kv_cache=True, sampler="fused")
+            return torch.cat((toks.flatten().float(), sampling.FUSED_DEBUG["probs"].flatten()))
+        finally:
+            sampling.FUSED_DEBUG = None
+    sampling.decode_cache_clear()
+    a1 = run(lr_a)
+    assert len(sampling._DECODE_CACHES) == 1
+    (_, _, cache), = sampling._DECODE_CACHES.values()
+    graph = cache._search.g_step
+    b_kept = run(lr_b)                                  # re-bound: other encoder memory, same graph
+    (_, _, c2), = sampling._DECODE_CACHES.values()
+    assert c2 is cache and cache._search.g_step is graph
+    assert torch.equal(run(lr_a), a1) and not torch.equal(a1, b_kept)
+    sampling.decode_cache_clear()
+    assert torch.equal(run(lr_b), b_kept)               # what a fresh cache gives
+    (_, _, c3), = sampling._DECODE_CACHES.values()
+    with torch.no_grad():
+        m.dec_embedding.weight.mul_(1.5)                # the weights move: table, stacked copies and graph are stale
+    moved = run(lr_b)
+    (_, _, c4), = sampling._DECODE_CACHES.values()
+    assert c4 is not c3
+    sampling.decode_cache_clear()
+    assert torch.equal(run(lr_b), moved)
+    sampling.decode_cache_clear()
+
+
 def test_generation_with_head_dim_without_a_cache_kernel():
     """heads=4 on a 48-wide model (head dim 12, served zero-padded by the window kernels): the
     generation loop keeps the reference's full-window evaluation instead of the cache (whose kernel takes
@@ -339,8 +384,8 @@ def test_config3_cascade_three_stages_readme_size_cached_equals_full_window(monk
     assert sum(len(seg) for seg in tape.segments) == sum(seqs) * 4          # num_beam draws per accepted token
     for mode in ("torch", "fused"):
         got, fused = cascade(mode)
-        # the fused sampler makes every draw but those of the last chunk of the 256-token stage, where the window
-        # starts to slide (its 4 candidates x 4 tokens come from cache steps + one full-window evaluation each)
-        assert fused == (sum(seqs) * 4 - 16 if mode == "fused" else 0)
+        # the fused sampler makes every draw, those of the last chunk of the 256-token stage included, where the
+        # window starts to slide (its 4 candidates x 4 tokens: cache steps + one full-window evaluation of 16 rows)
+        assert fused == (sum(seqs) * 4 if mode == "fused" else 0)
         for s in range(3):
             assert torch.equal(want[s], got[s]), (mode, s)

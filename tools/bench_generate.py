@@ -28,12 +28,15 @@ def build_stage_model(s, K, dev):
                        transformer_out_dim=K + 1, transformer_hidden_dim=2048).to(dev).eval()
 
 
-def run_cascade(args, dev, K, N, patches, prev):
-    """One pass over the stages; returns (last-stage tokens, per-stage records)."""
+def run_cascade(args, dev, K, N, patches, prev, models=None):
+    """One pass over the stages; returns (last-stage tokens, per-stage records).  models: the stage models of a
+    loaded generator (kept between cascades: the decode caches sampling keeps per model -- conditioning tables,
+    captured step graphs -- are reused from the second cascade on); None builds fresh ones per stage, i.e. every
+    cascade pays what a first call pays."""
     stages = []
     for s in range(args.stages):
         base = s == 0
-        model = build_stage_model(s, K, dev)
+        model = models[s] if models is not None else build_stage_model(s, K, dev)
         total = (32 // patches[s + 1]) ** 2
         first = prev if base else torch.full((N, 1), K, dtype=torch.int64, device=dev)
         lr_in = None if base else prev
@@ -68,6 +71,9 @@ def main():
     ap.add_argument("--no-kv-cache", action="store_true")
     ap.add_argument("--sampler", choices=["fused", "torch"], default=None,
                     help="cached loop: in-graph sampling kernel (default) or one torch.multinomial per token")
+    ap.add_argument("--rebuild-models", action="store_true",
+                    help="new random stage models for every cascade (no decode cache is ever reused: the cost of a "
+                         "generator's first call) instead of one set kept for the run")
     ap.add_argument("--cold", action="store_true",
                     help="skip the untimed warm-up pass (code-object loads, allocator growth, "
                          "first graph instantiation then land in stage 0)")
@@ -87,9 +93,11 @@ def main():
                      f"candidates={'one by one' if args.one_by_one else 'rows of one batch'}, "
                      f"kv_cache={not args.no_kv_cache}, sampler={args.sampler or sampling.DEFAULT_SAMPLER}, warm={not args.cold}"}
     prev0 = torch.randint(0, K, (N, 1), device=dev)
+    models = None if args.rebuild_models else [build_stage_model(s_, K, dev) for s_ in range(args.stages)]
+    out["config"] += f", models={'rebuilt per cascade' if models is None else 'kept'}"
     if not args.cold:
-        run_cascade(args, dev, K, N, patches, prev0)
-    prev, out["stages"] = run_cascade(args, dev, K, N, patches, prev0)
+        run_cascade(args, dev, K, N, patches, prev0, models)
+    prev, out["stages"] = run_cascade(args, dev, K, N, patches, prev0, models)
     tot_tokens = sum(N * st["seq"] for st in out["stages"])
     tot_time = sum(st["seconds"] for st in out["stages"])
     with torch.no_grad():
