@@ -201,11 +201,22 @@ def _fused_tail(model, cache, hr_input, pos, enc, use_sliding_window, sliding_wi
                     ctl[0:1].fill_(n - 1)
                     s.g_step.replay()
                     logits = s.logits
-                elif t_pos is None or not whole:
-                    logits = model.decode(t_in[:, t_start:].contiguous(), enc_eval, t_pos)[:, -1, :]
                 else:
-                    logits = model.decode(t_in[:, t_start:].contiguous(), enc_eval, t_pos.long(),
-                                          pos_bound=pos_bound)[:, -1, :]
+                    # A slid window is window - 1 tokens: rows x 255 is no whole number of GEMM tiles and runs the
+                    # guarded kernels.  One more token behind the last makes it one (16 x 256 = 4,096 rows) and
+                    # changes nothing before it -- self-attention is causal, everything else is per token -- so the
+                    # logits wanted are those of the last token but one.
+                    win, wpos = t_in[:, t_start:], t_pos
+                    rows_ = win.shape[0] * win.shape[1]
+                    pad = rows_ % 128 != 0 and (rows_ + win.shape[0]) % 128 == 0
+                    if pad:
+                        win = torch.cat((win, win[:, -1:]), dim=1)
+                        wpos = None if wpos is None else torch.cat((wpos, wpos[:, -1:]), dim=1)
+                    if wpos is None or not whole:
+                        logits = model.decode(win.contiguous(), enc_eval, wpos)
+                    else:
+                        logits = model.decode(win.contiguous(), enc_eval, wpos.long(), pos_bound=pos_bound)
+                    logits = logits[:, -2 if pad else -1, :]
                 ops.decode_sample(logits, s.T, s.end, s.gen, s.shift, s.uniforms, ctl, tok, bw, s.ids, s.chunk,
                                   s.comb, forced=s.forced, probs_log=s.probs, inc_len=False, beams=s.beams)
                 t_in = torch.cat((t_in, s.ids[:, None]), dim=1)
