@@ -49,7 +49,12 @@ def _cacheable(model, hr_input, use_sliding_window):
 # the reference does on --device cuda (same generator stream as the reference for a given seed, ~8 extra
 # launches and a graph boundary per token).  QARIG_SAMPLER overrides the default.
 DEFAULT_SAMPLER = "fused"
-ORDERED_ROWS = 16        # images x candidates the reference-order search runs as one batch (decode kernels: <= 16 rows)
+ORDERED_ROWS = 512       # images x candidates the reference-order search runs as rows of one batch (0: one by one)
+DECODE_ROWS = 16         # rows the single-token kernels take (csrc/decode.hip); more rows run the general kernels
+GROUP_BELOW_ROWS = 64    # fused sampler: 16 < images x candidates < 64 is generated in groups of 16 rows (measured:
+                         # 16 images x 4 candidates in groups 0.47 s per 256-token stage, 25 x 4 = 100 rows as one
+                         # batch on the general kernels 0.51 s -- from about 64 rows up one batch is the faster form)
+GROUP_IMAGES = True
 
 # Test hook of the fused sampler: {"forced": (draws, rows) int64 tensor or None, "log": bool}; after a stage
 # "probs" holds the (draws, rows, V) probability rows it sampled from and "draws" their number.
@@ -130,8 +135,8 @@ def _generate_fused(model, hr_input, enc, total_seq, temperature, use_sliding_wi
     N = hr_input.shape[0]
     # The candidate chunks of a position are independent given the kept prefix: they run as rows of one batch
     # either way.  Without --batch-beams every draw keeps the number the reference's candidate loop gives it
-    # (begin_search reference_order: same draws -> same tokens as one candidate after the other) as long as the
-    # rows fit the single-token kernels (16); beyond that the candidates run one after the other.
+    # (begin_search reference_order: same draws -> same tokens as one candidate after the other); ORDERED_ROWS = 0
+    # runs the candidates literally one after the other (tests, A/B).
     ordered = not batch_beams and num_beam > 1 and N * num_beam <= ORDERED_ROWS
     B = num_beam if (batch_beams or ordered) and num_beam > 1 else 1
     cap = stop_len + beam_width
@@ -319,6 +324,24 @@ def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_slidi
     assert mode in ("generate", "train")
     device = hr_input.device
     N = hr_input.shape[0]
+    fused = (sampler or os.environ.get("QARIG_SAMPLER", DEFAULT_SAMPLER)) == "fused"
+    # The single-token kernels behind the fused search take up to 16 rows (images x candidates).  A somewhat
+    # larger batch is generated in groups of that many, one after the other through the model's kept decode
+    # cache -- each group at the step time of 16 rows; from GROUP_BELOW_ROWS rows up the whole batch on the general
+    # kernels is faster (the weights stream once per step for all rows).  The images are independent
+    # (generate_images.py:256-345 loops over them only through the batch dimension).
+    group = max(1, DECODE_ROWS // max(1, num_beam))
+    rows_all = N * max(1, num_beam)
+    if fused and GROUP_IMAGES and use_kv_cache and N > group and DECODE_ROWS < rows_all < GROUP_BELOW_ROWS and \
+            _cacheable(model, hr_input, use_sliding_window):
+        outs = []
+        for g0 in range(0, N, group):
+            sub = slice(g0, min(N, g0 + group))
+            sub_progress = progress if g0 + group >= N else None
+            outs.append(generate_tokens(model, hr_input[sub], None if lr_input is None else lr_input[sub], total_seq,
+                                        temperature, use_sliding_window, sliding_window, end_token, shift, num_beam,
+                                        beam_width, mode, sub_progress, batch_beams, use_kv_cache, sampler))
+        return torch.cat(outs, dim=0)
     enc = model.encode(lr_input) if model.use_encoder else None
     pos = torch.zeros((N, 1), device=device) if use_sliding_window else None
     start = 0
@@ -330,7 +353,7 @@ def generate_tokens(model, hr_input, lr_input, total_seq, temperature, use_slidi
         args = (model, hr_input, enc, total_seq, temperature, use_sliding_window, sliding_window, end_token,
                 shift, num_beam, beam_width, mode, progress, stop_len, pos_off, batch_beams)
         done = None
-        if (sampler or os.environ.get("QARIG_SAMPLER", DEFAULT_SAMPLER)) == "fused":
+        if fused:
             done = _generate_fused(*args)
         if done is not None:
             hr_input, pos, cache = done

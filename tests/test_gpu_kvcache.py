@@ -287,6 +287,44 @@ def test_decode_caches_are_kept_per_model_rebound_to_new_inputs_and_follow_the_w
     sampling.decode_cache_clear()
 
 
+def test_batches_between_16_and_64_rows_are_generated_in_groups_of_16_rows():
+    """5 images x 4 candidates = 20 rows: generated as 4 + 1 images through the model's kept cache -- the same tokens
+    as generating the two groups by hand (same generator, same order); 1 x 4 and 16 x 4 rows are not split."""
+    from qarig import sampling
+    m = _model(True)
+    with torch.no_grad():
+        m.classifier[1].linear_layer[0].bias[40] -= 20.0
+    g = torch.Generator().manual_seed(8)
+    lr = torch.randint(0, 40, (16, 6), generator=g).cuda()
+    first = torch.randint(0, 40, (16, 1), generator=g).cuda()
+    calls = []
+    real = sampling._generate_fused
+
+    def spy(model, hr_input, *a, **k):
+        calls.append(hr_input.shape[0])
+        return real(model, hr_input, *a, **k)
+
+    def run(sl):
+        return sampling.generate_tokens(m, first[sl], lr[sl], 20, 0.7, True, 32, end_token=40, num_beam=4,
+                                        beam_width=4, mode="generate", use_kv_cache=True, sampler="fused")
+    sampling._generate_fused = spy
+    try:
+        torch.manual_seed(3)
+        whole = run(slice(0, 5))
+        assert calls == [4, 1]
+        torch.manual_seed(3)
+        parts = torch.cat((run(slice(0, 4)), run(slice(4, 5))), dim=0)
+        assert torch.equal(whole, parts) and whole.shape == (5, 21)
+        assert int(whole[:, 1:].min()) >= 0 and int(whole[:, 1:].max()) < 40
+        del calls[:]
+        run(slice(0, 1))
+        run(slice(0, 16))
+        assert calls == [1, 16]
+    finally:
+        sampling._generate_fused = real
+        sampling.decode_cache_clear()
+
+
 def test_generation_with_head_dim_without_a_cache_kernel():
     """heads=4 on a 48-wide model (head dim 12, served zero-padded by the window kernels): the
     generation loop keeps the reference's full-window evaluation instead of the cache (whose kernel takes

@@ -80,6 +80,8 @@ def main():
     args = ap.parse_args()
     if args.one_by_one:
         sampling.ORDERED_ROWS = 0
+    if os.environ.get("QARIG_NO_GROUPS") == "1":      # A/B: the whole batch at once on the general kernels
+        sampling.GROUP_IMAGES = False
     dev = torch.device("cuda", 0)
     torch.manual_seed(69)
     K, N = 512, args.images
