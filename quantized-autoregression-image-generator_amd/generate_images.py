@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Cascade image generation on MI355X: same command line, stage-config JSON and output
 files as the reference's generate_images.py (base stage "0" + encoder-decoder stages,
-best-of-`num_beam` chunks of `beam_width` tokens, sliding window)."""
+best-of-`num_beam` chunks of `beam_width` tokens, sliding window).
+
+Under torchrun (one process per GPU) the images are sharded across the ranks -- they are independent, no
+collective on the data path -- and every stage's token ids are gathered (a few KB) so that rank 0 decodes and
+writes the same image grids a single process writes; rank r seeds its generator with --seed + r."""
 import argparse
 import os
 import pathlib
@@ -10,7 +14,7 @@ import torch
 
 from models.Transformer import Transformer
 from qarig import cli_common as cc
-from qarig import ops, sampling
+from qarig import ops, parallel, sampling
 from utils.image_utils import save_images
 from utils.model_utils import load_model
 
@@ -42,18 +46,21 @@ def parse_args():
 
 def main():
     args = parse_args()
-    device, _, _ = cc.require_gpu(args["device"])
+    device, world, rank = cc.require_gpu(args["device"])
     num_images, out_dir = args["num_images"], args["out_dir"]
+    lo, hi = parallel.shard_range(num_images)
+    n_local = hi - lo                                    # this rank's images
+    log = print if rank == 0 else (lambda *a, **k: None)
     os.makedirs(out_dir, exist_ok=True)
     if args["seed"] is not None:
-        torch.manual_seed(args["seed"])
+        torch.manual_seed(args["seed"] + rank)
     config = cc.read_config(args["config_path"])
     decoder_model, _ = cc.load_decoder(args["decoder_path"], device)
     decoder_model.eval()
 
     hr_input = None
     for index, data in config.items():          # stages "0", "1", "2" in file order
-        print(f"Model: {int(index):,}")
+        log(f"Model: {int(index):,}")
         lr_codebook = None
         if data["lr_codebook_path"] is not None:
             lr_codebook, lr_d = cc.load_codebook(data["lr_codebook_path"], device)
@@ -85,27 +92,32 @@ def main():
                 # base stage: a random LR-codebook token is the image-level condition
                 k_lr = lr_d["num_embeddings"]
                 lr_input = None
-                hr_input = torch.randint(low=0, high=k_lr, size=(num_images, 1), device=device)
-                cond = decoder_model(lr_codebook.get_quantized_image(indices=hr_input,
-                                                                     unpatchify_input=True))
-                save_images(images=cond, file_name="recon_model_Cond", dest_path=out_dir, logging=print)
+                hr_input = torch.randint(low=0, high=k_lr, size=(n_local, 1), device=device)
+                all_cond = parallel.gather_rows(hr_input, num_images)
+                if rank == 0:
+                    cond = decoder_model(lr_codebook.get_quantized_image(indices=all_cond, unpatchify_input=True))
+                    save_images(images=cond, file_name="recon_model_Cond", dest_path=out_dir, logging=print)
                 shift = k_lr
             else:
                 lr_input = hr_input                                   # previous stage's tokens
-                hr_input = torch.full((num_images, 1), k_hr, dtype=torch.int64, device=device)
+                hr_input = torch.full((n_local, 1), k_hr, dtype=torch.int64, device=device)
 
-            hr_input = sampling.generate_tokens(
-                model, hr_input, lr_input, total_Seq, data["temperature"], md["use_sliding_window"],
-                md["sliding_window"], end_token=k_hr, shift=shift, num_beam=data["num_beam"],
-                beam_width=data["beam_width"], mode="generate",
-                progress=lambda i, t: print(f"{i:,} / {t:,}"), batch_beams=args["batch_beams"],
-                use_kv_cache=not args["no_kv_cache"], sampler=args["sampler"])
-            hr_input = hr_input[:, 1:] - shift
-            recon = decoder_model(hr_codebook.get_quantized_image(indices=hr_input,
-                                                                  unpatchify_input=True))
+            if n_local:
+                hr_input = sampling.generate_tokens(
+                    model, hr_input, lr_input, total_Seq, data["temperature"], md["use_sliding_window"],
+                    md["sliding_window"], end_token=k_hr, shift=shift, num_beam=data["num_beam"],
+                    beam_width=data["beam_width"], mode="generate",
+                    progress=lambda i, t: log(f"{i:,} / {t:,}"), batch_beams=args["batch_beams"],
+                    use_kv_cache=not args["no_kv_cache"], sampler=args["sampler"])
+                hr_input = hr_input[:, 1:] - shift
+            else:                                        # more ranks than images: nothing to generate here
+                hr_input = torch.zeros((0, total_Seq), dtype=torch.int64, device=device)
             ops.check_index_flag(device, f"stage {index} tokens")
-            save_images(images=recon, file_name=f"recon_model_{index}", dest_path=out_dir,
-                        logging=print)
+            all_tokens = parallel.gather_rows(hr_input, num_images)
+            if rank == 0:
+                recon = decoder_model(hr_codebook.get_quantized_image(indices=all_tokens, unpatchify_input=True))
+                ops.check_index_flag(device, f"stage {index} tokens")
+                save_images(images=recon, file_name=f"recon_model_{index}", dest_path=out_dir, logging=print)
         del model
         torch.cuda.empty_cache()
 

@@ -16,6 +16,7 @@ def require_gpu(device):
     if not torch.cuda.is_available():
         raise SystemExit("--device cuda requested but no GPU is visible")
     world, rank, local = parallel.init()
+    local %= torch.cuda.device_count()      # (more ranks than GPUs: gloo tests on a one-GPU box share the device)
     torch.cuda.set_device(local)
     return torch.device("cuda", local), world, rank
 

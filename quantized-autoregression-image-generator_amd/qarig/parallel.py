@@ -23,12 +23,12 @@ def init(backend=None, force=False):
     `force`, which tests use to drive the RCCL code path with a single rank)."""
     world, rank, local = env_world()
     if (world > 1 or force) and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:     # QARIG_DIST_BACKEND=gloo: several ranks on one GPU (tests; RCCL wants a GPU per rank)
+            backend = os.environ.get("QARIG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local)     # RCCL: one GPU per rank
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return world, rank, local
 
@@ -69,6 +69,30 @@ def shard(t, dim=0):
         return t
     per = t.shape[dim] // w
     return t.narrow(dim, r * per, per)
+
+
+def shard_range(n):
+    """[lo, hi) of this rank's contiguous share of n independent items (images to generate, files to encode):
+    ceil(n / world) each, the last ranks possibly fewer or none."""
+    w, r = world_size(), rank()
+    per = -(-n // w)
+    lo = min(n, r * per)
+    return lo, min(n, lo + per)
+
+
+def gather_rows(t, n):
+    """The shards of shard_range(n) -- this rank's (hi - lo, ...) tensor t -- as one (n, ...) tensor on every rank
+    (an all-gather of equal-sized, zero-padded pieces: the only exchange of sharded generation, a few KB of
+    token ids per stage)."""
+    w = world_size()
+    if w == 1:
+        return t
+    per = -(-n // w)
+    pad = torch.zeros((per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    parts = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(parts, pad)
+    return torch.cat(parts, dim=0)[:n]
 
 
 def broadcast_params(optim, src=0):

@@ -58,6 +58,15 @@ def _worker(rank, world, port, q):
     p = torch.arange(8.0)
     parallel.broadcast_params(p if rank == 0 else p.zero_())
     assert torch.equal(p, torch.arange(8.0))
+    # independent items sharded over the ranks (images of generate_images.py) and their rows gathered back:
+    # 5 items -> 3 + 2, 1 item -> 1 + 0 (a rank with nothing still takes part)
+    for n in (5, 1, 4):
+        lo, hi = parallel.shard_range(n)
+        per = -(-n // world)
+        assert (lo, hi) == (min(n, rank * per), min(n, rank * per + per))
+        mine = torch.arange(lo, hi)[:, None] * 10 + torch.arange(3)[None]          # (hi - lo, 3)
+        allr = parallel.gather_rows(mine, n)
+        assert torch.equal(allr, torch.arange(n)[:, None] * 10 + torch.arange(3)[None])
     if rank == 0:
         full = grads(x, t, pos)
         q.put((float((local - full).abs().max()), float(full.abs().max()),

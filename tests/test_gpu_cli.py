@@ -176,6 +176,23 @@ def test_cli_pipeline(tmp_path):
     a = open(f"{t}/gen/images/recon_model_1.jpg", "rb").read()
     b = open(f"{t}/gen2/images/recon_model_1.jpg", "rb").read()
     assert a == b
+    # two ranks (gloo: both on the test box's one GPU; production: one GPU each over RCCL): the images are sharded
+    # 2 + 1, rank 0 writes the same three grids of all three images; deterministic for a seed
+    grids = []
+    for tag in ("gen_w2a", "gen_w2b"):
+        env2 = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""),
+                    QARIG_DIST_BACKEND="gloo")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(PKG, "generate_images.py"),
+                            "--device", "cuda", "--decoder-path", f"{t}/ae/models_checkpoint/model_2.pt",
+                            "--num-images", "3", "--seed", "69", "--config-path", f"{t}/gen.json", "--out-dir",
+                            f"{t}/{tag}"], cwd=t, env=env2, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, f"2-rank generate_images.py failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+        for f in ("recon_model_Cond", "recon_model_0", "recon_model_1"):
+            assert os.path.exists(f"{t}/{tag}/images/{f}.jpg")
+        grids.append(open(f"{t}/{tag}/images/recon_model_1.jpg", "rb").read())
+    assert grids[0] == grids[1]
+    assert Image.open(f"{t}/gen_w2a/images/recon_model_1.jpg").size == Image.open(f"{t}/gen/images/recon_model_1.jpg").size
     # --device cpu is refused loudly
     env = dict(os.environ, PYTHONPATH=PKG)
     r = subprocess.run([sys.executable, os.path.join(PKG, "generate_images.py"), "--device", "cpu",
