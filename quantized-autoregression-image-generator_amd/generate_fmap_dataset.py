@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Encode an image dataset into per-image latent .npy files + a TinyDB-format index on
 MI355X: same command line and output layout (<out>/<folder>/<index> files,
-<out>/all_dataset.json) as the reference's generate_fmap_dataset.py."""
+<out>/all_dataset.json) as the reference's generate_fmap_dataset.py.
+
+Under torchrun every rank encodes a contiguous share of the files (independent units, no collective on the
+data path) under the file numbers a single process gives them; rank 0 writes the index of all of them."""
 import argparse
 import os
 import pathlib
@@ -11,21 +14,23 @@ import torch
 
 from models.FC_Encoder import FC_Encoder
 from qarig import cli_common as cc
+from qarig import parallel
 from dataset_loader._tinydb_json import write_all
 from dataset_loader.image_dataset import ImageDataset
 from utils.model_utils import load_model
 
 
-def save_feature_maps(model, dataloader, out_dir, device, num_files_folder=1_000):
-    file_index, folder_name, all_data = 0, 0, []
+def save_feature_maps(model, dataloader, out_dir, device, num_files_folder=1_000, first_index=0):
+    """first_index: the dataset position of the loader's first item (a rank's share starts there): file numbers
+    and folders are those of the whole dataset in order (reference generate_fmap_dataset.py:40-72)."""
+    file_index, all_data = first_index, []
     print("#" * 100)
     print("Saving Feature Maps to disk...")
     for index, (image, image_paths) in enumerate(dataloader):
         with torch.no_grad():
             latent = model(image.to(device)).cpu()
         for fmap, image_path in zip(latent, image_paths):
-            if file_index % num_files_folder == 0 and file_index > 0:
-                folder_name += 1
+            folder_name = file_index // num_files_folder
             folder = os.path.join(out_dir, str(folder_name))
             os.makedirs(folder, exist_ok=True)
             path = os.path.join(folder, f"{file_index}")
@@ -35,8 +40,14 @@ def save_feature_maps(model, dataloader, out_dir, device, num_files_folder=1_000
             all_data.append({"fmap_path": path, "image_path": image_path})
         print(f"{(index + 1):,} / {len(dataloader):,}")
     print("Finished saving feature maps.")
-    write_all(os.path.join(out_dir, "all_dataset.json"), all_data)
-    print("Finished saving json file.")
+    if parallel.world_size() > 1:                       # the records of every rank's share, in dataset order
+        import torch.distributed as dist
+        shares = [None] * parallel.world_size()
+        dist.all_gather_object(shares, all_data)
+        all_data = [rec for share in shares for rec in share]
+    if parallel.rank() == 0:
+        write_all(os.path.join(out_dir, "all_dataset.json"), all_data)
+        print("Finished saving json file.")
     print("#" * 100)
 
 
@@ -65,9 +76,12 @@ def main():
     encoder.custom_load_state_dict(d["model"], ignore_msgs=True)
     encoder = encoder.to(device).eval()
     dataset = ImageDataset(dataset_path=args["dataset_path"], return_filepaths=True)
+    lo, hi = parallel.shard_range(len(dataset))
+    if parallel.world_size() > 1:
+        dataset = torch.utils.data.Subset(dataset, range(lo, hi))
     loader = torch.utils.data.DataLoader(dataset, batch_size=args["batch_size"], num_workers=4,
                                          shuffle=False)
-    save_feature_maps(encoder, loader, str(args["out_dir"]), device, args["num_files_folder"])
+    save_feature_maps(encoder, loader, str(args["out_dir"]), device, args["num_files_folder"], first_index=lo)
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ import torch
 
 from models.Codebook import Codebook
 from qarig import cli_common as cc
-from qarig import ops
+from qarig import ops, parallel
 from dataset_loader.feature_map_dataset import FeatureMapDataset
 from utils.model_utils import save_model
 
@@ -25,7 +25,7 @@ def main():
     p.add_argument("--prune-threshold", type=int, default=10)
     p.add_argument("--out-dir", required=True, type=pathlib.Path)
     args = vars(p.parse_args())
-    device, _, rank = cc.require_gpu(args["device"])
+    device, world, rank = cc.require_gpu(args["device"])
     out_dir = args["out_dir"]
     cc.setup_logging(out_dir, project_name, rank)
     info = logging.info
@@ -43,12 +43,19 @@ def main():
     info("#" * 100)
     dataset = FeatureMapDataset(dataset_path=args["dataset_path"], load_image=False,
                                 return_filepaths=False)
+    if world > 1:       # every rank counts a contiguous share of the files; ONE exchange: the K-bin histogram
+        dataset = torch.utils.data.Subset(dataset, range(*parallel.shard_range(len(dataset))))
     loader = torch.utils.data.DataLoader(dataset, batch_size=args["batch_size"], num_workers=4,
                                          shuffle=True)
     counts = torch.zeros(d["num_embeddings"], dtype=torch.int64, device=device)
     for fm in loader:
         ops.index_histogram(codebook.get_patches_bmu(fm.to(device)), counts)
     ops.check_index_flag(device, "BMU histogram")
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        if rank != 0:
+            return                      # rank 0 prints the histogram and writes the pruned codebook
     counts = counts.cpu().tolist()
     good = []
     for i, c in enumerate(counts):

@@ -24,6 +24,17 @@ def run(script, *args, cwd):
     return r.stdout + r.stderr
 
 
+def run2(script, *args, cwd, port=29633):
+    """The script under torchrun with two ranks (gloo: both on the test box's one GPU; production: one GPU per
+    rank over RCCL)."""
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""), QARIG_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(PKG, script),
+                        *map(str, args)], cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"2-rank {script} failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    return r.stdout + r.stderr
+
+
 def test_cli_pipeline(tmp_path):
     from PIL import Image
     sys.path.insert(0, PKG)
@@ -75,6 +86,14 @@ def test_cli_pipeline(tmp_path):
     sd64 = {k: v.double() for k, v in ae["model"].items()}
     zref = rm.fc_encoder(sd64, x0.double(), final_act="tanh", prefix="fc_encoder.fc_encoder_layer")[0]
     assert float((torch.from_numpy(z0).double() - zref).abs().max() / zref.abs().max()) < 1e-5
+    # two ranks, a contiguous share of the files each: the same files under the same numbers, one index
+    run2("generate_fmap_dataset.py", "--device", "cuda", "--batch-size", 5, "--num-files-folder", 8, "--dataset-path",
+         f"{t}/dataset.json", "--model-path", f"{t}/ae/models_checkpoint/model_2.pt", "--out-dir", f"{t}/fmaps_w2", cwd=t)
+    frecs2 = read_all(f"{t}/fmaps_w2/all_dataset.json")
+    assert [r["image_path"] for r in frecs2] == [r["image_path"] for r in frecs]
+    for a_, b_ in zip(frecs, frecs2):
+        assert os.path.relpath(a_["fmap_path"], f"{t}/fmaps") == os.path.relpath(b_["fmap_path"], f"{t}/fmaps_w2")
+        assert open(a_["fmap_path"], "rb").read() == open(b_["fmap_path"], "rb").read()
     os.replace(f"{t}/fmaps/all_dataset.json", f"{t}/fmaps.json")
 
     for name, p, k in (("lr", 8, 8), ("mid", 2, 16), ("hr", 1, 16)):
@@ -108,6 +127,15 @@ def test_cli_pipeline(tmp_path):
     want = np.bincount(obmu.bmu(fm_all, wmid, (2, 2)), minlength=16)
     assert counts == want.tolist()
     assert np.array_equal(pr["checkpoint"]["codebook.weight"].numpy(), wmid[want >= 3])
+    # two ranks: a share of the files each, one all-reduce of the histogram; rank 0 prints and writes the same
+    out2 = run2("prune_codebook.py", "--device", "cuda", "--dataset-path", f"{t}/fmaps.json", "--codebook-path",
+                f"{t}/cb_mid/models_checkpoint/codebook_2.pt", "--batch-size", 4, "--prune-threshold", 3, "--out-dir",
+                f"{t}/prune_w2", cwd=t, port=29634)
+    counts2 = [int(l.split(": ")[1].replace(",", "")) for l in out2.splitlines()
+               if ": " in l and l.split(": ")[0].isdigit()]
+    ok, pr2 = load_model(f"{t}/prune_w2/models_checkpoint/pruned_codebook.pt")
+    assert ok and counts2 == counts
+    assert np.array_equal(pr2["checkpoint"]["codebook.weight"].numpy(), pr["checkpoint"]["codebook.weight"].numpy())
 
     tcfg = dict(model_lr=1e-3, num_enc_layers=1, num_dec_layers=2, cross_attn_heads=2,
                 self_attn_heads=4, in_dim=32, hidden_dim=64, hidden_activation="silu",
@@ -180,14 +208,9 @@ def test_cli_pipeline(tmp_path):
     # 2 + 1, rank 0 writes the same three grids of all three images; deterministic for a seed
     grids = []
     for tag in ("gen_w2a", "gen_w2b"):
-        env2 = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""),
-                    QARIG_DIST_BACKEND="gloo")
-        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                            "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(PKG, "generate_images.py"),
-                            "--device", "cuda", "--decoder-path", f"{t}/ae/models_checkpoint/model_2.pt",
-                            "--num-images", "3", "--seed", "69", "--config-path", f"{t}/gen.json", "--out-dir",
-                            f"{t}/{tag}"], cwd=t, env=env2, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, f"2-rank generate_images.py failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+        run2("generate_images.py", "--device", "cuda", "--decoder-path", f"{t}/ae/models_checkpoint/model_2.pt",
+             "--num-images", "3", "--seed", "69", "--config-path", f"{t}/gen.json", "--out-dir", f"{t}/{tag}", cwd=t,
+             port=29631)
         for f in ("recon_model_Cond", "recon_model_0", "recon_model_1"):
             assert os.path.exists(f"{t}/{tag}/images/{f}.jpg")
         grids.append(open(f"{t}/{tag}/images/recon_model_1.jpg", "rb").read())
