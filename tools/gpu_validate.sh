@@ -13,6 +13,8 @@ step 400 $O/${TAG}_bench_c5.json python bench.py --config c5 --steps 10 --warmup
 step 400 $O/${TAG}_bench_c3.json python bench.py --config c3 --steps 1 --warmup 1; cut -c1-330 $O/${TAG}_bench_c3.json
 step 300 $O/${TAG}_generate_c3_sequential.json python tools/bench_generate.py; cat $O/${TAG}_generate_c3_sequential.json
 step 300 $O/${TAG}_generate_c3_one_by_one.json python tools/bench_generate.py --one-by-one; cat $O/${TAG}_generate_c3_one_by_one.json
+step 300 $O/${TAG}_generate_c3_first_call.json python tools/bench_generate.py --rebuild-models; cat $O/${TAG}_generate_c3_first_call.json
+step 300 $O/${TAG}_generate_c3_25_images.json python tools/bench_generate.py --images 25; cat $O/${TAG}_generate_c3_25_images.json
 step 300 $O/${TAG}_generate_c3_batched_beams.json python tools/bench_generate.py --batch-beams; cat $O/${TAG}_generate_c3_batched_beams.json
 step 300 $O/${TAG}_decode_step_rows4.json python tools/decode_step_probe.py --rows 4; cat $O/${TAG}_decode_step_rows4.json
 step 300 $O/${TAG}_decode_step_rows16.json python tools/decode_step_probe.py --rows 16; cat $O/${TAG}_decode_step_rows16.json
