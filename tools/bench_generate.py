@@ -47,11 +47,12 @@ def run_cascade(args, dev, K, N, patches, prev, models=None):
                                         beam_width=args.beam_width, mode="generate",
                                         batch_beams=args.batch_beams,
                                         use_kv_cache=not args.no_kv_cache, sampler=args.sampler)
+        t_host = time.perf_counter() - t0           # until the call returned: everything enqueued, nothing awaited
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         prev = toks[:, 1:] - (K if base else 0)
         acc = N * total
-        stages.append({"stage": s, "seq": total, "seconds": round(dt, 3),
+        stages.append({"stage": s, "seq": total, "seconds": round(dt, 3), "host_enqueue_seconds": round(t_host, 3),
                        "accepted_tokens_per_s": round(acc / dt, 1),
                        "model_eval_tokens_per_s": round(acc * args.num_beam / dt, 1)})
         del model
