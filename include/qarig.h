@@ -178,6 +178,13 @@ int qarig_cast_colsum(const void* src, int64_t ld, int src_is_bf16, int M, int N
  * a caller that chooses the reduction split counts those tiles. */
 int qarig_gemm_tile64(int M, int N, int K);
 
+/* 1 when, under option gemm_x3 (qarig_set_option("gemm_x3", 1); off by default), qarig_gemm_f32 runs an
+ * (M, N, K) product with `splitk` reduction splits on the bf16 matrix pipe: both fp32 operands split on
+ * the fly into three bf16 pieces that add up to them exactly, six products per block accumulated in fp32
+ * (csrc/gemm_x3.hip: whole 128 x 128 tiles and 32-deep k-tiles per split).  Same operands, epilogue and
+ * tolerances as the fp32-MFMA kernels (models/layers.py:234-254, 330-340); non-finite operands give NaN. */
+int qarig_gemm_x3_ok(int M, int N, int K, int splitk);
+
 /* `groups` independent skinny products in one launch, C_g = act(A_g W_g^T + bias_g) with
  * X_g = X + g * x_gs (a_gs == 0 shares the activations).  Decode steps use it for the q/k/v
  * MLPs (models/layers.py:389-418) and for every projection of the conditioning vector

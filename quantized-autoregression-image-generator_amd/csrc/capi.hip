@@ -41,7 +41,7 @@ extern "C" int qarig_set_option(const char* name, int value) {
         {"lp_mfma16", &g_qarig_opt.lp_mfma16},     {"convt_pair", &g_qarig_opt.convt_pair},
         {"conv_ring", &g_qarig_opt.conv_ring},     {"gemm_xcd_splits", &g_qarig_opt.gemm_xcd_splits},
         {"decode_stream", &g_qarig_opt.decode_stream}, {"decode_rows", &g_qarig_opt.decode_rows},
-        {"gemm_tile64", &g_qarig_opt.gemm_tile64},
+        {"gemm_tile64", &g_qarig_opt.gemm_tile64}, {"gemm_x3", &g_qarig_opt.gemm_x3},
     };
     if (name)
         for (const Entry& e : table)
@@ -51,6 +51,6 @@ extern "C" int qarig_set_option(const char* name, int value) {
                 return old;
             }
     qarig_set_error("set_option: unknown option %s (gemm_dma, gemm_pair, bmu_cs, bmu_groups, bmu_coarse, attn_qw, "
-                    "attn_bw, lp_big, lp_mfma16, convt_pair, conv_ring, gemm_xcd_splits, decode_stream, decode_rows, gemm_tile64)", name ? name : "(null)");
+                    "attn_bw, lp_big, lp_mfma16, convt_pair, conv_ring, gemm_xcd_splits, decode_stream, decode_rows, gemm_tile64, gemm_x3)", name ? name : "(null)");
     return -2147483647 - 1;
 }

@@ -739,6 +739,11 @@ static void launch_skinny(const float* A, int64_t lda, const float* B, int64_t l
 int qarig_gemm64_launch(const float* A, int64_t lda, int a_kcontig, const float* B, int64_t ldb, int b_kcontig,
                         const GemmEpilogue& ep, int M, int N, int K, int splitk, float* slabs, hipStream_t st);
 
+// csrc/gemm_x3.hip
+extern "C" int qarig_gemm_x3_ok(int M, int N, int K, int splitk);
+int qarig_gemm_x3_launch(const float* A, int64_t lda, int a_kcontig, const float* B, int64_t ldb, int b_kcontig,
+                         const GemmEpilogue& ep, int M, int N, int K, int splitk, float* slabs, hipStream_t st);
+
 static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float* B,
                          int64_t ldb, int b_kcontig, float* C, int64_t ldc, int M, int N,
                          int K, const float* bias, const float* residual, int64_t ldr,
@@ -809,7 +814,12 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
                      qarig_gemm_tile64(M, N, K);
     const bool pair_ok = dma_on && fast && vec_epi && !(a_rowsum && a_kcontig) && !(!a_kcontig && b_kcontig) &&
                          nk_block % 2 == 0 && nk_block >= 4;
-    if (t64 && pair_env != 1) {           // (gemm_pair = 1 forces the two-team kernel: the cross-check of this one)
+    // opt-in: the products on the bf16 matrix pipe from exact three-way operand splits (gemm_x3.hip)
+    const bool x3 = g_qarig_opt.gemm_x3 != 0 && fast && vec_epi && !(a_rowsum && a_kcontig) &&
+                    qarig_gemm_x3_ok(M, N, K, splitk);
+    if (x3) {
+        qarig_gemm_x3_launch(A, lda, a_kcontig, B, ldb, b_kcontig, ep, M, N, K, splitk, slabs, st);
+    } else if (t64 && pair_env != 1) {    // (gemm_pair = 1 forces the two-team kernel: the cross-check of this one)
         qarig_gemm64_launch(A, lda, a_kcontig, B, ldb, b_kcontig, ep, M, N, K, splitk, slabs, st);
     } else if (pair_ok && pair_env != 0 && (pair_env == 1 || (long)grid.x * grid.z <= 256)) {
         constexpr int PAIR_LDS = 2 * PF_STAGES * DMA_STAGE_FLOATS * (int)sizeof(float);

@@ -36,6 +36,7 @@ SIGNATURES = {
     "qarig_gemm_f32": (I, [P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, I, P, P, Z,
                            P]),
     "qarig_gemm_tile64": (I, [I, I, I]),
+    "qarig_gemm_x3_ok": (I, [I, I, I, I]),
     "qarig_gemm_grouped_supported": (I, [I, I, I, I]),
     "qarig_gemm_grouped_workspace_bytes": (Z, [I, I, I, I, I]),
     "qarig_gemm_f32_grouped": (I, [I, P, L, I, P, L, I, P, L, I, I, I, P, P, L, P, L, I, P, L, I, I, I, I, P,
@@ -141,7 +142,7 @@ def load():
 
 
 OPTIONS = ("gemm_dma", "gemm_pair", "bmu_cs", "bmu_groups", "bmu_coarse", "attn_qw", "attn_bw", "lp_big",
-           "lp_mfma16", "convt_pair", "conv_ring", "gemm_xcd_splits", "decode_stream", "decode_rows", "gemm_tile64")
+           "lp_mfma16", "convt_pair", "conv_ring", "gemm_xcd_splits", "decode_stream", "decode_rows", "gemm_tile64", "gemm_x3")
 
 
 OPTION_EPOCH = 0     # bumped by set_option: cached artefacts whose layout depends on the kernel family carry it in their key

@@ -31,7 +31,7 @@ def test_unknown_option_is_refused():
 
 
 @pytest.mark.parametrize("name,value", [("gemm_dma", 0), ("gemm_pair", 0), ("gemm_pair", 1), ("gemm_xcd_splits", 0),
-                                        ("gemm_tile64", 0), ("gemm_tile64", 1)])
+                                        ("gemm_tile64", 0), ("gemm_tile64", 1), ("gemm_x3", 1)])
 def test_gemm_options(option, name, value):
     import test_gpu_core as core
     import test_gpu_grouped as grouped
@@ -45,6 +45,50 @@ def test_gemm_options(option, name, value):
     core.test_gemm_paired_teams(2048, 2048, 512, True, True, 1)
     core.test_gemm_paired_teams(2048, 512, 2048, False, False, 4)
     grouped.test_grouped_mlp_node_matches_separate_mlps_and_fp64(3, 256, 128, 256, 0, True)
+
+
+def test_gemm_x3_takes_the_products_and_keeps_the_fp32_tolerances(option):
+    """Option gemm_x3: the interior products run as six bf16-MFMA products of exact three-way operand splits
+    (csrc/gemm_x3.hip).  Every layout, split and epilogue against fp64 at the fp32 kernels' own tolerance
+    (2e-6 sqrt(K / 512)); the results differ from the fp32-MFMA kernel's in the last bits (another summation), so
+    the kernel did run; row sums riding on a weight-gradient product; a whole train step's parity follows in
+    test_gpu_pipeline_golden under the same option."""
+    from conftest import rel_err
+    from qarig import _lib, ops
+    import test_gpu_pipeline_golden as golden
+    g = torch.Generator().manual_seed(12)
+    lib = _lib.load()
+    assert lib.qarig_gemm_x3_ok(2048, 512, 512, 1) == 1 and lib.qarig_gemm_x3_ok(2048, 512, 520, 1) == 0
+    assert lib.qarig_gemm_x3_ok(2000, 512, 512, 1) == 0 and lib.qarig_gemm_x3_ok(512, 2048, 16384, 8) == 1
+    for (M, N, K, ak, bk, sk) in ((2048, 512, 512, True, True, 1), (1024, 2048, 2048, True, False, 1),
+                                  (512, 2048, 4096, False, False, 8), (256, 128, 8192, False, True, 4),
+                                  (128, 128, 32, True, True, 1)):
+        A = torch.randn((M, K) if ak else (K, M), generator=g).cuda()
+        B = (torch.randn((N, K) if bk else (K, N), generator=g) * 0.05).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        res = torch.randn((M, N), generator=g).cuda()
+        want = (A.double() if ak else A.double().t()) @ (B.double().t() if bk else B.double())
+        outs = {}
+        for x3 in (0, 1):
+            option("gemm_x3", x3)
+            outs[x3] = ops.gemm(A, B, a_kcontig=ak, b_kcontig=bk, splitk=sk)
+            tol = 2e-6 * max(1.0, K / 512) ** 0.5
+            assert rel_err(outs[x3], want) < tol, (M, N, K, ak, bk, sk, x3)
+            if sk == 1:
+                y = ops.gemm(A, B, a_kcontig=ak, b_kcontig=bk, bias=bias, residual=res, act=ops.act_id("silu"))
+                assert rel_err(y, torch.nn.functional.silu(want + bias.double() + res.double())) < tol
+        if K >= 512:
+            assert not torch.equal(outs[0], outs[1])
+    # the bias gradient riding on a weight-gradient product (tile-contiguous A)
+    option("gemm_x3", 1)
+    dT = torch.randn((4096, 512), generator=g).cuda()
+    X = torch.randn((4096, 2048), generator=g).cuda()
+    rs = torch.zeros(512, device="cuda")
+    dW = ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=8, a_rowsum=rs)
+    assert rel_err(dW, dT.double().t() @ X.double()) < 2e-6 * 8 ** 0.5
+    assert rel_err(rs, dT.double().sum(0)) < 2e-6 * 8 ** 0.5
+    # one full train step of the golden pipeline under the option
+    golden.test_train_step_matches_reference_step("base", False)
 
 
 @pytest.mark.parametrize("name,value", [("bmu_cs", 1), ("bmu_cs", 2), ("bmu_cs", 4), ("bmu_groups", 0),

@@ -1,4 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-for n in 8 4; do echo "--- $n images"; timeout -k 10 300 python tools/bench_generate.py --images $n 2> $O/r04x_g$n.err | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['accepted_tokens_per_s'], [(s['seconds'], s['host_enqueue_seconds']) for s in j['stages']])"; done
+QARIG_GEMM_X3=1 timeout -k 10 300 python bench.py --no-side-configs --no-cpu-baseline > $O/r04x_bench_c2_x3.json 2> $O/r04x_bench_c2_x3.err; cut -c1-400 $O/r04x_bench_c2_x3.json
+timeout -k 10 300 python bench.py --no-side-configs --no-cpu-baseline > $O/r04x_bench_c2_f32.json 2> $O/r04x_bench_c2_f32.err; cut -c1-300 $O/r04x_bench_c2_f32.json
+QARIG_GEMM_X3=1 timeout -k 10 900 python -m pytest tests -m gpu -q -x > $O/r04x_pytest_x3.log 2>&1; echo "pytest rc=$?"; tail -6 $O/r04x_pytest_x3.log
