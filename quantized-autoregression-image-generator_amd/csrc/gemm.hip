@@ -815,8 +815,10 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     const bool pair_ok = dma_on && fast && vec_epi && !(a_rowsum && a_kcontig) && !(!a_kcontig && b_kcontig) &&
                          nk_block % 2 == 0 && nk_block >= 4;
     // opt-in: the products on the bf16 matrix pipe from exact three-way operand splits (gemm_x3.hip)
+    // (from 32 output tiles up: below that the two-team and 64-tile kernels are faster -- 512 x 512 over 16,384 rows:
+    //  52 against 41 TF-equivalent)
     const bool x3 = g_qarig_opt.gemm_x3 != 0 && fast && vec_epi && !(a_rowsum && a_kcontig) &&
-                    qarig_gemm_x3_ok(M, N, K, splitk);
+                    (long)tiles_m * tiles_n >= 32 && qarig_gemm_x3_ok(M, N, K, splitk);
     if (x3) {
         qarig_gemm_x3_launch(A, lda, a_kcontig, B, ldb, b_kcontig, ep, M, N, K, splitk, slabs, st);
     } else if (t64 && pair_env != 1) {    // (gemm_pair = 1 forces the two-team kernel: the cross-check of this one)
