@@ -333,17 +333,7 @@ __global__ __launch_bounds__(2 * NTHREADS, 1) void gemm_dma_pf2_kernel(const flo
 // an XCD's L2 sees neighbouring tiles of one problem.  Slab index = g * splitk + z; in "sum" mode
 // (sum_g A_g B_g^T: the input gradient of MLPs that share their input) all groups * splits slabs
 // reduce into one output.
-constexpr int GEMM_MAX_GROUPS = 16;
-struct GemmGroupPtrs {
-    const float* A[GEMM_MAX_GROUPS];
-    const float* B[GEMM_MAX_GROUPS];
-    float* C[GEMM_MAX_GROUPS];
-    const float* bias[GEMM_MAX_GROUPS];
-    const float* residual[GEMM_MAX_GROUPS];
-    float* preact[GEMM_MAX_GROUPS];
-    const float* gradz[GEMM_MAX_GROUPS];
-    float* rowsum[GEMM_MAX_GROUPS];
-};
+// (GemmGroupPtrs / GEMM_MAX_GROUPS: gemm_epilogue.h)
 
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_dma_pf_grouped_kernel(GemmGroupPtrs gp, int64_t lda,
@@ -743,6 +733,9 @@ int qarig_gemm64_launch(const float* A, int64_t lda, int a_kcontig, const float*
 extern "C" int qarig_gemm_x3_ok(int M, int N, int K, int splitk);
 int qarig_gemm_x3_launch(const float* A, int64_t lda, int a_kcontig, const float* B, int64_t ldb, int b_kcontig,
                          const GemmEpilogue& ep, int M, int N, int K, int splitk, float* slabs, hipStream_t st);
+int qarig_gemm_x3_grouped_launch(const GemmGroupPtrs& gp, int64_t lda, int a_kcontig, int64_t ldb, int b_kcontig,
+                                 const GemmEpilogue& ep, int M, int N, int K, int tiles_n, int tiles, int splitk,
+                                 float* slabs, float* rs_part, unsigned total_wg, hipStream_t st);
 
 static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float* B,
                          int64_t ldb, int b_kcontig, float* C, int64_t ldc, int M, int N,
@@ -1033,7 +1026,11 @@ extern "C" int qarig_gemm_f32_grouped(int groups, const float* const* A, int64_t
     GemmEpilogue ep{nullptr, ldc, nullptr, nullptr, accumulate && !use_slabs ? ldc : ldr, nullptr, ldp, act,
                     nullptr, ldz, gact, nullptr};
     dim3 grid((unsigned)total_wg), block(NTHREADS);
-    if (a_kcontig && b_kcontig)
+    // opt-in: the grouped products on the bf16 matrix pipe from exact three-way operand splits (gemm_x3.hip)
+    if (g_qarig_opt.gemm_x3 != 0 && (K / splitk) % 32 == 0 && total_wg >= 32)
+        qarig_gemm_x3_grouped_launch(gp, lda, a_kcontig, ldb, b_kcontig, ep, M, N, K, tiles_n, tiles, splitk, slabs,
+                                     rs_part, (unsigned)total_wg, st);
+    else if (a_kcontig && b_kcontig)
         hipLaunchKernelGGL((gemm_dma_pf_grouped_kernel<true, true>), grid, block, 0, st, gp, lda, ldb, ep, M, N, K,
                            tiles_n, tiles, splitk, slabs, rs_part);
     else if (a_kcontig)

@@ -25,6 +25,19 @@ struct GemmEpilogue {
     const float* alpha_a; const float* alpha_b;
 };
 
+// operand / output pointers of a grouped launch (gemm.hip gemm_dma_pf_grouped_kernel, gemm_x3.hip)
+constexpr int GEMM_MAX_GROUPS = 16;
+struct GemmGroupPtrs {
+    const float* A[GEMM_MAX_GROUPS];
+    const float* B[GEMM_MAX_GROUPS];
+    float* C[GEMM_MAX_GROUPS];
+    const float* bias[GEMM_MAX_GROUPS];
+    const float* residual[GEMM_MAX_GROUPS];
+    float* preact[GEMM_MAX_GROUPS];
+    const float* gradz[GEMM_MAX_GROUPS];
+    float* rowsum[GEMM_MAX_GROUPS];
+};
+
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned int hi16) { return __uint_as_float(hi16 << 16); }
 
 // two fp32 -> one dword of two bf16 (round to nearest even, v_cvt_pk_bf16_f32)

@@ -126,25 +126,17 @@ __device__ __forceinline__ void x3_store(x3_u32x4* op, const f32x4 (&f)[8], int 
     }
 }
 
+// One 128 x 128 output tile: rows m0.., columns n0.., reduction [k_begin, k_begin + nk * XK).  rs_dst: where the
+// tile's 128 row sums of A go (null: none).  ep_splitk / ep_slabs: what the epilogue is told (slabs when > 1).
 template <bool AKC, bool BKC>
-__global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict__ A, int64_t lda,
-                                                         const float* __restrict__ B, int64_t ldb, GemmEpilogue ep,
-                                                         int M, int N, int K, int tiles_n, int splitk,
-                                                         float* __restrict__ slabs) {
+__device__ __forceinline__ void x3_tile(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                        int64_t ldb, const GemmEpilogue& ep, int M, int N, int m0, int n0,
+                                        int k_begin, int nk, float* __restrict__ rs_dst, int ep_splitk,
+                                        float* __restrict__ ep_slabs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
     x3_u32x4* lds = reinterpret_cast<x3_u32x4*>(x3_smem);
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    int k_begin = 0, k_end = K;
-    if (splitk > 1) {
-        const int per = ((K + splitk - 1) / splitk + XK - 1) / XK * XK;
-        k_begin = blockIdx.z * per;
-        k_end = min(K, k_begin + per);
-    }
-    const int nk = (k_end - k_begin) / XK;
     const int wm = wave >> 1, wn = wave & 1;
     const bool stage_a = wave < 2;                // waves 0-1 stage A, 2-3 stage B (a scalar branch: `wave` is an SGPR)
     const int ts = t & 127;
@@ -152,7 +144,7 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict
     acc_zero(acc);
     // sum_k A(m, k) of this split (the bias gradient riding on a weight-gradient product: tile-contiguous A, column
     // tiles 0 only): a staging thread keeps the sums of its four rows over its k rows
-    const bool do_rs = !AKC && ep.rowsum != nullptr && tn == 0 && stage_a;
+    const bool do_rs = !AKC && rs_dst != nullptr && stage_a;
     float4 rs4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     f32x4 f[8];
@@ -176,10 +168,11 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict
     // (vector ALU, LDS writes) the others run their MFMAs -- the co-execution the bf16 MFMA allows, obtained from the
     // hardware's choice between three waves per SIMD rather than from an instruction order the compiler would have
     // to keep (measured: two stages and one workgroup per CU 88-140 TF-equivalent, one stage and two 142-167, three
-    // 147-180).  The global loads of tile kt + 1 are issued behind the split of tile kt and have the whole MFMA phase to land.
+    // 147-180).  The global loads of tile kt + 1 are issued behind the split of tile kt and have the whole MFMA phase
+    // to land.
     if (nk > 0) load(0);
-    // unit of this lane inside a (tile, k step) block of 64, for even / odd tiles (x3_pos)
-    const int fl0 = (lane >> 5) * 32 + x3_pos(0, lane & 31), fl1 = (lane >> 5) * 32 + x3_pos(1, lane & 31);
+    // unit of this lane inside a (tile, k step) block of 64 (x3_pos: the same in every tile)
+    const int fl = (lane >> 5) * 32 + x3_pos(0, lane & 31);
     const x3_u32x4* sa = lds;
     const x3_u32x4* sb = lds + X3_OP;
     for (int kt = 0; kt < nk; ++kt) {
@@ -194,8 +187,8 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    a[i][p] = __builtin_bit_cast(x3_bf16x8, sa[p * X3_PLANE + ((wm * 2 + i) * 2 + ks) * 64 + (i ? fl1 : fl0)]);
-                    b[i][p] = __builtin_bit_cast(x3_bf16x8, sb[p * X3_PLANE + ((wn * 2 + i) * 2 + ks) * 64 + (i ? fl1 : fl0)]);
+                    a[i][p] = __builtin_bit_cast(x3_bf16x8, sa[p * X3_PLANE + ((wm * 2 + i) * 2 + ks) * 64 + fl]);
+                    b[i][p] = __builtin_bit_cast(x3_bf16x8, sb[p * X3_PLANE + ((wn * 2 + i) * 2 + ks) * 64 + fl]);
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -214,16 +207,60 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict
     }
     __syncthreads();
     float* scratch = reinterpret_cast<float*>(x3_smem);
-    if (!AKC && ep.rowsum != nullptr && tn == 0) {
+    if (!AKC && rs_dst != nullptr) {
         // four staging threads (k octets o = 0..3) hold partial sums of the same four rows: summed in o order
         if (stage_a) *reinterpret_cast<float4*>(scratch + (ts >> 5) * 128 + 4 * (ts & 31)) = rs4;
         __syncthreads();
-        if (t < 128)
-            ep.rowsum[(int64_t)blockIdx.z * M + m0 + t] =
-                ((scratch[t] + scratch[128 + t]) + scratch[256 + t]) + scratch[384 + t];
+        if (t < 128) rs_dst[t] = ((scratch[t] + scratch[128 + t]) + scratch[256 + t]) + scratch[384 + t];
         __syncthreads();
     }
-    gemm_epilogue_wide<0>(acc, ep, scratch, m0, n0, M, N, splitk, slabs);
+    gemm_epilogue_wide<0>(acc, ep, scratch, m0, n0, M, N, ep_splitk, ep_slabs);
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 3) void gemm_x3_kernel(const float* __restrict__ A, int64_t lda,
+                                                         const float* __restrict__ B, int64_t ldb, GemmEpilogue ep,
+                                                         int M, int N, int K, int tiles_n, int splitk,
+                                                         float* __restrict__ slabs) {
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    int k_begin = 0, k_end = K;
+    if (splitk > 1) {
+        const int per = ((K + splitk - 1) / splitk + XK - 1) / XK * XK;
+        k_begin = blockIdx.z * per;
+        k_end = min(K, k_begin + per);
+    }
+    float* rs_dst = (ep.rowsum != nullptr && tn == 0) ? ep.rowsum + (int64_t)blockIdx.z * M + m0 : nullptr;
+    x3_tile<AKC, BKC>(A, lda, B, ldb, ep, M, N, m0, n0, k_begin, (k_end - k_begin) / XK, rs_dst, splitk, slabs);
+}
+
+// The grouped form (gemm.hip gemm_dma_pf_grouped_kernel: `groups` problems of one shape in one flat grid,
+// workgroup -> (group, reduction split, tile); slab index = g * splitk + z).
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 3) void gemm_x3_grouped_kernel(GemmGroupPtrs gp, int64_t lda, int64_t ldb,
+                                                                 GemmEpilogue ep, int M, int N, int K, int tiles_n,
+                                                                 int tiles, int splitk, float* __restrict__ slabs,
+                                                                 float* __restrict__ rs_part) {
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_g = tiles * splitk;
+    const int g = lin / per_g;
+    const int r = lin - g * per_g;
+    const int z = r / tiles;
+    const int tile = r - z * tiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int per = K / splitk;                       // host: whole 32-deep tiles per split
+    ep.C = gp.C[g];
+    ep.bias = gp.bias[g];
+    ep.residual = gp.residual[g];
+    ep.preact = gp.preact[g];
+    ep.gradz = gp.gradz[g];
+    const int slab = g * splitk + z;
+    float* my_slab = slabs ? slabs + (int64_t)slab * M * N : nullptr;
+    float* rs_dst = (rs_part != nullptr && tn == 0) ? rs_part + (int64_t)slab * M + m0 : nullptr;
+    // (1-D grid: blockIdx.z == 0, so the epilogue's slab offset is the one folded into my_slab)
+    x3_tile<AKC, BKC>(gp.A[g], lda, gp.B[g], ldb, ep, M, N, m0, n0, z * per, per / XK, rs_dst, my_slab ? 2 : 1, my_slab);
 }
 
 }  // namespace qarig
@@ -238,6 +275,27 @@ extern "C" int qarig_gemm_x3_ok(int M, int N, int K, int splitk) {
         if (K % per) return 0;
     }
     return 1;
+}
+
+int qarig_gemm_x3_grouped_launch(const GemmGroupPtrs& gp, int64_t lda, int a_kcontig, int64_t ldb, int b_kcontig,
+                                 const GemmEpilogue& ep, int M, int N, int K, int tiles_n, int tiles, int splitk,
+                                 float* slabs, float* rs_part, unsigned total_wg, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_x3_grouped_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_x3_grouped_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_x3_grouped_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+        attr_set = true;
+    }
+    const dim3 grid(total_wg), block(256);
+#define QARIG_X3G(AK, BK_)                                                                                         \
+    hipLaunchKernelGGL((gemm_x3_grouped_kernel<AK, BK_>), grid, block, X3_LDS, st, gp, lda, ldb, ep, M, N, K, tiles_n, \
+                       tiles, splitk, slabs, rs_part)
+    if (a_kcontig && b_kcontig) QARIG_X3G(true, true);
+    else if (a_kcontig) QARIG_X3G(true, false);
+    else QARIG_X3G(false, false);                  // (the host refuses the (xc, kc) layout for grouped launches)
+#undef QARIG_X3G
+    return QARIG_OK;
 }
 
 int qarig_gemm_x3_launch(const float* A, int64_t lda, int a_kcontig, const float* B, int64_t ldb, int b_kcontig,

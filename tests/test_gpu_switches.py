@@ -89,8 +89,15 @@ def test_gemm_x3_takes_the_products_and_keeps_the_fp32_tolerances(option):
     dW = ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=8, a_rowsum=rs)
     assert rel_err(dW, dT.double().t() @ X.double()) < 2e-6 * 8 ** 0.5
     assert rel_err(rs, dT.double().sum(0)) < 2e-6 * 8 ** 0.5
+    # grouped launches (q/k/v MLPs of a 2,048-row shard, their summed input gradient, their weight gradients with row
+    # sums): every epilogue against fp64, as test_gpu_grouped runs them at small sizes
+    import test_gpu_grouped as grouped
+    for args in ((3, 2048, 512, 512, True, True, 1, True), (3, 2048, 2048, 512, True, False, 1, False),
+                 (3, 512, 2048, 2048, False, False, 4, False), (14, 128, 128, 192, True, False, 3, False)):
+        grouped.test_grouped_gemm_every_epilogue_vs_fp64(*args)
     # one full train step of the golden pipeline under the option
     golden.test_train_step_matches_reference_step("base", False)
+    golden.test_train_step_matches_reference_step("encdec", True)
 
 
 @pytest.mark.parametrize("name,value", [("bmu_cs", 1), ("bmu_cs", 2), ("bmu_cs", 4), ("bmu_groups", 0),
