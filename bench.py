@@ -89,6 +89,10 @@ def parse_args(argv=None):
     ap.add_argument("--config", choices=sorted(CONFIGS) + ["c3"], default="c2",
                     help="c2 (default, the headline workload), c3 (cascade generation), or the per-GPU shard of "
                          "config 4 / 5")
+    ap.add_argument("--gemm-x3", action="store_true",
+                    help="opt-in: the fp32 Linear products on the bf16 matrix pipe from exact three-way operand splits "
+                         "(csrc/gemm_x3.hip, option gemm_x3): fp32 operands, results and tolerances, reported under its "
+                         "own dtype and workload tag")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="default c2 run on one GPU: do not append the short c3 / c4-shard / c5-shard measurements "
                          "(`configs` object)")
@@ -378,12 +382,16 @@ def run_c3(args):
 
 def side_configs():
     """The default run's `configs` object: BASELINE configs 3, 4 (per-GPU shard) and 5 (per-GPU shard) measured
-    for a few steps each, every one by this script in a child process (started after the headline measurement;
-    the parent only waits), reduced to the fields a reader compares."""
+    for a few steps each -- and configs 2 and 4 again under the opt-in kernel option gemm_x3 --, every one by this
+    script in a child process (started after the headline measurement; the parent only waits), reduced to the
+    fields a reader compares."""
     out = {}
     runs = (("c3", ["--config", "c3", "--steps", "1", "--warmup", "1"]),
             ("c4_shard", ["--config", "c4", "--steps", "6", "--warmup", "3", "--no-cpu-baseline"]),
-            ("c5_shard", ["--config", "c5", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]))
+            ("c5_shard", ["--config", "c5", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]),
+            # opt-in kernel option gemm_x3: the same fp32 workloads with the Linear products on the bf16 matrix pipe
+            ("c2_gemm_x3", ["--config", "c2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--gemm-x3"]),
+            ("c4_shard_gemm_x3", ["--config", "c4", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--gemm-x3"]))
     for name, flags in runs:
         t0 = time.perf_counter()
         try:
@@ -429,6 +437,11 @@ def main():
         cfg["batch"] = args.batch
     precision = args.precision or ("bf16" if args.config == "c5" else "f32")
     ops.set_precision(precision)
+    x3 = bool(args.gemm_x3) or os.environ.get("QARIG_GEMM_X3") == "1"
+    if x3:
+        assert precision == "f32", "--gemm-x3 is a form of the fp32 products"
+        from qarig import _lib
+        _lib.set_option("gemm_x3", 1)
     world, rank, local = parallel.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
@@ -527,6 +540,11 @@ def main():
            "fp8": " [fp8 (e4m3, per-tensor scale) MFMA on the forward x W^T products of the Linear layers, bf16 MFMA "
                   "on the backward products and in attention, f32 accumulate; NOT the fp32 parity configuration]"
            }[precision]
+    if x3:
+        dtype = "f32 operands and results; products as 6 bf16-MFMA products of exact 3-way bf16 splits (gemm_x3)"
+        tag = (" [opt-in gemm_x3: the Linear products run on the bf16 matrix pipe from exact three-way operand splits, "
+               "fp32 accumulate; same operands, epilogues and test tolerances as the fp32-MFMA kernels; NOT the "
+               "fp32-MFMA headline]")
     out = {"metric": METRIC,
            "value": round(tokens / dt, 1), "unit": "image-tokens/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -577,6 +595,8 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "gemm_traffic.json")
             default_precision = "bf16" if args.config == "c5" else "f32"      # (as profiles/summarize.py names them)
             key = args.config if precision == default_precision else f"{args.config}_{precision}"
+            if x3:
+                key += "_x3"
             tj = json.load(open(pmc)).get(key) if os.path.exists(pmc) else None
             if tj:
                 traffic = tj.get("fabric_bytes_per_launch")
@@ -594,6 +614,13 @@ def main():
                      "bf16": "qarig::gemm_lp_kernel<bf16,*> (bf16 MFMA 32x32x16, bf16 operands in HBM)",
                      "fp8": "qarig::gemm_lp_kernel<bf16,*> + gemm_f8_kernel (forward x W^T on fp8 e4m3 "
                             "MFMA 32x32x64, e4m3 operands in HBM); priced against the bf16 peak"}[precision]
+            if x3:
+                # algorithmic fp32 FLOPs against the bf16 matrix pipe's capacity for them: six bf16 products each
+                peak = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
+                kname = ("qarig::gemm_x3_kernel<*> / gemm_x3_grouped_kernel<*> (six v_mfma_f32_32x32x16_bf16 per block "
+                         "on exact 3-way bf16 splits of the fp32 operands) + the fp32-MFMA kernels on the shapes it "
+                         "does not take; peak = dense bf16 peak / 6; the fp32-MFMA peak is "
+                         f"{PEAK_F32_MFMA_TFLOPS} TFLOP/s")
             out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": round(ach, 2), "peak": peak,
                                "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -624,7 +651,7 @@ def main():
         out["bmu"] = bmu_side_measure(device)
         if not args.no_cpu_baseline and world == 1 and args.config == "c2":
             out["cpu_baseline"] = cpu_baseline(cfg)
-        if world == 1 and args.config == "c2" and not args.no_side_configs and precision == "f32":
+        if world == 1 and args.config == "c2" and not args.no_side_configs and precision == "f32" and not x3:
             out["configs"] = side_configs()
         print(json.dumps(out), flush=True)
     if world > 1:

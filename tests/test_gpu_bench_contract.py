@@ -40,7 +40,7 @@ def test_bench_line_contract():
     # the other BASELINE configurations on the same line: cascade generation (config 3), the per-GPU shards of
     # configs 4 and 5 -- a few steps each, measured by child runs of this script
     side = out["configs"]
-    assert set(side) == {"c3", "c4_shard", "c5_shard"}
+    assert set(side) == {"c3", "c4_shard", "c5_shard", "c2_gemm_x3", "c4_shard_gemm_x3"}
     for name, o in side.items():
         assert "error" not in o, (name, o)
         assert {"workload", "value", "unit", "ms_per_step", "dtype", "roofline"} <= set(o), name
@@ -55,6 +55,10 @@ def test_bench_line_contract():
     assert c3["value"] > c3["sequential_one_by_one"]["accepted_tokens_per_s"]
     assert c3["batched_beams"]["accepted_tokens_per_s"] > 0.8 * c3["value"]
     assert side["c4_shard"]["dtype"] == "f32" and side["c5_shard"]["dtype"].startswith("bf16")
+    # the opt-in gemm_x3 form of the fp32 products: its own dtype and workload tag, never the headline's
+    for name in ("c2_gemm_x3", "c4_shard_gemm_x3"):
+        assert "gemm_x3" in side[name]["dtype"] and "gemm_x3" in side[name]["workload"]
+    assert out["dtype"] == "f32" and "gemm_x3" not in out["config"]["workload"]
     assert side["c4_shard"]["roofline"]["bound"] == side["c5_shard"]["roofline"]["bound"] == "mfma"
 
 

@@ -10,6 +10,9 @@ step 200 $O/${TAG}_smoke.log python -c "import __graft_entry__ as g; g.smoke(); 
 step 400 $O/${TAG}_bench_c2.json python bench.py; cut -c1-330 $O/${TAG}_bench_c2.json
 step 300 $O/${TAG}_bench_c4.json python bench.py --config c4 --steps 10 --warmup 3 --no-cpu-baseline; cut -c1-330 $O/${TAG}_bench_c4.json
 step 400 $O/${TAG}_bench_c5.json python bench.py --config c5 --steps 10 --warmup 3 --no-cpu-baseline; cut -c1-330 $O/${TAG}_bench_c5.json
+step 300 $O/${TAG}_bench_c2_gemm_x3.json python bench.py --gemm-x3 --no-side-configs --no-cpu-baseline; cut -c1-330 $O/${TAG}_bench_c2_gemm_x3.json
+step 300 $O/${TAG}_bench_c4_gemm_x3.json python bench.py --config c4 --gemm-x3 --steps 10 --warmup 3 --no-cpu-baseline; cut -c1-330 $O/${TAG}_bench_c4_gemm_x3.json
+step 300 $O/${TAG}_gemm_x3_sweep.log env SWEEP=gemm_x3=0,1 python tools/gemm_bench.py; tail -10 $O/${TAG}_gemm_x3_sweep.log
 step 400 $O/${TAG}_bench_c3.json python bench.py --config c3 --steps 1 --warmup 1; cut -c1-330 $O/${TAG}_bench_c3.json
 step 300 $O/${TAG}_generate_c3_sequential.json python tools/bench_generate.py; cat $O/${TAG}_generate_c3_sequential.json
 step 300 $O/${TAG}_generate_c3_one_by_one.json python tools/bench_generate.py --one-by-one; cat $O/${TAG}_generate_c3_one_by_one.json
