@@ -370,11 +370,12 @@ def check_waitcnt(name, code, labels):
                                 continue
                             found.setdefault((i, e), f"R3 {name}: `{ins.text}` @{ins.addr} touches the destination "
                                                      f"of `{p.text}` @{p.addr} before an s_waitcnt retired it")
+            # (counts saturate at 64: s_waitcnt cannot name more, and a bounded count bounds the iteration)
             if ins.vm:
-                vm = {e: c + 1 for e, c in vm.items()}
+                vm = {e: min(c + 1, 64) for e, c in vm.items()}
                 vm[i] = 0
             if ins.lgkm:
-                lg = {e: c + 1 for e, c in lg.items()}
+                lg = {e: min(c + 1, 64) for e, c in lg.items()}
                 lg[i] = 0
         last = code[ends[bi] - 1]
         out = []
@@ -413,7 +414,7 @@ def check_waitcnt(name, code, labels):
         node = work.pop()
         queued.discard(node)
         rounds += 1
-        if rounds > 400 * len(leaders) + 2000:
+        if rounds > 4000 * len(leaders) + 2000:
             return [f"R3 {name}: the data-flow iteration did not converge"]
         vm, lg, out = transfer(node[0], state[node][0], state[node][1], node[1], False)
         for sj, f in out:
