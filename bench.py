@@ -391,7 +391,7 @@ def side_configs():
             ("c5_shard", ["--config", "c5", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]),
             # opt-in kernel option gemm_x3: the same fp32 workloads with the Linear products on the bf16 matrix pipe
             ("c2_gemm_x3", ["--config", "c2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--gemm-x3"]),
-            ("c4_shard_gemm_x3", ["--config", "c4", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--gemm-x3"]))
+            ("c4_shard_gemm_x3", ["--config", "c4", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--gemm-x3"]))
     for name, flags in runs:
         t0 = time.perf_counter()
         try:
