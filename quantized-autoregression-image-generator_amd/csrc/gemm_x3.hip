@@ -269,9 +269,9 @@ using namespace qarig;
 
 // shapes the kernel takes: whole 128 x 128 tiles, whole 32-deep k-tiles per split, 16-B aligned operands and rows
 extern "C" int qarig_gemm_x3_ok(int M, int N, int K, int splitk) {
-    if (M < 128 || N < 128 || K < XK || M % BM || N % BN || K % XK) return 0;
+    if (M < 128 || N < 128 || K < XK || M % BM || N % BN || K % XK || splitk > K) return 0;
     if (splitk > 1) {
-        const int per = ((K + splitk - 1) / splitk + XK - 1) / XK * XK;
+        const long per = (((long)K + splitk - 1) / splitk + XK - 1) / XK * XK;
         if (K % per) return 0;
     }
     return 1;
