@@ -118,6 +118,7 @@ def main():
                 recon = decoder_model(hr_codebook.get_quantized_image(indices=all_tokens, unpatchify_input=True))
                 ops.check_index_flag(device, f"stage {index} tokens")
                 save_images(images=recon, file_name=f"recon_model_{index}", dest_path=out_dir, logging=print)
+        sampling.decode_cache_clear()        # (the stage's decode caches hold its model: let both go, as the reference does)
         del model
         torch.cuda.empty_cache()
 
