@@ -171,6 +171,14 @@ def test_cli_pipeline(tmp_path):
     assert 0.0 < final < 10.0          # (weights are drawn unseeded: only sanity here; bit-equality
     #                                     with the eager step is tests/test_gpu_dp.py's graphed test)
 
+    # --gemm-x3 (additive): the flag reaches the library option (the tiny products of this run stay on the fp32
+    # kernels; the kernel's parity is tests/test_gpu_switches.py)
+    out_x = run("train_quantized_transformer.py", *common, "--train-base-model", "--lr-codebook-path",
+                f"{t}/cb_lr/models_checkpoint/codebook_2.pt", "--hr-codebook-path",
+                f"{t}/cb_mid/models_checkpoint/codebook_2.pt", "--config-path", f"{t}/t_base.json",
+                "--out-dir", f"{t}/t_base_x3", "--gemm-x3", "--max-steps", 1, cwd=t)
+    assert "Cum. Steps: 1" in out_x
+
     tcfg2 = dict(tcfg, use_sliding_window=True, sliding_window=32)
     json.dump(tcfg2, open(f"{t}/t_s1.json", "w"))
     out = run("train_quantized_transformer.py", *common, "--lr-codebook-path",
