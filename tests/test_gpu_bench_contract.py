@@ -17,6 +17,7 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 
 def test_bench_line_contract():
     env = dict(os.environ, QARIG_CPU_BASELINE_SECONDS="2")
+    env.pop("QARIG_GEMM_X3", None)      # (the suite may run under the option; the line under test is the default one)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
