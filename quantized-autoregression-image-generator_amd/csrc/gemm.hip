@@ -733,6 +733,9 @@ int qarig_gemm64_launch(const float* A, int64_t lda, int a_kcontig, const float*
 extern "C" int qarig_gemm_x3_ok(int M, int N, int K, int splitk);
 int qarig_gemm_x3_launch(const float* A, int64_t lda, int a_kcontig, const float* B, int64_t ldb, int b_kcontig,
                          const GemmEpilogue& ep, int M, int N, int K, int splitk, float* slabs, hipStream_t st);
+int qarig_gemm_x3_half_ok(int M, int N, int K, int splitk);
+int qarig_gemm_x3_half_launch(const float* A, int64_t lda, int a_kcontig, const float* B, int64_t ldb, int b_kcontig,
+                              const GemmEpilogue& ep, int M, int N, int K, int splitk, float* slabs, hipStream_t st);
 int qarig_gemm_x3_grouped_launch(const GemmGroupPtrs& gp, int64_t lda, int a_kcontig, int64_t ldb, int b_kcontig,
                                  const GemmEpilogue& ep, int M, int N, int K, int tiles_n, int tiles, int splitk,
                                  float* slabs, float* rs_part, unsigned total_wg, hipStream_t st);
@@ -812,7 +815,15 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     //  52 against 41 TF-equivalent)
     const bool x3 = g_qarig_opt.gemm_x3 != 0 && fast && vec_epi && !(a_rowsum && a_kcontig) &&
                     (long)tiles_m * tiles_n >= 32 && qarig_gemm_x3_ok(M, N, K, splitk);
-    if (x3) {
+    // ... on 64 x 64 tiles where 128 x 128 tiles would leave most of the chip idle
+    // (fewer than 192 workgroups of 128 x 128 tiles, reduction splits counted: a weight gradient of 64 tiles x 16
+    //  splits fills the chip with the larger tile, whose split work per MFMA is half)
+    const bool x3h = g_qarig_opt.gemm_x3 != 0 && va && vb && vec_epi && !(a_rowsum && a_kcontig) &&
+                     (long)tiles_m * tiles_n * splitk < 192 && (long)(M / 64) * (N / 64) * splitk >= 32 &&
+                     qarig_gemm_x3_half_ok(M, N, K, splitk);
+    if (x3h) {
+        qarig_gemm_x3_half_launch(A, lda, a_kcontig, B, ldb, b_kcontig, ep, M, N, K, splitk, slabs, st);
+    } else if (x3) {
         qarig_gemm_x3_launch(A, lda, a_kcontig, B, ldb, b_kcontig, ep, M, N, K, splitk, slabs, st);
     } else if (t64 && pair_env != 1) {    // (gemm_pair = 1 forces the two-team kernel: the cross-check of this one)
         qarig_gemm64_launch(A, lda, a_kcontig, B, ldb, b_kcontig, ep, M, N, K, splitk, slabs, st);

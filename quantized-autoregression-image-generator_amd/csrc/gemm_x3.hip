@@ -82,6 +82,7 @@ __device__ __forceinline__ void x3_load(f32x4 (&f)[8], const float* __restrict__
 //     at 16384 x 512 x 2048).
 __device__ __forceinline__ int x3_pos(int tile, int r) { return r ^ ((r >> 2) & 2) ^ (r >> 4); }
 
+template <int PL = X3_PLANE>
 __device__ __forceinline__ void x3_put(x3_u32x4* op, int unit, const float (&v)[8]) {
     x3_u32x4 H, M, L;
 #pragma unroll
@@ -91,8 +92,8 @@ __device__ __forceinline__ void x3_put(x3_u32x4* op, int unit, const float (&v)[
         H[q] = h; M[q] = m; L[q] = l;
     }
     op[unit] = H;
-    op[X3_PLANE + unit] = M;
-    op[2 * X3_PLANE + unit] = L;
+    op[PL + unit] = M;
+    op[2 * PL + unit] = L;
 }
 template <bool KC>
 __device__ __forceinline__ void x3_store(x3_u32x4* op, const f32x4 (&f)[8], int t) {
@@ -263,9 +264,170 @@ __global__ __launch_bounds__(256, 3) void gemm_x3_grouped_kernel(GemmGroupPtrs g
     x3_tile<AKC, BKC>(gp.A[g], lda, gp.B[g], ldb, ep, M, N, m0, n0, z * per, per / XK, rs_dst, my_slab ? 2 : 1, my_slab);
 }
 
+
+// ---- the 64 x 64-tile form: products whose 128 x 128 tiling leaves most of the chip idle (a 2,048-row shard's
+// 512 -> 512 Linear products: 64 tiles of 128, 256 of 64).  Same pieces, units, swizzle and MFMA order; a wave owns one
+// 32 x 32 accumulator; an operand tile is 64 rows x 32 k = 16 values per staging thread:
+//   KC ([X][K]): thread (row = t & 63, h = t >> 6): 4 16-B loads, k = 16 h .. 16 h + 15 -> the octets 2h, 2h + 1
+//   XC ([K][X]): thread (q = t & 31, o = t >> 5): 8 8-B loads, rows 2q, 2q + 1 at k = 8 o + j -> octet o of both rows
+constexpr int X3H_PLANE = 2 * 2 * 2 * 32;     // units of one piece of one 64-row operand tile
+constexpr int X3H_OP = 3 * X3H_PLANE;         // 12 KB
+constexpr int X3H_LDS = 2 * X3H_OP * 16;      // 24 KB: A then B
+
+template <bool KC>
+__device__ __forceinline__ void x3h_load(f32x4 (&f)[4], const float* __restrict__ P, int64_t ld, int x0, int k0, int t) {
+    if (KC) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(P + (int64_t)(x0 + (t & 63)) * ld + k0 + 16 * (t >> 6));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = p[j];
+    } else {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const float* p = P + (int64_t)(k0 + 8 * (t >> 5)) * ld + x0 + 2 * (t & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                     // f[j] = (rows 2q, 2q+1 at k 2j), (the same at k 2j + 1)
+            const f32x2 a = *reinterpret_cast<const f32x2*>(p + (int64_t)(2 * j) * ld);
+            const f32x2 b = *reinterpret_cast<const f32x2*>(p + (int64_t)(2 * j + 1) * ld);
+            f[j] = f32x4{a[0], a[1], b[0], b[1]};
+        }
+    }
+}
+template <bool KC>
+__device__ __forceinline__ void x3h_store(x3_u32x4* op, const f32x4 (&f)[4], int t) {
+    if (KC) {
+        const int row = t & 63, h = t >> 6, tile = row >> 5, r = row & 31;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float v[8] = {f[2 * u][0], f[2 * u][1], f[2 * u][2], f[2 * u][3],
+                                f[2 * u + 1][0], f[2 * u + 1][1], f[2 * u + 1][2], f[2 * u + 1][3]};
+            x3_put<X3H_PLANE>(op, (tile * 4 + 2 * h + u) * 32 + x3_pos(tile, r), v);
+        }
+    } else {
+        const int q = t & 31, o = t >> 5, tile = q >> 4, r0 = (2 * q) & 31;
+        {
+            const float v[8] = {f[0][0], f[0][2], f[1][0], f[1][2], f[2][0], f[2][2], f[3][0], f[3][2]};
+            x3_put<X3H_PLANE>(op, (tile * 4 + o) * 32 + x3_pos(tile, r0), v);
+        }
+        {
+            const float v[8] = {f[0][1], f[0][3], f[1][1], f[1][3], f[2][1], f[2][3], f[3][1], f[3][3]};
+            x3_put<X3H_PLANE>(op, (tile * 4 + o) * 32 + x3_pos(tile, r0 + 1), v);
+        }
+    }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 4) void gemm_x3_half_kernel(const float* __restrict__ A, int64_t lda,
+                                                              const float* __restrict__ B, int64_t ldb,
+                                                              GemmEpilogue ep, int M, int N, int K, int tiles_n,
+                                                              int splitk, float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
+    x3_u32x4* lds = reinterpret_cast<x3_u32x4*>(x3_smem);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * 64, n0 = tn * 64;
+    int k_begin = 0, k_end = K;
+    if (splitk > 1) {
+        const int per = ((K + splitk - 1) / splitk + XK - 1) / XK * XK;
+        k_begin = blockIdx.z * per;
+        k_end = min(K, k_begin + per);
+    }
+    const int nk = (k_end - k_begin) / XK;
+    const int wm = wave >> 1, wn = wave & 1;
+    const bool stage_a = wave < 2;
+    const int ts = t & 127;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const bool want_rs = !AKC && ep.rowsum != nullptr && tn == 0;
+    const bool do_rs = want_rs && stage_a;
+    float rs0 = 0.0f, rs1 = 0.0f;           // rows 2q, 2q + 1 over this thread's k rows
+
+    f32x4 f[4];
+    auto load = [&](int kt) {
+        const int k0 = k_begin + kt * XK;
+        if (stage_a) x3h_load<AKC>(f, A, lda, m0, k0, ts);
+        else x3h_load<BKC>(f, B, ldb, n0, k0, ts);
+    };
+    auto store = [&]() {
+        if (stage_a) {
+            if (do_rs) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { rs0 += f[j][0] + f[j][2]; rs1 += f[j][1] + f[j][3]; }
+            }
+            x3h_store<AKC>(lds, f, ts);
+        } else {
+            x3h_store<BKC>(lds + X3H_OP, f, ts);
+        }
+    };
+    if (nk > 0) load(0);
+    const int fl = (lane >> 5) * 32 + x3_pos(0, lane & 31);
+    const x3_u32x4* sa = lds;
+    const x3_u32x4* sb = lds + X3H_OP;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        store();
+        if (kt + 1 < nk) load(kt + 1);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            x3_bf16x8 a[3], b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[p] = __builtin_bit_cast(x3_bf16x8, sa[p * X3H_PLANE + (wm * 2 + ks) * 64 + fl]);
+                b[p] = __builtin_bit_cast(x3_bf16x8, sb[p * X3H_PLANE + (wn * 2 + ks) * 64 + fl]);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);      // small products first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* scratch = reinterpret_cast<float*>(x3_smem);
+    if (want_rs) {
+        // four staging threads (k octets o = 0..3) hold partial sums of the same two rows: summed in o order
+        if (stage_a) { scratch[(ts >> 5) * 64 + 2 * (ts & 31)] = rs0; scratch[(ts >> 5) * 64 + 2 * (ts & 31) + 1] = rs1; }
+        __syncthreads();
+        if (t < 64)
+            ep.rowsum[(int64_t)blockIdx.z * M + m0 + t] = ((scratch[t] + scratch[64 + t]) + scratch[128 + t]) + scratch[192 + t];
+        __syncthreads();
+    }
+    Acc one;
+    one.t[0][0] = acc;
+    gemm_epilogue_wave<1, Acc, 0>(one, ep, scratch + wave * (32 * 32), m0 + wm * 32, n0 + wn * 32, M, N, splitk, slabs, 0, 1);
+}
+
 }  // namespace qarig
 
 using namespace qarig;
+
+// the 64 x 64-tile form: whole 64-tiles and 32-deep k-tiles per split, fewer than 192 tiles of 128 x 128
+int qarig_gemm_x3_half_ok(int M, int N, int K, int splitk) {
+    if (M < 64 || N < 64 || K < XK || M % 64 || N % 64 || K % XK || splitk > K || splitk < 1) return 0;
+    if (splitk > 1) {
+        const long per = (((long)K + splitk - 1) / splitk + XK - 1) / XK * XK;
+        if (K % per) return 0;
+    }
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    return t128 < 192;
+}
+
+int qarig_gemm_x3_half_launch(const float* A, int64_t lda, int a_kcontig, const float* B, int64_t ldb, int b_kcontig,
+                              const GemmEpilogue& ep, int M, int N, int K, int splitk, float* slabs, hipStream_t st) {
+    const int tiles_n = N / 64;
+    const dim3 grid((M / 64) * tiles_n, 1, splitk), block(256);
+#define QARIG_X3H(AK, BK_)                                                                                         \
+    hipLaunchKernelGGL((gemm_x3_half_kernel<AK, BK_>), grid, block, X3H_LDS, st, A, lda, B, ldb, ep, M, N, K, tiles_n, splitk, slabs)
+    if (a_kcontig && b_kcontig) QARIG_X3H(true, true);
+    else if (a_kcontig) QARIG_X3H(true, false);
+    else if (b_kcontig) QARIG_X3H(false, true);
+    else QARIG_X3H(false, false);
+#undef QARIG_X3H
+    return QARIG_OK;
+}
 
 // shapes the kernel takes: whole 128 x 128 tiles, whole 32-deep k-tiles per split, 16-B aligned operands and rows
 extern "C" int qarig_gemm_x3_ok(int M, int N, int K, int splitk) {

@@ -60,9 +60,13 @@ def test_gemm_x3_takes_the_products_and_keeps_the_fp32_tolerances(option):
     lib = _lib.load()
     assert lib.qarig_gemm_x3_ok(2048, 512, 512, 1) == 1 and lib.qarig_gemm_x3_ok(2048, 512, 520, 1) == 0
     assert lib.qarig_gemm_x3_ok(2000, 512, 512, 1) == 0 and lib.qarig_gemm_x3_ok(512, 2048, 16384, 8) == 1
+    # (products of fewer than 192 tiles of 128 x 128 take the 64 x 64-tile form, the others the 128 x 128 one;
+    #  the last: too few workgroups, not taken)
     for (M, N, K, ak, bk, sk) in ((2048, 512, 512, True, True, 1), (1024, 2048, 2048, True, False, 1),
                                   (512, 2048, 4096, False, False, 8), (1024, 512, 8192, False, True, 4),
-                                  (128, 128, 32, True, True, 1)):       # (the last: under 32 tiles, not taken)
+                                  (4096, 2048, 512, True, True, 1), (2048, 4096, 1024, True, False, 1),
+                                  (2048, 2048, 2048, False, False, 2), (192, 320, 96, False, False, 1),
+                                  (128, 128, 32, True, True, 1)):
         A = torch.randn((M, K) if ak else (K, M), generator=g).cuda()
         B = (torch.randn((N, K) if bk else (K, N), generator=g) * 0.05).cuda()
         bias = torch.randn(N, generator=g).cuda()
@@ -77,10 +81,10 @@ def test_gemm_x3_takes_the_products_and_keeps_the_fp32_tolerances(option):
             if sk == 1:
                 y = ops.gemm(A, B, a_kcontig=ak, b_kcontig=bk, bias=bias, residual=res, act=ops.act_id("silu"))
                 assert rel_err(y, torch.nn.functional.silu(want + bias.double() + res.double())) < tol
-        if (M // 128) * (N // 128) >= 32:
-            assert not torch.equal(outs[0], outs[1])
-        else:
-            assert torch.equal(outs[0], outs[1])
+        t128 = -(-M // 128) * -(-N // 128)
+        half = t128 * sk < 192 and (M // 64) * (N // 64) * sk >= 32
+        full = M % 128 == 0 and N % 128 == 0 and t128 >= 32
+        assert torch.equal(outs[0], outs[1]) == (not (half or full)), (M, N, K)
     # the bias gradient riding on a weight-gradient product (tile-contiguous A)
     option("gemm_x3", 1)
     dT = torch.randn((4096, 512), generator=g).cuda()
@@ -89,6 +93,12 @@ def test_gemm_x3_takes_the_products_and_keeps_the_fp32_tolerances(option):
     dW = ops.gemm(dT, X, a_kcontig=False, b_kcontig=False, splitk=8, a_rowsum=rs)
     assert rel_err(dW, dT.double().t() @ X.double()) < 2e-6 * 8 ** 0.5
     assert rel_err(rs, dT.double().sum(0)) < 2e-6 * 8 ** 0.5
+    dT2 = torch.randn((2048, 2048), generator=g).cuda()             # ... and on the 128 x 128-tile form (256 tiles)
+    X2 = torch.randn((2048, 2048), generator=g).cuda()
+    rs2 = torch.zeros(2048, device="cuda")
+    dW2 = ops.gemm(dT2, X2, a_kcontig=False, b_kcontig=False, splitk=2, a_rowsum=rs2)
+    assert rel_err(dW2, dT2.double().t() @ X2.double()) < 2e-6 * 4 ** 0.5
+    assert rel_err(rs2, dT2.double().sum(0)) < 2e-6 * 4 ** 0.5
     # grouped launches (q/k/v MLPs of a 2,048-row shard, their summed input gradient, their weight gradients with row
     # sums): every epilogue against fp64, as test_gpu_grouped runs them at small sizes
     import test_gpu_grouped as grouped

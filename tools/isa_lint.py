@@ -475,10 +475,16 @@ def check_m0(name, code):
     return findings
 
 
-def lint(so_path, only=None):
+def _lint_one(job):
+    name, code, labels = job
+    return check_hazards(name, code, labels) + check_waitcnt(name, code, labels) + check_m0(name, code)
+
+
+def lint(so_path, only=None, workers=None):
     with tempfile.TemporaryDirectory() as wd:
         funcs, labels = disassemble(so_path, wd)
     findings, stats = [], {"kernels": 0, "instructions": 0, "mfma": 0, "lds_dma": 0, "asm_style_loads": 0}
+    jobs = []
     for name, code in funcs.items():
         if only and only not in name:
             continue
@@ -487,10 +493,19 @@ def lint(so_path, only=None):
         stats["mfma"] += sum(1 for c in code if c.mfma)
         stats["lds_dma"] += sum(1 for c in code if _is_dma(c))
         stats["asm_style_loads"] += sum(1 for c in code if _asm_form_dma(c))
-        findings += check_hazards(name, code, labels[name])
-        findings += check_waitcnt(name, code, labels[name])
-        findings += check_m0(name, code)
-    return findings, stats
+        jobs.append((name, code, labels[name]))
+    # the kernels are independent and the walk is pure Python: one process per core, largest kernels first
+    jobs.sort(key=lambda j: -len(j[1]))
+    workers = workers or min(len(jobs), os.cpu_count() or 1, 8)
+    if workers > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            for f in pool.imap_unordered(_lint_one, jobs):
+                findings += f
+    else:
+        for j in jobs:
+            findings += _lint_one(j)
+    return sorted(findings), stats
 
 
 if __name__ == "__main__":
