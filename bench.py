@@ -437,11 +437,11 @@ def main():
         cfg["batch"] = args.batch
     precision = args.precision or ("bf16" if args.config == "c5" else "f32")
     ops.set_precision(precision)
-    x3 = bool(args.gemm_x3) or os.environ.get("QARIG_GEMM_X3") == "1"
+    x3 = bool(args.gemm_x3) or os.environ.get("QARIG_GEMM_X3", "0") not in ("", "0")
     if x3:
         assert precision == "f32", "--gemm-x3 is a form of the fp32 products"
         from qarig import _lib
-        _lib.set_option("gemm_x3", 1)
+        _lib.set_option("gemm_x3", int(os.environ.get("QARIG_GEMM_X3", "1")) or 1)    # (2: the 128-tile form only)
     world, rank, local = parallel.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"

@@ -818,7 +818,7 @@ static int gemm_dispatch(const float* A, int64_t lda, int a_kcontig, const float
     // ... on 64 x 64 tiles where 128 x 128 tiles would leave most of the chip idle
     // (fewer than 192 workgroups of 128 x 128 tiles, reduction splits counted: a weight gradient of 64 tiles x 16
     //  splits fills the chip with the larger tile, whose split work per MFMA is half)
-    const bool x3h = g_qarig_opt.gemm_x3 != 0 && va && vb && vec_epi && !(a_rowsum && a_kcontig) &&
+    const bool x3h = g_qarig_opt.gemm_x3 == 1 && va && vb && vec_epi && !(a_rowsum && a_kcontig) &&
                      (long)tiles_m * tiles_n * splitk < 192 && (long)(M / 64) * (N / 64) * splitk >= 32 &&
                      qarig_gemm_x3_half_ok(M, N, K, splitk);
     if (x3h) {

@@ -47,6 +47,7 @@ struct QarigOptions {
     int lp_mfma16 = 1;     // reduced precision, v_mfma_f32_16x16x32_bf16 (1) or 32x32x16 (0)
     int convt_pair = 1;    // ConvTranspose parity classes paired per workgroup where a class is < 512 workgroups
     int gemm_x3 = 0;       // fp32 GEMMs as six bf16-MFMA products of exact three-way operand splits (gemm_x3.hip): opt-in
+                           // (1: 128 x 128 and 64 x 64 tiles; 2: the 128 x 128-tile form only -- the A/B of the other)
     int gemm_tile64 = -1;  // 64 x 64-tile GEMM: -1 auto (fewer than 192 tiles of 128 x 128), 0 never, 1 wherever eligible
     int decode_rows = 1;   // 5 ... 16-row decode Linear layers: rows split over the waves (1) or all rows in every lane (0)
     int decode_stream = 1; // decode-step Linear layers of <= 16 rows on decode_linear_kernel (1) or gemm_skinny_kernel (0)
